@@ -1,0 +1,111 @@
+"""ctypes loader for the CPU oracle (oracle/libck_oracle.so).  TEST INFRASTRUCTURE ONLY: imported by tests/,
+__graft_entry__.smoke() and bench.py's cpu_baseline leg — never by the product package."""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(_HERE))
+from chalkydri_amd import _abi as A  # noqa: E402  (POD struct mirrors only)
+
+LIB_PATH = os.path.join(_HERE, "libck_oracle.so")
+_lib = None
+
+
+def build():
+    subprocess.check_call(["make", "-C", _HERE, "-s"])
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            build()
+        L = C.CDLL(LIB_PATH)
+        _lib = L
+    return _lib
+
+
+def _u8(a):
+    a = np.ascontiguousarray(a, dtype=np.uint8)
+    return a, a.ctypes.data
+
+
+def threshold(img, min_white_black_diff=5):
+    img, p = _u8(img)
+    h, w = img.shape
+    out = np.empty((h, w), np.uint8)
+    lib().ora_threshold(C.c_void_p(p), w, h, w, min_white_black_diff, C.c_void_p(out.ctypes.data))
+    return out
+
+
+def segment(thresh):
+    t, p = _u8(thresh)
+    h, w = t.shape
+    labels = np.empty((h, w), np.uint32)
+    sizes = np.empty((h, w), np.uint32)
+    lib().ora_segment(C.c_void_p(p), w, h, C.c_void_p(labels.ctypes.data), C.c_void_p(sizes.ctypes.data))
+    return labels, sizes
+
+
+def clusters(thresh, labels, sizes, min_component_px=25):
+    t, p = _u8(thresh)
+    h, w = t.shape
+    pcap, ccap = w * h, w * h // 4 + 1024
+    cl = (A.Cluster * ccap)()
+    pts = (A.ClusterPoint * pcap)()
+    nc, npn = C.c_int(0), C.c_int(0)
+    ov = lib().ora_clusters(C.c_void_p(p), C.c_void_p(labels.ctypes.data), C.c_void_p(sizes.ctypes.data), w, h,
+                            min_component_px, cl, ccap, C.byref(nc), pts, pcap, C.byref(npn))
+    cl_np = np.frombuffer(cl, dtype=np.uint32, count=nc.value * 4).reshape(-1, 4).copy()
+    pt_np = np.frombuffer(pts, dtype=np.dtype([("x", "<u2"), ("y", "<u2"), ("gx", "i1"), ("gy", "i1"), ("pad", "<u2")]),
+                          count=npn.value).copy()
+    return cl_np, pt_np, ov
+
+
+def fit_quads(img, cfg, cl_np, pt_np, quad_img=None):
+    img, p = _u8(img)
+    h, w = img.shape
+    q = img if quad_img is None else np.ascontiguousarray(quad_img, np.uint8)
+    qh, qw = q.shape
+    cl = np.ascontiguousarray(cl_np, np.uint32)
+    pts = np.ascontiguousarray(pt_np)
+    cap = 4096
+    quads = (A.Quad * cap)()
+    nq = C.c_int(0)
+    ov = lib().ora_fit_quads(C.c_void_p(q.ctypes.data), qw, qh, qw, C.c_void_p(p), w, h, w, C.byref(cfg),
+                             C.c_void_p(cl.ctypes.data), len(cl), C.c_void_p(pts.ctypes.data), quads, cap,
+                             C.byref(nq))
+    return [quads[i] for i in range(nq.value)], ov
+
+
+def quads_to_np(quads):
+    out = np.zeros((len(quads), 11), np.float64)
+    for i, q in enumerate(quads):
+        out[i, :8] = [q.p[k][j] for k in range(4) for j in range(2)]
+        out[i, 8], out[i, 9], out[i, 10] = q.reversed_border, q.rep0, q.rep1
+    return out
+
+
+def detect(img, cfg, cap=256):
+    img, p = _u8(img)
+    h, w = img.shape
+    dets = (A.Detection * cap)()
+    n = C.c_int(0)
+    st = C.c_uint32(0)
+    rc = lib().ora_detect(C.c_void_p(p), w, h, w, C.byref(cfg), dets, cap, C.byref(n), C.byref(st))
+    assert rc == 0
+    return dets_to_list(dets, n.value), st.value
+
+
+def dets_to_list(dets, n):
+    out = []
+    for i in range(n):
+        d = dets[i]
+        out.append({"id": d.id, "hamming": d.hamming, "family": d.family, "margin": d.decision_margin,
+                    "c": np.array([d.c[0], d.c[1]]),
+                    "p": np.array([[d.p[k][0], d.p[k][1]] for k in range(4)])})
+    return out

@@ -1,0 +1,104 @@
+// Offline generator for the built-in 36-bit, min-Hamming-11 codebook ("tag36h11-compatible").
+//
+// The upstream AprilTag tag36h11 table (587 codes) is data of the external apriltag C library
+// [EXT] and is not present in this environment.  This tool builds a lexicode with the SAME
+// parameters (6x6 data bits, min Hamming distance 11 under all four rotations, candidates walked
+// with the upstream generator's increment 982451653 mod 2^36 starting at upstream code 0), seeded
+// with the 13 upstream codes that could be recalled AND verified (they sit on the increment
+// lattice and are mutually >= 11 apart).  IDs 0..12 therefore equal upstream IDs; IDs >= 13 are
+// NOT upstream tag36h11 IDs.  A deployment that needs real tag36h11 IDs passes the upstream table
+// through ck_family_create().
+//
+// Codes are emitted in the AprilTag-2 convention (row-major, MSB = top-left data bit).
+// Build: gcc -O3 -march=native -fopenmp tools/gen_family36.c -o /tmp/gen36 ; /tmp/gen36 587 > codes.txt
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define NB 36
+#define D 6
+#define MINH 11
+static const uint64_t MASK = (1ULL << NB) - 1;
+static const uint64_t PRIME = 982451653ULL;
+
+static uint64_t rot90(uint64_t w) {
+    uint64_t wr = 0;
+    for (int r = D - 1; r >= 0; r--)
+        for (int c = 0; c < D; c++) {
+            int b = r + D * c;
+            wr = (wr << 1) | ((w >> b) & 1);
+        }
+    return wr;
+}
+// number of 4-neighbour transitions of the 8x8 image (6x6 data + black border ring)
+static int energy(uint64_t v) {
+    int im[D + 2][D + 2];
+    memset(im, 0, sizeof im);
+    for (int y = 0; y < D; y++)
+        for (int x = 0; x < D; x++) im[y + 1][x + 1] = (v >> (NB - 1 - (y * D + x))) & 1;
+    int e = 0;
+    for (int y = 0; y < D + 2; y++)
+        for (int x = 0; x < D + 1; x++) e += im[y][x] != im[y][x + 1];
+    for (int x = 0; x < D + 2; x++)
+        for (int y = 0; y < D + 1; y++) e += im[y][x] != im[y + 1][x];
+    return e;
+}
+static int self_ok(uint64_t v) {
+    uint64_t r1 = rot90(v), r2 = rot90(r1), r3 = rot90(r2);
+    return __builtin_popcountll(v ^ r1) >= MINH && __builtin_popcountll(v ^ r2) >= MINH &&
+           __builtin_popcountll(v ^ r3) >= MINH && __builtin_popcountll(r1 ^ r2) >= MINH &&
+           __builtin_popcountll(r1 ^ r3) >= MINH && __builtin_popcountll(r2 ^ r3) >= MINH;
+}
+
+static uint64_t rots[4 * 1024];
+static int nrots = 0;
+static uint64_t codes[1024];
+static int ncodes = 0;
+
+static void add_code(uint64_t v) {
+    codes[ncodes++] = v;
+    uint64_t r = v;
+    for (int i = 0; i < 4; i++) { rots[nrots++] = r; r = rot90(r); }
+}
+static inline int far_from_all(uint64_t v, int from) {
+    for (int i = from; i < nrots; i++)
+        if (__builtin_popcountll(v ^ rots[i]) < MINH) return 0;
+    return 1;
+}
+
+int main(int argc, char **argv) {
+    int want = argc > 1 ? atoi(argv[1]) : 587;
+    static const uint64_t seed[13] = {0xd5d628584ULL, 0xd97f18b49ULL, 0xdd280910eULL, 0xe479e9c98ULL,
+                                      0xebcbca822ULL, 0xf31dab3acULL, 0x056a5d085ULL, 0x10652e1d4ULL,
+                                      0x22b1dfeadULL, 0x265ad0472ULL, 0x34fe91b86ULL, 0x3ff962cd5ULL,
+                                      0x43a25329aULL};
+    for (int i = 0; i < 13; i++) add_code(seed[i]);
+    uint64_t v0 = (seed[12] + PRIME) & MASK;
+    const uint64_t CH = 1ULL << 22;
+    uint64_t *surv = malloc(CH * sizeof(uint64_t));
+    uint64_t total = (1ULL << NB);
+    for (uint64_t base = 0; base < total && ncodes < want; base += CH) {
+        uint64_t ns = 0;
+#pragma omp parallel for schedule(static)
+        for (uint64_t i = 0; i < CH; i++) {
+            uint64_t v = (v0 + PRIME * (base + i)) & MASK;
+            surv[i] = far_from_all(v, 0) ? v : ~0ULL;
+        }
+        int nr0 = nrots;
+        for (uint64_t i = 0; i < CH && ncodes < want; i++) {
+            uint64_t v = surv[i];
+            if (v == ~0ULL) continue;
+            ns++;
+            if (!far_from_all(v, nr0)) continue;
+            if (energy(v) < 34) continue;  // reasonably complex (>= 30% of the 112 possible transitions)
+            if (!self_ok(v)) continue;
+            add_code(v);
+            fprintf(stderr, "code %d = 0x%09llx at iter %llu\n", ncodes - 1, (unsigned long long)v,
+                    (unsigned long long)(base + i));
+        }
+        (void)ns;
+    }
+    for (int i = 0; i < ncodes; i++) printf("0x%09llx\n", (unsigned long long)codes[i]);
+    return 0;
+}
