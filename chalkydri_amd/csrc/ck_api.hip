@@ -1,0 +1,221 @@
+// ck_api.hip — C ABI entry points: handle lifecycle, frame staging, stage orchestration.
+// See include/chalkydri_hip.h for the contract and the reference interfaces each entry replaces.
+#include <string.h>
+
+#include <new>
+#include <vector>
+
+#include "ck_internal.h"
+
+thread_local char ck_err_text[512] = "";
+
+extern "C" const char *ck_last_error(void) { return ck_err_text; }
+
+extern "C" int ck_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+static int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+extern "C" int ck_create(const ck_config_t *cfg, ck_handle_t **out) {
+    if (!cfg || !out) return CK_EINVAL;
+    *out = nullptr;
+    if (cfg->width < 16 || cfg->height < 16 || cfg->width > 4095 || cfg->height > 4095) return CK_EINVAL;
+    if (cfg->max_batch < 1 || cfg->n_families < 1 || cfg->n_families > CK_MAX_FAMILIES) return CK_EINVAL;
+    if (cfg->quad_decimate != 1 && cfg->quad_decimate != 2) return CK_EUNSUPPORTED;
+    for (int i = 0; i < cfg->n_families; i++)
+        if (!cfg->families[i] || cfg->families[i]->nbits > 64 || cfg->families[i]->total_width > 16) return CK_EINVAL;
+    int qw = cfg->width / cfg->quad_decimate, qh = cfg->height / cfg->quad_decimate;
+    if ((qw & 3) || (qh & 3)) return CK_EUNSUPPORTED; // the threshold kernel assumes whole 4x4 tiles
+    if (ck_device_count() <= 0) return CK_ENODEVICE;
+    ck_handle *h = new (std::nothrow) ck_handle();
+    if (!h) return CK_ENOMEM;
+    memset(h, 0, sizeof *h);
+    h->cfg = *cfg;
+    h->device = cfg->device;
+    h->w = cfg->width; h->h = cfg->height; h->qw = qw; h->qh = qh;
+    h->npix = (size_t)qw * qh;
+    h->tiles_x = (qw + CK_TW - 1) / CK_TW; h->tiles_y = (qh + CK_TH - 1) / CK_TH;
+    h->broot_cap = h->tiles_x * h->tiles_y * 2 * (CK_TW + CK_TH);
+    h->frame_stride = round_up(cfg->width, 16);
+    h->frame_pitch = (size_t)h->frame_stride * cfg->height;
+    const size_t nb = (size_t)cfg->max_batch;
+    int rc = CK_OK;
+    auto fail = [&](int code) { ck_destroy(h); return code; };
+#define CK_TRY(call)                                                                                  \
+    do {                                                                                              \
+        hipError_t e_ = (call);                                                                       \
+        if (e_ != hipSuccess) {                                                                       \
+            snprintf(ck_err_text, sizeof ck_err_text, "%s failed: %s", #call, hipGetErrorString(e_)); \
+            return fail(e_ == hipErrorOutOfMemory ? CK_ENOMEM : CK_EDEVICE);                          \
+        }                                                                                             \
+    } while (0)
+    CK_TRY(hipSetDevice(h->device));
+    CK_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    for (auto &e : h->ev) CK_TRY(hipEventCreate(&e));
+    CK_TRY(hipMalloc(&h->d_frames, h->frame_pitch * nb));
+    if (cfg->quad_decimate > 1) CK_TRY(hipMalloc(&h->d_qframes, (size_t)round_up(qw, 16) * qh * nb));
+    CK_TRY(hipMalloc(&h->d_thresh, h->npix * nb));
+    CK_TRY(hipMalloc(&h->d_labels, h->npix * nb * sizeof(uint32_t)));
+    CK_TRY(hipMalloc(&h->d_csize, h->npix * nb * sizeof(uint32_t)));
+    CK_TRY(hipMalloc(&h->d_broots, (size_t)h->broot_cap * nb * sizeof(ck_border_root)));
+    CK_TRY(hipMalloc(&h->d_broot_count, nb * sizeof(uint32_t)));
+    rc = ck_stage_alloc(h);
+    if (rc != CK_OK) return fail(rc);
+#undef CK_TRY
+    *out = h;
+    return CK_OK;
+}
+
+extern "C" void ck_destroy(ck_handle_t *h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    ck_stage_free(h);
+    (void)hipFree(h->d_frames); (void)hipFree(h->d_qframes); (void)hipFree(h->d_thresh); (void)hipFree(h->d_labels);
+    (void)hipFree(h->d_csize); (void)hipFree(h->d_broots); (void)hipFree(h->d_broot_count);
+    for (auto &e : h->ev) if (e) (void)hipEventDestroy(e);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+static int check_imgs(const ck_handle *h, const ck_image_u8_t *imgs, int n) {
+    if (n < 0 || (n > 0 && !imgs)) return CK_EINVAL;
+    if (n > h->cfg.max_batch) return CK_ECAPACITY;
+    for (int i = 0; i < n; i++)
+        if (!imgs[i].buf || imgs[i].width != h->w || imgs[i].height != h->h || imgs[i].stride < imgs[i].width) return CK_EINVAL;
+    return CK_OK;
+}
+
+extern "C" int ck_upload_frames(ck_handle_t *h, const ck_image_u8_t *imgs, int32_t n) {
+    if (!h) return CK_EINVAL;
+    int rc = check_imgs(h, imgs, n);
+    if (rc != CK_OK) return rc;
+    CK_HIP(hipSetDevice(h->device));
+    for (int i = 0; i < n; i++)
+        CK_HIP(hipMemcpy2DAsync(h->d_frames + (size_t)i * h->frame_pitch, (size_t)h->frame_stride, imgs[i].buf, (size_t)imgs[i].stride,
+                                (size_t)h->w, (size_t)h->h, hipMemcpyHostToDevice, h->stream));
+    CK_HIP(hipStreamSynchronize(h->stream));
+    h->n_staged = n;
+    return CK_OK;
+}
+
+// Makes d_frames hold a 16-byte aligned copy of caller-resident device frames when their layout is not directly usable.
+int ck_stage_device_frames(ck_handle *h, const uint8_t *d_frames, int n, int stride, int64_t frame_pitch, const uint8_t **use,
+                           int *use_stride, size_t *use_pitch) {
+    if (!d_frames || n < 0 || stride < h->w || frame_pitch < (int64_t)stride * h->h) return CK_EINVAL;
+    if (n > h->cfg.max_batch) return CK_ECAPACITY;
+    bool aligned = ((uintptr_t)d_frames % 16 == 0) && (stride % 16 == 0) && (frame_pitch % 16 == 0);
+    if (aligned) { *use = d_frames; *use_stride = stride; *use_pitch = (size_t)frame_pitch; return CK_OK; }
+    for (int i = 0; i < n; i++)
+        CK_HIP(hipMemcpy2DAsync(h->d_frames + (size_t)i * h->frame_pitch, (size_t)h->frame_stride, d_frames + (size_t)i * frame_pitch,
+                                (size_t)stride, (size_t)h->w, (size_t)h->h, hipMemcpyDeviceToDevice, h->stream));
+    h->n_staged = n;
+    *use = h->d_frames; *use_stride = h->frame_stride; *use_pitch = h->frame_pitch;
+    return CK_OK;
+}
+
+// Runs decimate (if configured) + threshold + segment on n staged frames.
+int ck_run_threshold_segment(ck_handle *h, const uint8_t *frames, int stride, size_t pitch, int n) {
+    if (h->cfg.quad_decimate > 1) {
+        int rc = ck_launch_decimate(h, frames, stride, pitch, n);
+        if (rc != CK_OK) return rc;
+        return ck_launch_threshold_segment(h, h->d_qframes, round_up(h->qw, 16), (size_t)round_up(h->qw, 16) * h->qh, n);
+    }
+    return ck_launch_threshold_segment(h, frames, stride, pitch, n);
+}
+
+static int stage_input(ck_handle *h, const ck_image_u8_t *imgs, int n) {
+    if (imgs) return ck_upload_frames(h, imgs, n);
+    if (n < 0 || n > h->n_staged) return CK_EINVAL;
+    return CK_OK;
+}
+
+extern "C" int ck_threshold_batch(ck_handle_t *h, const ck_image_u8_t *imgs, int32_t n, uint8_t *thresh_out) {
+    if (!h || !thresh_out) return CK_EINVAL;
+    int rc = stage_input(h, imgs, n);
+    if (rc != CK_OK) return rc;
+    CK_HIP(hipSetDevice(h->device));
+    rc = ck_run_threshold_segment(h, h->d_frames, h->frame_stride, h->frame_pitch, n);
+    if (rc != CK_OK) return rc;
+    CK_HIP(hipMemcpyAsync(thresh_out, h->d_thresh, h->npix * (size_t)n, hipMemcpyDeviceToHost, h->stream));
+    CK_HIP(hipStreamSynchronize(h->stream));
+    return CK_OK;
+}
+
+extern "C" int ck_segment_batch(ck_handle_t *h, const ck_image_u8_t *imgs, int32_t n, uint32_t *labels_out, uint32_t *sizes_out) {
+    if (!h || !labels_out) return CK_EINVAL;
+    int rc = stage_input(h, imgs, n);
+    if (rc != CK_OK) return rc;
+    CK_HIP(hipSetDevice(h->device));
+    rc = ck_run_threshold_segment(h, h->d_frames, h->frame_stride, h->frame_pitch, n);
+    if (rc != CK_OK) return rc;
+    size_t total = h->npix * (size_t)n;
+    uint32_t *d_canon = nullptr, *d_sizes = nullptr;
+    CK_HIP(hipMalloc(&d_canon, total * sizeof(uint32_t)));
+    if (sizes_out) CK_HIP(hipMalloc(&d_sizes, total * sizeof(uint32_t)));
+    rc = ck_launch_canonical_labels(h, n, d_canon, d_sizes);
+    if (rc == CK_OK) {
+        hipError_t e = hipMemcpyAsync(labels_out, d_canon, total * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream);
+        if (e == hipSuccess && sizes_out) e = hipMemcpyAsync(sizes_out, d_sizes, total * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+        if (e != hipSuccess) { snprintf(ck_err_text, sizeof ck_err_text, "segment D2H failed: %s", hipGetErrorString(e)); rc = CK_EDEVICE; }
+    }
+    (void)hipFree(d_canon); (void)hipFree(d_sizes);
+    return rc;
+}
+
+extern "C" int ck_time_threshold_segment(ck_handle_t *h, int32_t n, int32_t iters, float *ms_out) {
+    if (!h || !ms_out || iters < 1 || n < 1 || n > h->n_staged) return CK_EINVAL;
+    CK_HIP(hipSetDevice(h->device));
+    int rc = ck_run_threshold_segment(h, h->d_frames, h->frame_stride, h->frame_pitch, n); // warm-up
+    if (rc != CK_OK) return rc;
+    CK_HIP(hipEventRecord(h->ev[0], h->stream));
+    for (int i = 0; i < iters; i++) {
+        rc = ck_run_threshold_segment(h, h->d_frames, h->frame_stride, h->frame_pitch, n);
+        if (rc != CK_OK) return rc;
+    }
+    CK_HIP(hipEventRecord(h->ev[1], h->stream));
+    CK_HIP(hipEventSynchronize(h->ev[1]));
+    float ms = 0;
+    CK_HIP(hipEventElapsedTime(&ms, h->ev[0], h->ev[1]));
+    *ms_out = ms / (float)iters;
+    return CK_OK;
+}
+
+extern "C" int ck_last_stage_ms(ck_handle_t *h, ck_stage_ms_t *out) {
+    if (!h || !out) return CK_EINVAL;
+    *out = h->last_ms;
+    return CK_OK;
+}
+
+// fp64 conformance probe ------------------------------------------------------------------------------------------
+__global__ void k_fp64_probe(int op, const double *a, const double *b, int n, double *out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double x = a[i], y = b ? b[i] : 0.0, r;
+    switch (op) {
+    case 0: r = x + y; break;
+    case 1: r = x * y; break;
+    case 2: r = x / y; break;
+    case 3: r = sqrt(x); break;
+    default: { double t = x * y; r = t + x; } break;
+    }
+    out[i] = r;
+}
+extern "C" int ck_selftest_fp64(ck_handle_t *h, int32_t op, const double *a, const double *b, int32_t n, double *out) {
+    if (!h || !a || !out || n < 0) return CK_EINVAL;
+    CK_HIP(hipSetDevice(h->device));
+    double *da = nullptr, *db = nullptr, *dout = nullptr;
+    CK_HIP(hipMalloc(&da, sizeof(double) * (size_t)n));
+    CK_HIP(hipMalloc(&dout, sizeof(double) * (size_t)n));
+    CK_HIP(hipMemcpy(da, a, sizeof(double) * (size_t)n, hipMemcpyHostToDevice));
+    if (b) { CK_HIP(hipMalloc(&db, sizeof(double) * (size_t)n)); CK_HIP(hipMemcpy(db, b, sizeof(double) * (size_t)n, hipMemcpyHostToDevice)); }
+    hipLaunchKernelGGL(k_fp64_probe, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, op, da, db, n, dout);
+    CK_HIP(hipStreamSynchronize(h->stream));
+    CK_HIP(hipMemcpy(out, dout, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost));
+    (void)hipFree(da); (void)hipFree(db); (void)hipFree(dout);
+    return CK_OK;
+}

@@ -1,0 +1,90 @@
+// Internal declarations shared by the HIP translation units of libchalkydri_hip.so.
+#ifndef CK_INTERNAL_H
+#define CK_INTERNAL_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "chalkydri_hip.h"
+
+// ---- label word format (segment stage output; DESIGN.md §Data layout) --------------------------------
+// bits 0..25  pixel index (y*width+x) of the component root the pixel points at
+// bit  30     CK_LBL_BORDER: the tile-local component touches its tile's outer ring, so it may continue in a
+//             neighbouring tile; resolve with one extra hop through the root's own (flattened) entry and
+//             take the size from csize[]
+// bit  31     CK_LBL_SMALL : tile-interior component with fewer than min_component_px pixels (final)
+// 0xFFFFFFFF  pixel thresholded to 127 (no component)
+#define CK_LBL_IDX_MASK 0x03FFFFFFu
+#define CK_LBL_BORDER 0x40000000u
+#define CK_LBL_SMALL 0x80000000u
+#define CK_LBL_INVALID 0xFFFFFFFFu
+
+// CCL tile geometry (one workgroup per tile)
+#define CK_TW 128
+#define CK_TH 64
+
+struct ck_border_root {
+    uint32_t root; // pixel index of a tile-local root whose component touches the tile ring
+    uint32_t size; // its tile-local pixel count
+};
+
+struct ck_dev_family {
+    uint32_t nbits, ncodes;
+    int32_t width_at_border, total_width, reversed_border;
+    const uint64_t *codes; // device
+    uint32_t bit_x[64], bit_y[64];
+};
+
+struct ck_handle {
+    ck_config_t cfg;
+    int device;
+    hipStream_t stream;
+    hipEvent_t ev[16];
+    int w, h;            // full-resolution frame
+    int qw, qh;          // geometry of the image the quad stages run on (w/decimate)
+    int tiles_x, tiles_y;
+    size_t npix;         // qw*qh
+    // device buffers, sized for cfg.max_batch frames
+    uint8_t *d_frames;   // staged input frames, pitch = frame_stride
+    int frame_stride;
+    size_t frame_pitch;
+    uint8_t *d_qframes;  // decimated copy (== d_frames when quad_decimate == 1)
+    uint8_t *d_thresh;   // [n][qh][qw]
+    uint32_t *d_labels;  // [n][qh][qw] label words
+    uint32_t *d_csize;   // [n][qh][qw] sparse: valid at roots of BORDER components
+    ck_border_root *d_broots; // [n][broot_cap]
+    uint32_t *d_broot_count;  // [n]
+    int broot_cap;
+    // later stages
+    void *d_stage;       // opaque per-stage workspace (clusters/quads/decode), see k_*.hip
+    ck_stage_ms_t last_ms;
+    ck_dev_family *d_fams;
+    int n_staged;        // frames currently staged in d_frames
+};
+
+extern thread_local char ck_err_text[512];
+#define CK_HIP(call)                                                                                       \
+    do {                                                                                                    \
+        hipError_t e_ = (call);                                                                             \
+        if (e_ != hipSuccess) {                                                                             \
+            snprintf(ck_err_text, sizeof ck_err_text, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), \
+                     __FILE__, __LINE__);                                                                   \
+            return CK_EDEVICE;                                                                              \
+        }                                                                                                   \
+    } while (0)
+
+// ---- stage launchers (k_*.hip) ------------------------------------------------------------------------
+// threshold + tile-local CCL + cross-tile merge + border-root flatten, on frames [0,n) of `frames`
+int ck_launch_threshold_segment(ck_handle *h, const uint8_t *frames, int stride, size_t frame_pitch, int n);
+// canonical labels (min pixel index, flags stripped) and exact sizes — parity/test path, not the hot path
+int ck_launch_canonical_labels(ck_handle *h, int n, uint32_t *d_labels_out, uint32_t *d_sizes_out);
+int ck_launch_decimate(ck_handle *h, const uint8_t *frames, int stride, size_t frame_pitch, int n);
+// workspace of the irregular stages (clusters / quads / decode)
+int ck_stage_alloc(ck_handle *h);
+void ck_stage_free(ck_handle *h);
+int ck_stage_device_frames(ck_handle *h, const uint8_t *d_frames, int n, int stride, int64_t frame_pitch, const uint8_t **use,
+                           int *use_stride, size_t *use_pitch);
+int ck_run_threshold_segment(ck_handle *h, const uint8_t *frames, int stride, size_t pitch, int n);
+
+#endif

@@ -1,0 +1,524 @@
+// k_ccl.hip — adaptive threshold + union-find segmentation for gfx950 (the stage scored against the HBM
+// roofline: 7 algorithmic bytes per pixel = 1 R image + 1 W thresholded + 1 R thresholded + 4 W label).
+//
+// Replaces, in the reference's production path, the threshold and connected-component stages of the external
+// AprilTag-3 detector reached at crates/apriltags/src/lib.rs:301; the connectivity rule is the one CAT spells
+// out in crates/chalkydri-apriltags/src/lib.rs:501-549 (4-connected black, 8-connected white, origin columns
+// 1..w-2).
+//
+// Structure (one launch each, batched over frames):
+//   k_tile   one workgroup per 64x128 tile: coalesced 16-byte loads of the tile + 4-px halo into LDS, 4x4
+//            tile min/max, 3x3 dilation, tri-state threshold (written once, 16 B/lane), bit-parallel
+//            union-find in LDS (one lane per 64-pixel row segment and colour, runs found with clz/ctz on u64
+//            masks), labels written once (64 B/lane).  HBM traffic 1.2 R + 1 W + 4 W bytes per pixel.
+//   k_merge  one thread per tile-ring pixel: joins components across tile boundaries with atomicMin on the
+//            label words of the (few) roots involved.
+//   k_roots_a/b  flatten the entries of ring-touching roots and accumulate their sizes into csize[].
+// No full-frame relabel pass exists: interior components are final when k_tile writes them; ring-touching
+// ones are resolved by consumers with one extra hop (label word format in ck_internal.h).
+#include "ck_internal.h"
+
+namespace {
+
+constexpr int TW = CK_TW, TH = CK_TH, NT = 256;
+constexpr int IMG_PITCH = 160;          // 12 pad | 4 halo | 128 tile | 4 halo | 12 pad
+constexpr int IMG_ROWS = TH + 8;
+constexpr int T4X = TW / 4 + 2, T4Y = TH / 4 + 2;
+constexpr int NSEG = TW / 64;
+
+constexpr int OFF_PARENT = 0;                              // u32[TH*TW]
+constexpr int OFF_UNION = TH * TW * 4;                     // phase A: image + minmax + thr; phase B: sizes
+constexpr int OFF_IMG = OFF_UNION;                         // IMG_ROWS*IMG_PITCH = 11520
+constexpr int OFF_MINMAX = OFF_IMG + IMG_ROWS * IMG_PITCH; // u16[T4Y*T4X] (1224 -> 1280)
+constexpr int OFF_THR = OFF_MINMAX + 1280;                 // u16[(TH/4)*(TW/4)] = 1024
+constexpr int OFF_SIZE = OFF_UNION;                        // packed u16[TH*TW] = 16384 (bit 15 = ring flag)
+constexpr int UNION_BYTES = TH * TW * 2;
+constexpr int OFF_MASK = OFF_UNION + UNION_BYTES;          // u64[TH][NSEG][2]
+constexpr int LDS_BYTES = OFF_MASK + TH * NSEG * 2 * 8;
+static_assert(OFF_THR + 1024 <= OFF_UNION + UNION_BYTES, "phase A scratch must fit in the size array");
+static_assert(LDS_BYTES <= 53248, "keep three workgroups per CU");
+
+__device__ __forceinline__ uint32_t lds_find(volatile uint32_t *p, uint32_t a) {
+    uint32_t n;
+    while ((n = p[a]) != a) a = n;
+    return a;
+}
+// root = smaller index; the only writes to p[] during the union phase are these atomicMin's
+__device__ __forceinline__ void lds_union(uint32_t *p, uint32_t a, uint32_t b) {
+    for (;;) {
+        a = lds_find(p, a);
+        b = lds_find(p, b);
+        if (a == b) return;
+        if (a < b) { uint32_t t = a; a = b; b = t; }
+        uint32_t old = atomicMin(&p[a], b);
+        if (old == a) return;
+        a = old;
+    }
+}
+// start bit of the run that contains bit i, given the run-start mask S (bit i's run start is <= i)
+__device__ __forceinline__ int run_start(uint64_t S, int i) {
+    return 63 - __builtin_clzll(S & (~0ull >> (63 - i)));
+}
+__device__ __forceinline__ uint64_t origin_mask(int x0, int w) {
+    uint64_t O = ~0ull;
+    if (x0 == 0) O &= ~1ull;
+    int last = (w - 1) - x0;
+    if (last >= 0 && last < 64) O &= ~(1ull << last);
+    return O;
+}
+// gathers bit 7 of each byte of v into a nibble (bit k = byte k)
+__device__ __forceinline__ uint32_t msb_nibble(uint32_t v) {
+    return (((v >> 7) & 0x01010101u) * 0x01020408u) >> 24 & 0xFu;
+}
+
+__global__ __launch_bounds__(NT) void k_tile(const uint8_t *__restrict__ frames, size_t frame_pitch, int stride,
+                                             int w, int h, int tiles_x, int tiles_y, int min_diff, int min_comp,
+                                             uint8_t *__restrict__ thresh, uint32_t *__restrict__ labels,
+                                             ck_border_root *__restrict__ broots,
+                                             uint32_t *__restrict__ broot_count, int broot_cap) {
+    __shared__ __attribute__((aligned(16))) uint8_t lds[LDS_BYTES];
+    const int tid = threadIdx.x;
+    const int tiles = tiles_x * tiles_y;
+    const int frame = blockIdx.x / tiles, tile = blockIdx.x - frame * tiles;
+    const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+    const int tx0 = tx * TW, ty0 = ty * TH;
+    const uint8_t *img = frames + (size_t)frame * frame_pitch;
+    const size_t fbase = (size_t)frame * (size_t)w * (size_t)h;
+    uint32_t *parent = reinterpret_cast<uint32_t *>(lds + OFF_PARENT);
+
+    // ---- P0: parent[i] = i; stage the tile and its 4-pixel halo -------------------------------------
+    for (int i = tid * 4; i < TH * TW; i += NT * 4)
+        *reinterpret_cast<uint4 *>(&parent[i]) = make_uint4(i, i + 1, i + 2, i + 3);
+    for (int item = tid; item < IMG_ROWS * 8; item += NT) {
+        int r = item >> 3, c = item & 7;
+        int gy = ty0 - 4 + r, gx = tx0 + 16 * c;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (gy >= 0 && gy < h) {
+            const uint8_t *src = img + (size_t)gy * stride + gx;
+            if (gx + 16 <= w) v = *reinterpret_cast<const uint4 *>(src);
+            else {
+                if (gx + 4 <= w) v.x = *reinterpret_cast<const uint32_t *>(src);
+                if (gx + 8 <= w) v.y = *reinterpret_cast<const uint32_t *>(src + 4);
+                if (gx + 12 <= w) v.z = *reinterpret_cast<const uint32_t *>(src + 8);
+            }
+        }
+        *reinterpret_cast<uint4 *>(lds + OFF_IMG + r * IMG_PITCH + 16 + 16 * c) = v;
+    }
+    for (int item = tid; item < IMG_ROWS * 2; item += NT) {
+        int r = item >> 1, side = item & 1;
+        int gy = ty0 - 4 + r, gx = side ? tx0 + TW : tx0 - 4;
+        uint32_t v = 0;
+        if (gy >= 0 && gy < h && gx >= 0 && gx + 4 <= w)
+            v = *reinterpret_cast<const uint32_t *>(img + (size_t)gy * stride + gx);
+        *reinterpret_cast<uint32_t *>(lds + OFF_IMG + r * IMG_PITCH + (side ? 16 + TW : 12)) = v;
+    }
+    __syncthreads();
+
+    // ---- P1: min/max of every 4x4 tile of the staged region -------------------------------------------
+    uint16_t *minmax = reinterpret_cast<uint16_t *>(lds + OFF_MINMAX);
+    const int w4 = w >> 2, h4 = h >> 2;
+    for (int item = tid; item < T4Y * T4X; item += NT) {
+        int i = item / T4X, j = item - i * T4X;
+        int g4x = (tx0 >> 2) - 1 + j, g4y = (ty0 >> 2) - 1 + i;
+        uint32_t mn = 255, mx = 0;
+        if (g4x >= 0 && g4x < w4 && g4y >= 0 && g4y < h4) {
+#pragma unroll
+            for (int rr = 0; rr < 4; rr++) {
+                uint32_t d = *reinterpret_cast<const uint32_t *>(lds + OFF_IMG + (4 * i + rr) * IMG_PITCH + 12 + 4 * j);
+#pragma unroll
+                for (int b = 0; b < 4; b++) {
+                    uint32_t v = (d >> (8 * b)) & 255u;
+                    mn = min(mn, v); mx = max(mx, v);
+                }
+            }
+        }
+        minmax[item] = (uint16_t)(mn | (mx << 8)); // outside the frame: (255,0) is neutral for the dilation
+    }
+    __syncthreads();
+
+    // ---- P2: 3x3 dilation -> per-4x4-tile threshold word (bit 8 = low contrast) ---------------------------
+    uint16_t *thr = reinterpret_cast<uint16_t *>(lds + OFF_THR);
+    for (int item = tid; item < (TH / 4) * (TW / 4); item += NT) {
+        int i = item / (TW / 4), j = item - i * (TW / 4);
+        uint32_t mn = 255, mx = 0;
+#pragma unroll
+        for (int di = 0; di < 3; di++)
+#pragma unroll
+            for (int dj = 0; dj < 3; dj++) {
+                uint32_t m = minmax[(i + di) * T4X + j + dj];
+                mn = min(mn, m & 255u); mx = max(mx, m >> 8);
+            }
+        int diff = (int)mx - (int)mn;
+        thr[item] = (uint16_t)((diff < min_diff) ? 0x100u : (mn + (uint32_t)(diff >> 1)));
+    }
+    __syncthreads();
+
+    // ---- P3: threshold 16 pixels per item, write them, build the per-row colour masks ----------------------
+    uint16_t *mask16 = reinterpret_cast<uint16_t *>(lds + OFF_MASK); // [r][seg][colour][piece]
+    for (int item = tid; item < TH * 8; item += NT) {
+        int r = item >> 3, c = item & 7;
+        int gy = ty0 + r, gx = tx0 + 16 * c;
+        uint4 px = *reinterpret_cast<const uint4 *>(lds + OFF_IMG + (r + 4) * IMG_PITCH + 16 + 16 * c);
+        uint32_t in[4] = {px.x, px.y, px.z, px.w}, out[4];
+        uint32_t wbits = 0, bbits = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            uint32_t tw_ = thr[(r >> 2) * (TW / 4) + 4 * c + k];
+            uint32_t o;
+            if (gy >= h || gx + 4 * k >= w) o = 0x7F7F7F7Fu;      // outside the frame: no colour
+            else if (tw_ & 0x100u) o = 0x7F7F7F7Fu;
+            else {
+                o = 0;
+#pragma unroll
+                for (int b = 0; b < 4; b++)
+                    if (((in[k] >> (8 * b)) & 255u) > tw_) o |= 0xFFu << (8 * b);
+            }
+            out[k] = o;
+            wbits |= msb_nibble(o) << (4 * k);                     // 255 -> bit 7 set
+            bbits |= msb_nibble(~(o << 7)) << (4 * k);             // 0 -> bit 0 clear (127 and 255 have it set)
+        }
+        if (gy < h && gx < w) {
+            uint8_t *dst = thresh + fbase + (size_t)gy * w + gx;
+            if (gx + 16 <= w && (w & 15) == 0) *reinterpret_cast<uint4 *>(dst) = make_uint4(out[0], out[1], out[2], out[3]);
+            else
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                    if (gx + 4 * k < w) *reinterpret_cast<uint32_t *>(dst + 4 * k) = out[k];
+        }
+        int seg = c >> 2, piece = c & 3;
+        mask16[((r * NSEG + seg) * 2 + 0) * 4 + piece] = (uint16_t)wbits;
+        mask16[((r * NSEG + seg) * 2 + 1) * 4 + piece] = (uint16_t)bbits;
+    }
+    __syncthreads();
+
+    // ---- P4: the image scratch is dead; it becomes the size array ---------------------------------------------
+    for (int i = tid * 16; i < UNION_BYTES; i += NT * 16) *reinterpret_cast<uint4 *>(lds + OFF_SIZE + i) = make_uint4(0, 0, 0, 0);
+
+    // ---- P5: unions.  thread = (colour, row, segment) --------------------------------------------------------------
+    const uint64_t *masks = reinterpret_cast<const uint64_t *>(lds + OFF_MASK);
+    const int color = tid >> 7, sitem = tid & 127;
+    const int r = sitem / NSEG, s = sitem - r * NSEG;
+    const int x0 = tx0 + 64 * s;
+    const uint64_t M = masks[(r * NSEG + s) * 2 + color];
+    const uint64_t O = origin_mask(x0, w);
+    const uint64_t S = M & ~((M << 1) & O); // segment-local run starts
+    const uint32_t base = (uint32_t)(r * TW + 64 * s);
+    if (M) {
+        if (s > 0 && (M & O & 1ull)) { // run continues from the segment on the left
+            uint64_t Ml = masks[(r * NSEG + s - 1) * 2 + color];
+            if (Ml >> 63) {
+                uint64_t Ol = origin_mask(x0 - 64, w);
+                uint64_t Sl = Ml & ~((Ml << 1) & Ol);
+                lds_union(parent, base, base - 64 + (uint32_t)(63 - __builtin_clzll(Sl)));
+            }
+        }
+        if (r > 0) {
+            const uint64_t U = masks[((r - 1) * NSEG + s) * 2 + color];
+            const uint64_t Su = U & ~((U << 1) & O);
+            uint64_t V = M & U & O;
+            uint64_t Ev = V & ~(V << 1);
+            while (Ev) {
+                int i = __builtin_ctzll(Ev);
+                Ev &= Ev - 1;
+                lds_union(parent, base + run_start(S, i), base - TW + run_start(Su, i));
+            }
+            if (color == 0) { // white: diagonal links
+                uint64_t Ul = 0, Ur = 0;
+                if (s > 0) Ul = masks[((r - 1) * NSEG + s - 1) * 2];
+                if (s < NSEG - 1) Ur = masks[((r - 1) * NSEG + s + 1) * 2];
+                int xn = x0 + 64; // origin flag of the column right of this segment
+                uint64_t On = (xn >= 1 && xn <= w - 2) ? 1ull : 0ull;
+                uint64_t MO = M & O;
+                uint64_t DL = MO & ((U << 1) | (Ul >> 63)) & ~U & ~(MO << 1);
+                uint64_t DR = MO & ((U >> 1) | (Ur << 63)) & ~(U & ((O >> 1) | (On << 63))) & ~(MO >> 1);
+                while (DL) {
+                    int i = __builtin_ctzll(DL);
+                    DL &= DL - 1;
+                    uint32_t b;
+                    if (i > 0) b = base - TW + run_start(Su, i - 1);
+                    else {
+                        uint64_t Ol = origin_mask(x0 - 64, w);
+                        uint64_t Sl = Ul & ~((Ul << 1) & Ol);
+                        b = base - TW - 64 + (uint32_t)(63 - __builtin_clzll(Sl));
+                    }
+                    lds_union(parent, base + run_start(S, i), b);
+                }
+                while (DR) {
+                    int i = __builtin_ctzll(DR);
+                    DR &= DR - 1;
+                    uint32_t b = (i < 63) ? base - TW + run_start(Su, i + 1) : base - TW + 64; // bit 0 of the right segment starts a run
+                    lds_union(parent, base + run_start(S, i), b);
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- P6: flatten run starts, accumulate sizes and ring flags at the roots ---------------------------------------
+    uint32_t *size32 = reinterpret_cast<uint32_t *>(lds + OFF_SIZE);
+    {
+        const bool ring_row = (r == 0 && ty0 > 0) || (r == TH - 1 && ty0 + TH < h);
+        uint64_t St = S;
+        while (St) {
+            int i = __builtin_ctzll(St);
+            St &= St - 1;
+            uint64_t above = St ? (St & (0ull - St)) : 0ull; // lowest remaining start
+            uint64_t span = above ? (above - (1ull << i)) : (~0ull << i);
+            uint64_t run = M & span;
+            uint32_t node = base + i;
+            uint32_t root = lds_find(parent, node);
+            parent[node] = root;
+            bool ring = ring_row || (s == 0 && tx0 > 0 && (run & 1ull)) ||
+                        (s == NSEG - 1 && tx0 + TW < w && (run >> 63));
+            uint32_t add = (uint32_t)__popcll(run) << (16 * (root & 1));
+            atomicAdd(&size32[root >> 1], add);
+            if (ring) atomicOr(&size32[root >> 1], 0x8000u << (16 * (root & 1)));
+        }
+    }
+    __syncthreads();
+
+    // ---- P7: write label words (16 pixels per item) -------------------------------------------------------------------
+    const uint16_t *size16 = reinterpret_cast<const uint16_t *>(lds + OFF_SIZE);
+    for (int item = tid; item < TH * 8; item += NT) {
+        int rr = item >> 3, c = item & 7;
+        int gy = ty0 + rr, gx = tx0 + 16 * c;
+        if (gy >= h || gx >= w) continue;
+        int seg = c >> 2, piece = c & 3;
+        uint64_t Wm = masks[(rr * NSEG + seg) * 2], Bm = masks[(rr * NSEG + seg) * 2 + 1];
+        uint64_t Oo = origin_mask(tx0 + 64 * seg, w);
+        uint64_t SW = Wm & ~((Wm << 1) & Oo), SB = Bm & ~((Bm << 1) & Oo);
+        uint32_t sbase = (uint32_t)(rr * TW + 64 * seg);
+        uint32_t outw[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            int bit = 16 * piece + k;
+            uint32_t word = CK_LBL_INVALID;
+            bool isw = (Wm >> bit) & 1ull, isb = (Bm >> bit) & 1ull;
+            if (isw || isb) {
+                uint32_t node = sbase + run_start(isw ? SW : SB, bit);
+                uint32_t root = parent[node];
+                uint32_t sw = size16[root];
+                uint32_t gidx = (uint32_t)(ty0 + (int)(root / TW)) * (uint32_t)w + (uint32_t)(tx0 + (int)(root % TW));
+                word = gidx | ((sw & 0x8000u) ? CK_LBL_BORDER : ((int)(sw & 0x7FFFu) < min_comp ? CK_LBL_SMALL : 0u));
+            }
+            outw[k] = word;
+        }
+        uint32_t *dst = labels + fbase + (size_t)gy * w + gx;
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            if (gx + 4 * q < w)
+                *reinterpret_cast<uint4 *>(dst + 4 * q) = make_uint4(outw[4 * q], outw[4 * q + 1], outw[4 * q + 2], outw[4 * q + 3]);
+    }
+
+    // ---- P8: append ring-touching roots (wave ballot / prefix-sum compaction) ----------------------------------------
+    {
+        int cnt = 0;
+        uint64_t St = S;
+        while (St) {
+            int i = __builtin_ctzll(St);
+            St &= St - 1;
+            uint32_t node = base + i;
+            if (parent[node] == node && (size16[node] & 0x8000u)) cnt++;
+        }
+        // inclusive wave scan of cnt
+        int lane = tid & 63, incl = cnt;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            int o = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += o;
+        }
+        int total = __shfl(incl, 63, 64);
+        uint32_t wbase = 0;
+        if (lane == 63 && total > 0) wbase = atomicAdd(&broot_count[frame], (uint32_t)total);
+        wbase = __shfl(wbase, 63, 64);
+        uint32_t pos = wbase + (uint32_t)(incl - cnt);
+        St = S;
+        while (St) {
+            int i = __builtin_ctzll(St);
+            St &= St - 1;
+            uint32_t node = base + i;
+            uint32_t sw = size16[node];
+            if (parent[node] == node && (sw & 0x8000u)) {
+                if (pos < (uint32_t)broot_cap) {
+                    ck_border_root br;
+                    br.root = (uint32_t)(ty0 + (int)(node / TW)) * (uint32_t)w + (uint32_t)(tx0 + (int)(node % TW));
+                    br.size = sw & 0x7FFFu;
+                    broots[(size_t)frame * broot_cap + pos] = br;
+                }
+                pos++;
+            }
+        }
+    }
+}
+
+// ---- cross-tile merge ----------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t g_find(const uint32_t *L, uint32_t r) {
+    for (;;) {
+        uint32_t n = __builtin_nontemporal_load(&L[r]) & CK_LBL_IDX_MASK;
+        if (n == r) return r;
+        r = n;
+    }
+}
+__device__ __forceinline__ void g_union(uint32_t *L, uint32_t p, uint32_t q) {
+    uint32_t a = __builtin_nontemporal_load(&L[p]) & CK_LBL_IDX_MASK, b = __builtin_nontemporal_load(&L[q]) & CK_LBL_IDX_MASK;
+    for (;;) {
+        a = g_find(L, a);
+        b = g_find(L, b);
+        if (a == b) return;
+        if (a < b) { uint32_t t = a; a = b; b = t; }
+        uint32_t old = atomicMin(&L[a], b | CK_LBL_BORDER) & CK_LBL_IDX_MASK;
+        if (old == a) return;
+        a = old;
+    }
+}
+
+__global__ __launch_bounds__(NT) void k_merge(const uint8_t *__restrict__ thresh, uint32_t *__restrict__ labels, int w, int h,
+                                              int tiles_x, int tiles_y) {
+    const int tid = threadIdx.x;
+    const int tiles = tiles_x * tiles_y;
+    const int frame = blockIdx.x / tiles, tile = blockIdx.x - frame * tiles;
+    const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+    const int tx0 = tx * TW, ty0 = ty * TH;
+    const size_t fbase = (size_t)frame * (size_t)w * (size_t)h;
+    const uint8_t *T = thresh + fbase;
+    uint32_t *L = labels + fbase;
+    int x, y, kind;
+    if (tid < TW) { x = tx0 + tid; y = ty0; kind = 0; }
+    else if (tid < TW + TH) { x = tx0; y = ty0 + 1 + (tid - TW); kind = 1; }
+    else { x = tx0 + TW - 1; y = ty0 + 1 + (tid - TW - TH); kind = 2; }
+    if (y >= ty0 + TH || x >= w || y >= h) return;
+    if (x < 1 || x > w - 2) return; // not an origin column
+    const uint32_t p = (uint32_t)y * (uint32_t)w + (uint32_t)x;
+    const uint8_t v = T[p];
+    if (v == 127) return;
+    if (kind == 0) {
+        if (x == tx0 && tx0 > 0 && T[p - 1] == v) g_union(L, p, p - 1);
+        if (y >= 1) {
+            if (T[p - w] == v) g_union(L, p, p - w);
+            if (v == 255) {
+                if (T[p - w - 1] == 255) g_union(L, p, p - w - 1);
+                if (T[p - w + 1] == 255) g_union(L, p, p - w + 1);
+            }
+        }
+    } else if (kind == 1) {
+        if (tx0 > 0) {
+            if (T[p - 1] == v) g_union(L, p, p - 1);
+            if (v == 255 && T[p - w - 1] == 255) g_union(L, p, p - w - 1);
+        }
+    } else {
+        if (v == 255 && T[p - w + 1] == 255) g_union(L, p, p - w + 1);
+    }
+}
+
+// ---- ring-touching roots: flatten their entries, then accumulate sizes at the global roots ------------------------------------
+__global__ __launch_bounds__(NT) void k_roots_a(uint32_t *__restrict__ labels, uint32_t *__restrict__ csize,
+                                                const ck_border_root *__restrict__ broots,
+                                                const uint32_t *__restrict__ broot_count, int broot_cap, size_t npix) {
+    const int frame = blockIdx.y;
+    uint32_t n = min(broot_count[frame], (uint32_t)broot_cap);
+    uint32_t *L = labels + (size_t)frame * npix;
+    uint32_t *C = csize + (size_t)frame * npix;
+    for (uint32_t k = blockIdx.x * NT + threadIdx.x; k < n; k += gridDim.x * NT) {
+        ck_border_root br = broots[(size_t)frame * broot_cap + k];
+        uint32_t g = g_find(L, br.root);
+        C[br.root] = br.size;
+        if (g != br.root) L[br.root] = g | CK_LBL_BORDER; // still a valid ancestor for concurrent finds
+    }
+}
+__global__ __launch_bounds__(NT) void k_roots_b(const uint32_t *__restrict__ labels, uint32_t *__restrict__ csize,
+                                                const ck_border_root *__restrict__ broots,
+                                                const uint32_t *__restrict__ broot_count, int broot_cap, size_t npix) {
+    const int frame = blockIdx.y;
+    uint32_t n = min(broot_count[frame], (uint32_t)broot_cap);
+    const uint32_t *L = labels + (size_t)frame * npix;
+    uint32_t *C = csize + (size_t)frame * npix;
+    for (uint32_t k = blockIdx.x * NT + threadIdx.x; k < n; k += gridDim.x * NT) {
+        ck_border_root br = broots[(size_t)frame * broot_cap + k];
+        uint32_t g = L[br.root] & CK_LBL_IDX_MASK;
+        if (g != br.root) atomicAdd(&C[g], br.size);
+    }
+}
+
+// ---- parity / test path: canonical labels and exact sizes ---------------------------------------------------------------------
+__global__ __launch_bounds__(NT) void k_canon(const uint32_t *__restrict__ labels, uint32_t *__restrict__ out, size_t npix, size_t total) {
+    size_t i = (size_t)blockIdx.x * NT + threadIdx.x;
+    if (i >= total) return;
+    size_t fb = (i / npix) * npix;
+    uint32_t l = labels[i];
+    uint32_t g = CK_LBL_INVALID;
+    if (l != CK_LBL_INVALID) {
+        g = l & CK_LBL_IDX_MASK;
+        if (l & CK_LBL_BORDER) g = labels[fb + g] & CK_LBL_IDX_MASK;
+    }
+    out[i] = g;
+}
+__global__ __launch_bounds__(NT) void k_count(const uint32_t *__restrict__ canon, uint32_t *__restrict__ cnt, size_t npix, size_t total) {
+    size_t i = (size_t)blockIdx.x * NT + threadIdx.x;
+    if (i >= total) return;
+    uint32_t g = canon[i];
+    if (g != CK_LBL_INVALID) atomicAdd(&cnt[(i / npix) * npix + g], 1u);
+}
+__global__ __launch_bounds__(NT) void k_sizes(const uint32_t *__restrict__ canon, const uint32_t *__restrict__ cnt, uint32_t *__restrict__ sizes, size_t npix, size_t total) {
+    size_t i = (size_t)blockIdx.x * NT + threadIdx.x;
+    if (i >= total) return;
+    uint32_t g = canon[i];
+    sizes[i] = (g == CK_LBL_INVALID) ? 0u : cnt[(i / npix) * npix + g];
+}
+
+__global__ __launch_bounds__(NT) void k_decimate(const uint8_t *__restrict__ src, size_t frame_pitch, int stride, int f, int qw, int qh,
+                                                 uint8_t *__restrict__ dst, size_t total) {
+    size_t i = (size_t)blockIdx.x * NT + threadIdx.x;
+    if (i >= total) return;
+    size_t npix = (size_t)qw * qh;
+    size_t fr = i / npix, rem = i - fr * npix;
+    int y = (int)(rem / qw), x = (int)(rem - (size_t)y * qw);
+    dst[i] = src[fr * frame_pitch + (size_t)(y * f) * stride + (size_t)x * f];
+}
+
+} // namespace
+
+int ck_launch_threshold_segment(ck_handle *h, const uint8_t *frames, int stride, size_t frame_pitch, int n) {
+    const int tiles = h->tiles_x * h->tiles_y;
+    CK_HIP(hipMemsetAsync(h->d_broot_count, 0, sizeof(uint32_t) * (size_t)n, h->stream));
+    hipLaunchKernelGGL(k_tile, dim3((unsigned)(tiles * n)), dim3(NT), 0, h->stream, frames, frame_pitch, stride, h->qw, h->qh,
+                       h->tiles_x, h->tiles_y, h->cfg.min_white_black_diff, h->cfg.min_component_px, h->d_thresh, h->d_labels,
+                       h->d_broots, h->d_broot_count, h->broot_cap);
+    hipLaunchKernelGGL(k_merge, dim3((unsigned)(tiles * n)), dim3(NT), 0, h->stream, h->d_thresh, h->d_labels, h->qw, h->qh,
+                       h->tiles_x, h->tiles_y);
+    int bx = (h->broot_cap + NT * 8 - 1) / (NT * 8);
+    if (bx < 1) bx = 1;
+    if (bx > 64) bx = 64;
+    hipLaunchKernelGGL(k_roots_a, dim3((unsigned)bx, (unsigned)n), dim3(NT), 0, h->stream, h->d_labels, h->d_csize, h->d_broots,
+                       h->d_broot_count, h->broot_cap, h->npix);
+    hipLaunchKernelGGL(k_roots_b, dim3((unsigned)bx, (unsigned)n), dim3(NT), 0, h->stream, h->d_labels, h->d_csize, h->d_broots,
+                       h->d_broot_count, h->broot_cap, h->npix);
+    CK_HIP(hipGetLastError());
+    return CK_OK;
+}
+
+int ck_launch_canonical_labels(ck_handle *h, int n, uint32_t *d_out, uint32_t *d_sizes) {
+    size_t total = h->npix * (size_t)n;
+    unsigned blocks = (unsigned)((total + NT - 1) / NT);
+    hipLaunchKernelGGL(k_canon, dim3(blocks), dim3(NT), 0, h->stream, h->d_labels, d_out, h->npix, total);
+    if (d_sizes) {
+        // exact sizes by counting: test path only (the pipeline uses the SMALL flag / csize[] instead)
+        uint32_t *cnt = nullptr;
+        CK_HIP(hipMalloc(&cnt, total * sizeof(uint32_t)));
+        CK_HIP(hipMemsetAsync(cnt, 0, total * sizeof(uint32_t), h->stream));
+        hipLaunchKernelGGL(k_count, dim3(blocks), dim3(NT), 0, h->stream, d_out, cnt, h->npix, total);
+        hipLaunchKernelGGL(k_sizes, dim3(blocks), dim3(NT), 0, h->stream, d_out, cnt, d_sizes, h->npix, total);
+        CK_HIP(hipStreamSynchronize(h->stream));
+        CK_HIP(hipFree(cnt));
+    }
+    CK_HIP(hipGetLastError());
+    return CK_OK;
+}
+
+int ck_launch_decimate(ck_handle *h, const uint8_t *frames, int stride, size_t frame_pitch, int n) {
+    size_t total = h->npix * (size_t)n;
+    unsigned blocks = (unsigned)((total + NT - 1) / NT);
+    hipLaunchKernelGGL(k_decimate, dim3(blocks), dim3(NT), 0, h->stream, frames, frame_pitch, stride, h->cfg.quad_decimate, h->qw,
+                       h->qh, h->d_qframes, total);
+    CK_HIP(hipGetLastError());
+    return CK_OK;
+}
