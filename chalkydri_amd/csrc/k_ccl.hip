@@ -38,12 +38,26 @@ constexpr int LDS_BYTES = OFF_MASK + TH * NSEG * 2 * 8;
 static_assert(OFF_THR + 1024 <= OFF_UNION + UNION_BYTES, "phase A scratch must fit in the size array");
 static_assert(LDS_BYTES <= 53248, "keep three workgroups per CU");
 
+// find with path halving.  Plain stores race with the atomicMin hooks of lds_union, but every value ever
+// written to p[a] is an ancestor of a, so the forest stays valid (a lost hook is re-issued by its own union).
 __device__ __forceinline__ uint32_t lds_find(volatile uint32_t *p, uint32_t a) {
+    for (;;) {
+        uint32_t n = p[a];
+        if (n == a) return a;
+        uint32_t g = p[n];
+        if (g == n) return n;
+        p[a] = g;
+        a = g;
+    }
+}
+// read-only find for the flatten phases: there the only stores are owners writing the final root into their
+// own entry, so a halving store from another walker must not be allowed to overwrite one with a stale ancestor
+__device__ __forceinline__ uint32_t lds_find_ro(const volatile uint32_t *p, uint32_t a) {
     uint32_t n;
     while ((n = p[a]) != a) a = n;
     return a;
 }
-// root = smaller index; the only writes to p[] during the union phase are these atomicMin's
+// root = smaller index
 __device__ __forceinline__ void lds_union(uint32_t *p, uint32_t a, uint32_t b) {
     for (;;) {
         a = lds_find(p, a);
@@ -266,7 +280,7 @@ __global__ __launch_bounds__(NT) void k_tile(const uint8_t *__restrict__ frames,
             uint64_t span = above ? (above - (1ull << i)) : (~0ull << i);
             uint64_t run = M & span;
             uint32_t node = base + i;
-            uint32_t root = lds_find(parent, node);
+            uint32_t root = lds_find_ro(parent, node);
             parent[node] = root;
             bool ring = ring_row || (s == 0 && tx0 > 0 && (run & 1ull)) ||
                         (s == NSEG - 1 && tx0 + TW < w && (run >> 63));
@@ -352,15 +366,29 @@ __global__ __launch_bounds__(NT) void k_tile(const uint8_t *__restrict__ frames,
 }
 
 // ---- cross-tile merge ----------------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t g_find(const uint32_t *L, uint32_t r) {
+__device__ __forceinline__ uint32_t g_load(const uint32_t *L, uint32_t i) {
+    return __hip_atomic_load(&L[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & CK_LBL_IDX_MASK;
+}
+// find over the root entries of ring-touching components, with path halving (same argument as lds_find)
+__device__ __forceinline__ uint32_t g_find(uint32_t *L, uint32_t r) {
     for (;;) {
-        uint32_t n = __builtin_nontemporal_load(&L[r]) & CK_LBL_IDX_MASK;
+        uint32_t n = g_load(L, r);
+        if (n == r) return r;
+        uint32_t g = g_load(L, n);
+        if (g == n) return n;
+        __hip_atomic_store(&L[r], g | CK_LBL_BORDER, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        r = g;
+    }
+}
+__device__ __forceinline__ uint32_t g_find_ro(const uint32_t *L, uint32_t r) {
+    for (;;) {
+        uint32_t n = g_load(L, r);
         if (n == r) return r;
         r = n;
     }
 }
 __device__ __forceinline__ void g_union(uint32_t *L, uint32_t p, uint32_t q) {
-    uint32_t a = __builtin_nontemporal_load(&L[p]) & CK_LBL_IDX_MASK, b = __builtin_nontemporal_load(&L[q]) & CK_LBL_IDX_MASK;
+    uint32_t a = g_load(L, p), b = g_load(L, q);
     for (;;) {
         a = g_find(L, a);
         b = g_find(L, b);
@@ -420,7 +448,7 @@ __global__ __launch_bounds__(NT) void k_roots_a(uint32_t *__restrict__ labels, u
     uint32_t *C = csize + (size_t)frame * npix;
     for (uint32_t k = blockIdx.x * NT + threadIdx.x; k < n; k += gridDim.x * NT) {
         ck_border_root br = broots[(size_t)frame * broot_cap + k];
-        uint32_t g = g_find(L, br.root);
+        uint32_t g = g_find_ro(L, br.root);
         C[br.root] = br.size;
         if (g != br.root) L[br.root] = g | CK_LBL_BORDER; // still a valid ancestor for concurrent finds
     }
