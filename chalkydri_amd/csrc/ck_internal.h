@@ -36,6 +36,40 @@ struct ck_dev_family {
     uint32_t bit_x[64], bit_y[64];
 };
 
+// One boundary point while it waits to be grouped (k_clusters.hip)
+struct ck_tmp_point {
+    uint32_t slot;  // hash-table slot of its cluster
+    uint32_t rank;  // position inside the cluster
+    uint16_t x, y;  // half-pixel coordinates
+    int8_t gx, gy;
+    uint16_t pad;
+};
+
+// Workspace of the irregular stages, sized for cfg.max_batch frames
+struct ck_stage_ws {
+    int ht_size;               // hash-table slots per frame (power of two)
+    int point_cap, cluster_cap, quad_cap, det_cap;
+    int max_cluster_points;
+    unsigned long long *d_ht_keys; // [n][ht_size]  (rep0<<32 | rep1), 0 = empty
+    uint32_t *d_ht_count;      // [n][ht_size]
+    uint32_t *d_ht_off;        // [n][ht_size] start of the cluster in d_points, or 0xFFFFFFFF
+    ck_tmp_point *d_tmp;       // [n][point_cap]
+    ck_cluster_point_t *d_points; // [n][point_cap]
+    ck_cluster_t *d_clusters;  // [n][cluster_cap]
+    uint32_t *d_counters;      // [n][8]: 0 tmp points, 1 clusters, 2 kept points, 3 quads, 4 detections, 5 status
+    ck_quad_t *d_quads;        // [n][quad_cap]
+    ck_detection_t *d_dets;    // [n][det_cap]
+    void *d_fit_scratch;       // global scratch for clusters too large for LDS
+    size_t fit_scratch_bytes;
+};
+#define CK_CNT_TMP 0
+#define CK_CNT_CLUSTERS 1
+#define CK_CNT_POINTS 2
+#define CK_CNT_QUADS 3
+#define CK_CNT_DETS 4
+#define CK_CNT_STATUS 5
+#define CK_CNT_STRIDE 8
+
 struct ck_handle {
     ck_config_t cfg;
     int device;
@@ -57,7 +91,7 @@ struct ck_handle {
     uint32_t *d_broot_count;  // [n]
     int broot_cap;
     // later stages
-    void *d_stage;       // opaque per-stage workspace (clusters/quads/decode), see k_*.hip
+    ck_stage_ws ws;      // workspace of clusters / quads / decode
     ck_stage_ms_t last_ms;
     ck_dev_family *d_fams;
     int n_staged;        // frames currently staged in d_frames
@@ -86,5 +120,11 @@ void ck_stage_free(ck_handle *h);
 int ck_stage_device_frames(ck_handle *h, const uint8_t *d_frames, int n, int stride, int64_t frame_pitch, const uint8_t **use,
                            int *use_stride, size_t *use_pitch);
 int ck_run_threshold_segment(ck_handle *h, const uint8_t *frames, int stride, size_t pitch, int n);
+// gradient clusters from thresh/labels/csize of frames [0,n)
+int ck_launch_clusters(ck_handle *h, int n);
+// quad fit (+ edge refinement) of every cluster; qframes = image the clusters came from, frames = full resolution
+int ck_launch_fit_quads(ck_handle *h, const uint8_t *qframes, int qstride, size_t qpitch, const uint8_t *frames, int stride,
+                        size_t pitch, int n);
+int ck_launch_decode(ck_handle *h, const uint8_t *frames, int stride, size_t pitch, int n);
 
 #endif

@@ -1,0 +1,195 @@
+// ck_stages.hip — workspace of the irregular stages and the detect / clusters / quads entry points.
+#include <string.h>
+
+#include <vector>
+
+#include "ck_internal.h"
+
+static int next_pow2(int v) { int p = 1; while (p < v) p <<= 1; return p; }
+
+int ck_stage_alloc(ck_handle *h) {
+    ck_stage_ws &ws = h->ws;
+    const ck_config_t &cfg = h->cfg;
+    const size_t nb = (size_t)cfg.max_batch;
+    const int npix = (int)h->npix;
+    ws.point_cap = cfg.max_points_per_frame > 0 ? cfg.max_points_per_frame : 2 * npix;
+    ws.cluster_cap = cfg.max_clusters_per_frame > 0 ? cfg.max_clusters_per_frame : npix / 32;
+    if (ws.cluster_cap < 1024) ws.cluster_cap = 1024;
+    if (ws.cluster_cap > (1 << 20) - 1) ws.cluster_cap = (1 << 20) - 1;
+    ws.quad_cap = cfg.max_quads_per_frame > 0 ? cfg.max_quads_per_frame : 1024;
+    ws.det_cap = 256;
+    ws.ht_size = next_pow2(2 * ws.cluster_cap);
+    if (ws.ht_size < 1024) ws.ht_size = 1024;
+    ws.max_cluster_points = 3 * (2 * h->qw + 2 * h->qh);
+    if (ws.max_cluster_points > 16384) ws.max_cluster_points = 16384;
+    if (cfg.max_nmaxima < 4 || cfg.max_nmaxima > 15) return CK_EINVAL;
+    CK_HIP(hipMalloc(&ws.d_ht_keys, sizeof(unsigned long long) * (size_t)ws.ht_size * nb));
+    CK_HIP(hipMalloc(&ws.d_ht_count, sizeof(uint32_t) * (size_t)ws.ht_size * nb));
+    CK_HIP(hipMalloc(&ws.d_ht_off, sizeof(uint32_t) * (size_t)ws.ht_size * nb));
+    CK_HIP(hipMalloc(&ws.d_tmp, sizeof(ck_tmp_point) * (size_t)ws.point_cap * nb));
+    CK_HIP(hipMalloc(&ws.d_points, sizeof(ck_cluster_point_t) * (size_t)ws.point_cap * nb));
+    CK_HIP(hipMalloc(&ws.d_clusters, sizeof(ck_cluster_t) * (size_t)ws.cluster_cap * nb));
+    CK_HIP(hipMalloc(&ws.d_counters, sizeof(uint32_t) * CK_CNT_STRIDE * nb));
+    CK_HIP(hipMalloc(&ws.d_quads, sizeof(ck_quad_t) * (size_t)ws.quad_cap * nb));
+    CK_HIP(hipMalloc(&ws.d_dets, sizeof(ck_detection_t) * (size_t)ws.det_cap * nb));
+    // fit scratch: 3 work lists + counters, then the decode candidates
+    size_t list_bytes = ((size_t)3 * ws.cluster_cap * nb + 16) * sizeof(uint32_t);
+    size_t cand_bytes = 256 + ((nb * 4 + 255) / 256) * 256 + sizeof(ck_detection_t) * (size_t)ws.quad_cap * cfg.n_families * nb;
+    ws.fit_scratch_bytes = ((list_bytes + 255) / 256) * 256 + cand_bytes;
+    CK_HIP(hipMalloc(&ws.d_fit_scratch, ws.fit_scratch_bytes));
+    // family tables
+    std::vector<ck_dev_family> fams((size_t)cfg.n_families);
+    for (int f = 0; f < cfg.n_families; f++) {
+        const ck_family_t *src = cfg.families[f];
+        ck_dev_family &d = fams[(size_t)f];
+        memset(&d, 0, sizeof d);
+        d.nbits = src->nbits; d.ncodes = src->ncodes; d.width_at_border = src->width_at_border;
+        d.total_width = src->total_width; d.reversed_border = src->reversed_border;
+        for (uint32_t i = 0; i < src->nbits; i++) { d.bit_x[i] = src->bit_x[i]; d.bit_y[i] = src->bit_y[i]; }
+        uint64_t *dc = nullptr;
+        CK_HIP(hipMalloc(&dc, sizeof(uint64_t) * src->ncodes));
+        CK_HIP(hipMemcpy(dc, src->codes, sizeof(uint64_t) * src->ncodes, hipMemcpyHostToDevice));
+        d.codes = dc;
+    }
+    CK_HIP(hipMalloc(&h->d_fams, sizeof(ck_dev_family) * fams.size()));
+    CK_HIP(hipMemcpy(h->d_fams, fams.data(), sizeof(ck_dev_family) * fams.size(), hipMemcpyHostToDevice));
+    return CK_OK;
+}
+
+void ck_stage_free(ck_handle *h) {
+    ck_stage_ws &ws = h->ws;
+    if (h->d_fams) {
+        std::vector<ck_dev_family> fams((size_t)h->cfg.n_families);
+        if (hipMemcpy(fams.data(), h->d_fams, sizeof(ck_dev_family) * fams.size(), hipMemcpyDeviceToHost) == hipSuccess)
+            for (auto &f : fams) (void)hipFree(const_cast<uint64_t *>(f.codes));
+        (void)hipFree(h->d_fams);
+    }
+    (void)hipFree(ws.d_ht_keys); (void)hipFree(ws.d_ht_count); (void)hipFree(ws.d_ht_off); (void)hipFree(ws.d_tmp);
+    (void)hipFree(ws.d_points); (void)hipFree(ws.d_clusters); (void)hipFree(ws.d_counters); (void)hipFree(ws.d_quads);
+    (void)hipFree(ws.d_dets); (void)hipFree(ws.d_fit_scratch);
+}
+
+// the whole detector on n frames resident on the device
+static int run_pipeline(ck_handle *h, const uint8_t *frames, int stride, size_t pitch, int n, int upto /*1 clusters, 2 quads, 3 all*/) {
+    hipEvent_t *ev = h->ev;
+    CK_HIP(hipEventRecord(ev[1], h->stream));
+    int rc = ck_run_threshold_segment(h, frames, stride, pitch, n);
+    if (rc != CK_OK) return rc;
+    CK_HIP(hipEventRecord(ev[2], h->stream));
+    rc = ck_launch_clusters(h, n);
+    if (rc != CK_OK) return rc;
+    CK_HIP(hipEventRecord(ev[3], h->stream));
+    if (upto >= 2) {
+        const uint8_t *q = frames; int qs = stride; size_t qp = pitch;
+        if (h->cfg.quad_decimate > 1) { q = h->d_qframes; qs = (h->qw + 15) / 16 * 16; qp = (size_t)qs * h->qh; }
+        rc = ck_launch_fit_quads(h, q, qs, qp, frames, stride, pitch, n);
+        if (rc != CK_OK) return rc;
+    }
+    CK_HIP(hipEventRecord(ev[4], h->stream));
+    if (upto >= 3) {
+        rc = ck_launch_decode(h, frames, stride, pitch, n);
+        if (rc != CK_OK) return rc;
+    }
+    CK_HIP(hipEventRecord(ev[5], h->stream));
+    return CK_OK;
+}
+
+static int fetch_detections(ck_handle *h, int n, ck_detection_t *dets, int cap, int32_t *counts, uint32_t *status) {
+    ck_stage_ws &ws = h->ws;
+    std::vector<uint32_t> counters((size_t)n * CK_CNT_STRIDE);
+    std::vector<ck_detection_t> all((size_t)n * ws.det_cap);
+    CK_HIP(hipMemcpyAsync(counters.data(), ws.d_counters, counters.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+    CK_HIP(hipMemcpyAsync(all.data(), ws.d_dets, all.size() * sizeof(ck_detection_t), hipMemcpyDeviceToHost, h->stream));
+    CK_HIP(hipEventRecord(h->ev[6], h->stream));
+    CK_HIP(hipStreamSynchronize(h->stream));
+    for (int i = 0; i < n; i++) {
+        uint32_t nd = counters[(size_t)i * CK_CNT_STRIDE + CK_CNT_DETS];
+        uint32_t st = counters[(size_t)i * CK_CNT_STRIDE + CK_CNT_STATUS];
+        if ((int)nd > cap) { nd = (uint32_t)cap; st |= CK_FRAME_DETS_OVERFLOW; }
+        memcpy(dets + (size_t)i * cap, all.data() + (size_t)i * ws.det_cap, sizeof(ck_detection_t) * nd);
+        counts[i] = (int32_t)nd;
+        if (status) status[i] = st;
+    }
+    ck_stage_ms_t &ms = h->last_ms;
+    float t;
+    auto el = [&](int a, int b) { t = 0; (void)hipEventElapsedTime(&t, h->ev[a], h->ev[b]); return t; };
+    ms.h2d = el(0, 1); ms.threshold = el(1, 2); ms.segment = 0; ms.clusters = el(2, 3); ms.quads = el(3, 4);
+    ms.decode = el(4, 5); ms.d2h = el(5, 6); ms.total = el(0, 6);
+    return CK_OK;
+}
+
+extern "C" int ck_detect_uploaded(ck_handle_t *h, int32_t n, ck_detection_t *dets, int32_t cap, int32_t *counts, uint32_t *status) {
+    if (!h || !dets || !counts || cap < 1 || n < 0 || n > h->n_staged) return CK_EINVAL;
+    CK_HIP(hipSetDevice(h->device));
+    CK_HIP(hipEventRecord(h->ev[0], h->stream));
+    int rc = run_pipeline(h, h->d_frames, h->frame_stride, h->frame_pitch, n, 3);
+    if (rc != CK_OK) return rc;
+    return fetch_detections(h, n, dets, cap, counts, status);
+}
+
+extern "C" int ck_detect_batch(ck_handle_t *h, const ck_image_u8_t *imgs, int32_t n, ck_detection_t *dets, int32_t cap,
+                               int32_t *counts, uint32_t *status) {
+    if (!h || !dets || !counts || cap < 1) return CK_EINVAL;
+    CK_HIP(hipSetDevice(h->device));
+    CK_HIP(hipEventRecord(h->ev[0], h->stream));
+    int rc = ck_upload_frames(h, imgs, n);
+    if (rc != CK_OK) return rc;
+    rc = run_pipeline(h, h->d_frames, h->frame_stride, h->frame_pitch, n, 3);
+    if (rc != CK_OK) return rc;
+    return fetch_detections(h, n, dets, cap, counts, status);
+}
+
+extern "C" int ck_detect_batch_device(ck_handle_t *h, const uint8_t *d_frames, int32_t n, int32_t stride, int64_t frame_pitch,
+                                      ck_detection_t *dets, int32_t cap, int32_t *counts, uint32_t *status) {
+    if (!h || !dets || !counts || cap < 1) return CK_EINVAL;
+    CK_HIP(hipSetDevice(h->device));
+    CK_HIP(hipEventRecord(h->ev[0], h->stream));
+    const uint8_t *use; int us; size_t up;
+    int rc = ck_stage_device_frames(h, d_frames, n, stride, frame_pitch, &use, &us, &up);
+    if (rc != CK_OK) return rc;
+    rc = run_pipeline(h, use, us, up, n, 3);
+    if (rc != CK_OK) return rc;
+    return fetch_detections(h, n, dets, cap, counts, status);
+}
+
+extern "C" int ck_clusters_batch(ck_handle_t *h, const ck_image_u8_t *imgs, int32_t n, ck_cluster_t *clusters, int32_t cluster_cap,
+                                 int32_t *n_clusters, ck_cluster_point_t *points, int32_t point_cap, int32_t *n_points) {
+    if (!h || !clusters || !n_clusters || !points || !n_points) return CK_EINVAL;
+    CK_HIP(hipSetDevice(h->device));
+    int rc = imgs ? ck_upload_frames(h, imgs, n) : (n <= h->n_staged ? CK_OK : CK_EINVAL);
+    if (rc != CK_OK) return rc;
+    rc = run_pipeline(h, h->d_frames, h->frame_stride, h->frame_pitch, n, 1);
+    if (rc != CK_OK) return rc;
+    ck_stage_ws &ws = h->ws;
+    CK_HIP(hipStreamSynchronize(h->stream));
+    std::vector<uint32_t> counters((size_t)n * CK_CNT_STRIDE);
+    CK_HIP(hipMemcpy(counters.data(), ws.d_counters, counters.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    for (int i = 0; i < n; i++) {
+        uint32_t nc = counters[(size_t)i * CK_CNT_STRIDE + CK_CNT_CLUSTERS], np = counters[(size_t)i * CK_CNT_STRIDE + CK_CNT_POINTS];
+        if ((int)nc > cluster_cap || (int)np > point_cap) return CK_ECAPACITY;
+        CK_HIP(hipMemcpy(clusters + (size_t)i * cluster_cap, ws.d_clusters + (size_t)i * ws.cluster_cap, sizeof(ck_cluster_t) * nc, hipMemcpyDeviceToHost));
+        CK_HIP(hipMemcpy(points + (size_t)i * point_cap, ws.d_points + (size_t)i * ws.point_cap, sizeof(ck_cluster_point_t) * np, hipMemcpyDeviceToHost));
+        n_clusters[i] = (int32_t)nc; n_points[i] = (int32_t)np;
+    }
+    return CK_OK;
+}
+
+extern "C" int ck_quads_batch(ck_handle_t *h, const ck_image_u8_t *imgs, int32_t n, ck_quad_t *quads, int32_t quad_cap, int32_t *n_quads) {
+    if (!h || !quads || !n_quads) return CK_EINVAL;
+    CK_HIP(hipSetDevice(h->device));
+    int rc = imgs ? ck_upload_frames(h, imgs, n) : (n <= h->n_staged ? CK_OK : CK_EINVAL);
+    if (rc != CK_OK) return rc;
+    rc = run_pipeline(h, h->d_frames, h->frame_stride, h->frame_pitch, n, 2);
+    if (rc != CK_OK) return rc;
+    ck_stage_ws &ws = h->ws;
+    CK_HIP(hipStreamSynchronize(h->stream));
+    std::vector<uint32_t> counters((size_t)n * CK_CNT_STRIDE);
+    CK_HIP(hipMemcpy(counters.data(), ws.d_counters, counters.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    for (int i = 0; i < n; i++) {
+        uint32_t nq = counters[(size_t)i * CK_CNT_STRIDE + CK_CNT_QUADS];
+        if ((int)nq > quad_cap) return CK_ECAPACITY;
+        CK_HIP(hipMemcpy(quads + (size_t)i * quad_cap, ws.d_quads + (size_t)i * ws.quad_cap, sizeof(ck_quad_t) * nq, hipMemcpyDeviceToHost));
+        n_quads[i] = (int32_t)nq;
+    }
+    return CK_OK;
+}

@@ -1,0 +1,265 @@
+// k_clusters.hip — gradient clusters: one point per 8-neighbour pair of opposite colour whose components both
+// have >= min_component_px pixels, grouped by the unordered pair of component ids.
+//
+// Replaces the "gradient clusters" stage of the external AprilTag-3 detector (crates/apriltags/src/lib.rs:301);
+// the hash-map-of-component-pairs formulation is the one CAT was converging on (stub `ClusterHash`, `u64hash_2`
+// and the 0.2*w*h cluster map at crates/chalkydri-apriltags/src/lib.rs:115-124,551-557).
+//
+//   k_emit     one workgroup per 16x64 pixel tile: resolves every pixel's component once into LDS (one extra
+//              hop for ring-touching components, see ck_internal.h), aggregates the tile's points per cluster key
+//              in an LDS hash table, then makes ONE global insert + two global atomics per (tile, key) and writes
+//              its points to the temp array with their final rank inside the cluster.
+//   k_scan     one workgroup per frame: prefix sums over the frame's hash table -> cluster table + point offsets
+//              (clusters outside [min_cluster_pixels, max_cluster_points] are dropped here).
+//   k_scatter  temp points -> points grouped by cluster.
+#include "ck_internal.h"
+
+namespace {
+
+constexpr int NT = 256;
+constexpr int ETW = 64, ETH = 16;         // emit tile
+constexpr int LW = ETW + 2, LH = ETH + 1; // staged region: one column each side, one row below
+constexpr int LHT = 512;                  // LDS hash slots
+constexpr uint32_t SKIP = 0xFFFFFFFFu;
+
+__device__ __forceinline__ uint32_t key_hash(unsigned long long k) {
+    uint32_t x = (uint32_t)((k >> 32) ^ k); // u64hash_2 of the reference's stub
+    x *= 2654435761u;
+    return x ^ (x >> 15);
+}
+
+struct EmitArgs {
+    const uint8_t *thresh;
+    const uint32_t *labels;
+    const uint32_t *csize;
+    int w, h, tiles_x, tiles_y, min_comp;
+    ck_stage_ws ws;
+};
+
+// resolved component id of pixel i, or SKIP when it has no component / the component is too small
+__device__ __forceinline__ uint32_t resolve(const uint32_t *L, const uint32_t *C, uint32_t i, int min_comp) {
+    uint32_t l = L[i];
+    if (l & CK_LBL_SMALL) return SKIP; // covers CK_LBL_INVALID too
+    uint32_t rep = l & CK_LBL_IDX_MASK;
+    if (l & CK_LBL_BORDER) {
+        rep = L[rep] & CK_LBL_IDX_MASK;
+        if ((int)C[rep] < min_comp) return SKIP;
+    }
+    return rep;
+}
+
+__global__ __launch_bounds__(NT) void k_emit(EmitArgs a) {
+    __shared__ uint8_t sT[LH][LW + 2];
+    __shared__ uint32_t sR[LH][LW];
+    __shared__ unsigned long long sKey[LHT];
+    __shared__ uint32_t sCnt[LHT], sCnt2[LHT], sSlot[LHT], sBase[LHT], sTBase[LHT];
+    const int tid = threadIdx.x;
+    const int tiles = a.tiles_x * a.tiles_y;
+    const int frame = blockIdx.x / tiles, tile = blockIdx.x - frame * tiles;
+    const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
+    const int x0 = tx * ETW, y0 = ty * ETH;
+    const int w = a.w, h = a.h;
+    const size_t npix = (size_t)w * h;
+    const uint8_t *T = a.thresh + (size_t)frame * npix;
+    const uint32_t *L = a.labels + (size_t)frame * npix;
+    const uint32_t *C = a.csize + (size_t)frame * npix;
+    const ck_stage_ws &ws = a.ws;
+    unsigned long long *gkeys = ws.d_ht_keys + (size_t)frame * ws.ht_size;
+    uint32_t *gcount = ws.d_ht_count + (size_t)frame * ws.ht_size;
+    uint32_t *counters = ws.d_counters + (size_t)frame * CK_CNT_STRIDE;
+    ck_tmp_point *tmp = ws.d_tmp + (size_t)frame * ws.point_cap;
+
+    for (int i = tid; i < LHT; i += NT) { sKey[i] = 0ull; sCnt[i] = 0; sCnt2[i] = 0; }
+    for (int i = tid; i < LH * LW; i += NT) {
+        int ly = i / LW, lx = i - ly * LW;
+        int gy = y0 + ly, gx = x0 - 1 + lx;
+        uint8_t t = 127;
+        uint32_t r = SKIP;
+        if (gy < h && gx >= 0 && gx < w) {
+            uint32_t p = (uint32_t)gy * (uint32_t)w + (uint32_t)gx;
+            t = T[p];
+            if (t != 127) r = resolve(L, C, p, a.min_comp);
+        }
+        sT[ly][lx] = t;
+        sR[ly][lx] = r;
+    }
+    __syncthreads();
+
+    const int lx = (tid & 63) + 1; // staged column of this thread's pixels
+    const int gx = x0 + (tid & 63);
+    const int row0 = (tid >> 6) * 4;
+    const int dxs[4] = {1, 0, -1, 1}, dys[4] = {0, 1, 1, 1};
+    const bool colok = gx >= 1 && gx <= w - 2;
+
+    // pass 1: count points per key in the LDS table
+    if (colok) {
+#pragma unroll
+        for (int rr = 0; rr < 4; rr++) {
+            int ly = row0 + rr, gy = y0 + ly;
+            if (gy < 1 || gy > h - 2) continue;
+            int v0 = sT[ly][lx];
+            uint32_t r0 = sR[ly][lx];
+            if (r0 == SKIP) continue;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                int v1 = sT[ly + dys[k]][lx + dxs[k]];
+                if (v0 + v1 != 255) continue;
+                uint32_t r1 = sR[ly + dys[k]][lx + dxs[k]];
+                if (r1 == SKIP) continue;
+                unsigned long long key = r0 < r1 ? ((unsigned long long)r0 << 32) | r1 : ((unsigned long long)r1 << 32) | r0;
+                uint32_t s = key_hash(key) & (LHT - 1);
+                for (int probe = 0; probe < LHT; probe++) {
+                    unsigned long long prev = atomicCAS(&sKey[s], 0ull, key);
+                    if (prev == 0ull || prev == key) { atomicAdd(&sCnt[s], 1u); break; }
+                    s = (s + 1) & (LHT - 1);
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // pass 2: one global reservation per (tile, key)
+    for (int s = tid; s < LHT; s += NT) {
+        unsigned long long key = sKey[s];
+        if (key == 0ull) continue;
+        uint32_t cnt = sCnt[s];
+        uint32_t g = key_hash(key) & (uint32_t)(ws.ht_size - 1);
+        uint32_t found = SKIP;
+        for (int probe = 0; probe < ws.ht_size; probe++) {
+            unsigned long long prev = atomicCAS(&gkeys[g], 0ull, key);
+            if (prev == 0ull || prev == key) { found = g; break; }
+            g = (g + 1) & (uint32_t)(ws.ht_size - 1);
+        }
+        if (found == SKIP) { atomicOr(&counters[CK_CNT_STATUS], (uint32_t)CK_FRAME_CLUSTERS_OVERFLOW); sSlot[s] = SKIP; continue; }
+        sSlot[s] = found;
+        sBase[s] = atomicAdd(&gcount[found], cnt);
+        sTBase[s] = atomicAdd(&counters[CK_CNT_TMP], cnt);
+    }
+    __syncthreads();
+
+    // pass 3: write the points
+    if (colok) {
+#pragma unroll
+        for (int rr = 0; rr < 4; rr++) {
+            int ly = row0 + rr, gy = y0 + ly;
+            if (gy < 1 || gy > h - 2) continue;
+            int v0 = sT[ly][lx];
+            uint32_t r0 = sR[ly][lx];
+            if (r0 == SKIP) continue;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                int v1 = sT[ly + dys[k]][lx + dxs[k]];
+                if (v0 + v1 != 255) continue;
+                uint32_t r1 = sR[ly + dys[k]][lx + dxs[k]];
+                if (r1 == SKIP) continue;
+                unsigned long long key = r0 < r1 ? ((unsigned long long)r0 << 32) | r1 : ((unsigned long long)r1 << 32) | r0;
+                uint32_t s = key_hash(key) & (LHT - 1);
+                bool hit = false;
+                for (int probe = 0; probe < LHT; probe++) {
+                    unsigned long long kk = sKey[s];
+                    if (kk == key) { hit = true; break; }
+                    if (kk == 0ull) break;
+                    s = (s + 1) & (LHT - 1);
+                }
+                if (!hit) { atomicOr(&counters[CK_CNT_STATUS], (uint32_t)CK_FRAME_CLUSTERS_OVERFLOW); continue; }
+                uint32_t slot = sSlot[s];
+                if (slot == SKIP) continue;
+                uint32_t lr = atomicAdd(&sCnt2[s], 1u);
+                uint32_t ti = sTBase[s] + lr;
+                if (ti >= (uint32_t)ws.point_cap) { atomicOr(&counters[CK_CNT_STATUS], (uint32_t)CK_FRAME_POINTS_OVERFLOW); continue; }
+                ck_tmp_point tp;
+                tp.slot = slot; tp.rank = sBase[s] + lr;
+                tp.x = (uint16_t)(2 * gx + dxs[k]); tp.y = (uint16_t)(2 * gy + dys[k]);
+                int sgn = v1 > v0 ? 1 : -1;
+                tp.gx = (int8_t)(dxs[k] * sgn); tp.gy = (int8_t)(dys[k] * sgn); tp.pad = 0;
+                tmp[ti] = tp;
+            }
+        }
+    }
+}
+
+// ---- per-frame scan of the hash table -------------------------------------------------------------------------
+constexpr int SNT = 1024;
+__global__ __launch_bounds__(SNT) void k_scan(ck_stage_ws ws, int min_cluster, int max_cluster) {
+    __shared__ uint32_t sPts[SNT], sCl[SNT];
+    const int frame = blockIdx.x, tid = threadIdx.x;
+    const unsigned long long *gkeys = ws.d_ht_keys + (size_t)frame * ws.ht_size;
+    const uint32_t *gcount = ws.d_ht_count + (size_t)frame * ws.ht_size;
+    uint32_t *goff = ws.d_ht_off + (size_t)frame * ws.ht_size;
+    uint32_t *counters = ws.d_counters + (size_t)frame * CK_CNT_STRIDE;
+    ck_cluster_t *clusters = ws.d_clusters + (size_t)frame * ws.cluster_cap;
+    const int per = ws.ht_size / SNT; // ht_size is a multiple of SNT
+    uint32_t pts = 0, cl = 0;
+    for (int i = 0; i < per; i++) {
+        uint32_t c = gcount[tid * per + i];
+        if ((int)c >= min_cluster && (int)c <= max_cluster) { pts += c; cl++; }
+    }
+    sPts[tid] = pts; sCl[tid] = cl;
+    __syncthreads();
+    for (int d = 1; d < SNT; d <<= 1) { // inclusive Hillis-Steele scan
+        uint32_t a = 0, b = 0;
+        if (tid >= d) { a = sPts[tid - d]; b = sCl[tid - d]; }
+        __syncthreads();
+        sPts[tid] += a; sCl[tid] += b;
+        __syncthreads();
+    }
+    uint32_t po = sPts[tid] - pts, co = sCl[tid] - cl;
+    for (int i = 0; i < per; i++) {
+        int e = tid * per + i;
+        uint32_t c = gcount[e];
+        uint32_t off = SKIP;
+        if ((int)c >= min_cluster && (int)c <= max_cluster) {
+            if (co < (uint32_t)ws.cluster_cap && po + c <= (uint32_t)ws.point_cap) {
+                off = po;
+                unsigned long long key = gkeys[e];
+                ck_cluster_t ck;
+                ck.rep0 = (uint32_t)(key >> 32); ck.rep1 = (uint32_t)key; ck.start = po; ck.count = c;
+                clusters[co] = ck;
+            } else atomicOr(&counters[CK_CNT_STATUS], (uint32_t)CK_FRAME_CLUSTERS_OVERFLOW);
+            po += c; co++;
+        }
+        goff[e] = off;
+    }
+    if (tid == SNT - 1) {
+        counters[CK_CNT_CLUSTERS] = min(sCl[tid], (uint32_t)ws.cluster_cap);
+        counters[CK_CNT_POINTS] = min(sPts[tid], (uint32_t)ws.point_cap);
+    }
+}
+
+__global__ __launch_bounds__(NT) void k_scatter(ck_stage_ws ws) {
+    const int frame = blockIdx.y;
+    const uint32_t *counters = ws.d_counters + (size_t)frame * CK_CNT_STRIDE;
+    uint32_t n = min(counters[CK_CNT_TMP], (uint32_t)ws.point_cap);
+    const ck_tmp_point *tmp = ws.d_tmp + (size_t)frame * ws.point_cap;
+    const uint32_t *goff = ws.d_ht_off + (size_t)frame * ws.ht_size;
+    ck_cluster_point_t *pts = ws.d_points + (size_t)frame * ws.point_cap;
+    for (uint32_t i = blockIdx.x * NT + threadIdx.x; i < n; i += gridDim.x * NT) {
+        ck_tmp_point tp = tmp[i];
+        uint32_t off = goff[tp.slot];
+        if (off == SKIP) continue;
+        ck_cluster_point_t p;
+        p.x = tp.x; p.y = tp.y; p.gx = tp.gx; p.gy = tp.gy; p.pad = 0;
+        pts[off + tp.rank] = p;
+    }
+}
+
+} // namespace
+
+int ck_launch_clusters(ck_handle *h, int n) {
+    ck_stage_ws &ws = h->ws;
+    CK_HIP(hipMemsetAsync(ws.d_ht_keys, 0, sizeof(unsigned long long) * (size_t)ws.ht_size * n, h->stream));
+    CK_HIP(hipMemsetAsync(ws.d_ht_count, 0, sizeof(uint32_t) * (size_t)ws.ht_size * n, h->stream));
+    CK_HIP(hipMemsetAsync(ws.d_counters, 0, sizeof(uint32_t) * CK_CNT_STRIDE * (size_t)n, h->stream));
+    EmitArgs a;
+    a.thresh = h->d_thresh; a.labels = h->d_labels; a.csize = h->d_csize;
+    a.w = h->qw; a.h = h->qh; a.tiles_x = (h->qw + ETW - 1) / ETW; a.tiles_y = (h->qh + ETH - 1) / ETH;
+    a.min_comp = h->cfg.min_component_px; a.ws = ws;
+    hipLaunchKernelGGL(k_emit, dim3((unsigned)(a.tiles_x * a.tiles_y * n)), dim3(NT), 0, h->stream, a);
+    int min_cluster = h->cfg.min_cluster_pixels < 24 ? 24 : h->cfg.min_cluster_pixels;
+    hipLaunchKernelGGL(k_scan, dim3((unsigned)n), dim3(SNT), 0, h->stream, ws, min_cluster, ws.max_cluster_points);
+    unsigned bx = (unsigned)((ws.point_cap + NT * 4 - 1) / (NT * 4));
+    if (bx > 2048) bx = 2048;
+    hipLaunchKernelGGL(k_scatter, dim3(bx, (unsigned)n), dim3(NT), 0, h->stream, ws);
+    CK_HIP(hipGetLastError());
+    return CK_OK;
+}

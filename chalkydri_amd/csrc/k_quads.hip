@@ -1,0 +1,670 @@
+// k_quads.hip — quad fitting: one workgroup per gradient cluster.
+//
+// Replaces the quad-fit and edge-refinement stages of the external AprilTag-3 detector reached at
+// crates/apriltags/src/lib.rs:301.  Bit-exact with oracle/detector.c (fit_quad, refine_edges): all decisions
+// are made on int64 moments or on doubles evaluated in the oracle's order with -ffp-contract=off.
+//
+// Per cluster (template: NTH threads, up to CAP points, chunks of CH points):
+//   1. bounding box and border direction (integer reductions over the raw points);
+//   2. exact 60-bit angular keys -> bitonic sort in LDS -> drop duplicate coordinates;
+//   3. chunk loop: gradient weights (image gather), int64 moment prefix sums over the chunk + halo (block scan),
+//      windowed line-fit error, 7-tap smoothing, local maxima appended to a per-cluster list that reuses the
+//      cluster's own (now dead) slice of the point array;
+//   4. keep the max_nmaxima strongest maxima, evaluate every 4-subset in parallel (argmin with the oracle's
+//      lexicographic tie-break), intersect the four lines, area/angle/winding checks, optional edge refinement.
+// Clusters are dispatched through per-size-class work lists built by k_classify (S <= 512, M <= 4096,
+// L <= 16384 points); each variant is a persistent grid that pulls cluster indices until the list is drained.
+#include "ck_internal.h"
+
+namespace {
+
+struct FitArgs {
+    const uint8_t *qim; int qw, qh, qstride; size_t qpitch;     // image the clusters came from
+    const uint8_t *im; int w, h, stride; size_t pitch;          // full resolution image
+    int decimate, refine, max_nmaxima, min_tag_width, normal_ok, reversed_ok;
+    double cos_critical, max_mse;
+    ck_stage_ws ws;
+    const uint32_t *list;   // work list of this size class: frame << 20 | cluster index
+    const uint32_t *list_count;
+    uint32_t *head;         // dequeue counter
+};
+
+struct M6 { long long Mx, My, Mxx, Mxy, Myy, W; };
+__device__ __forceinline__ M6 m6_add(M6 a, M6 b) { a.Mx += b.Mx; a.My += b.My; a.Mxx += b.Mxx; a.Mxy += b.Mxy; a.Myy += b.Myy; a.W += b.W; return a; }
+__device__ __forceinline__ M6 m6_sub(M6 a, M6 b) { a.Mx -= b.Mx; a.My -= b.My; a.Mxx -= b.Mxx; a.Mxy -= b.Mxy; a.Myy -= b.Myy; a.W -= b.W; return a; }
+__device__ __forceinline__ M6 m6_zero() { M6 z = {0, 0, 0, 0, 0, 0}; return z; }
+
+__device__ __forceinline__ unsigned long long angle_key(int x, int y, int xmin, int xmax, int ymin, int ymax) {
+    long long dx = 4ll * x - 2ll * (xmin + xmax) - 1;
+    long long dy = 4ll * y - 2ll * (ymin + ymax) + 1;
+    long long ax = dx < 0 ? -dx : dx, ay = dy < 0 ? -dy : dy;
+    int oct, inv;
+    long long num, den;
+    if (dy < 0) {
+        if (dx < 0) { if (ay <= ax) { oct = 0; inv = 0; num = ay; den = ax; } else { oct = 1; inv = 1; num = ax; den = ay; } }
+        else        { if (ay > ax)  { oct = 2; inv = 0; num = ax; den = ay; } else { oct = 3; inv = 1; num = ay; den = ax; } }
+    } else {
+        if (dx > 0) { if (ay <= ax) { oct = 4; inv = 0; num = ay; den = ax; } else { oct = 5; inv = 1; num = ax; den = ay; } }
+        else        { if (ay > ax)  { oct = 6; inv = 0; num = ax; den = ay; } else { oct = 7; inv = 1; num = ay; den = ax; } }
+    }
+    unsigned long long frac = ((unsigned long long)num << 30) / (unsigned long long)den;
+    if (inv) frac = (1ull << 30) - frac;
+    return ((unsigned long long)oct << 57) | (frac << 26) | ((unsigned long long)x << 13) | (unsigned long long)y;
+}
+__device__ __forceinline__ uint32_t isqrt_u32(uint32_t v) {
+    uint32_t r = (uint32_t)sqrt((double)v);
+    while ((unsigned long long)r * r > v) r--;
+    while ((unsigned long long)(r + 1) * (r + 1) <= v) r++;
+    return r;
+}
+
+// line fit from a moment sum over N points (half-pixel units) — mirrors fit_line() of the oracle exactly
+__device__ __forceinline__ void fit_line_m(const M6 &m, int N, double *lineparm, double *err, double *mse) {
+    double dW = (double)m.W;
+    double Ex = (0.5 * (double)m.Mx) / dW;
+    double Ey = (0.5 * (double)m.My) / dW;
+    double Cxx = (0.25 * (double)m.Mxx) / dW - Ex * Ex;
+    double Cxy = (0.25 * (double)m.Mxy) / dW - Ex * Ey;
+    double Cyy = (0.25 * (double)m.Myy) / dW - Ey * Ey;
+    double d = Cxx - Cyy;
+    double q = 4.0 * Cxy;
+    double disc = sqrt(d * d + q * Cxy);
+    double tr = Cxx + Cyy;
+    double eig_small = 0.5 * (tr - disc);
+    if (lineparm) {
+        lineparm[0] = Ex; lineparm[1] = Ey;
+        double eig = 0.5 * (tr + disc);
+        double nx1 = Cxx - eig, ny1 = Cxy;
+        double M1 = nx1 * nx1 + ny1 * ny1;
+        double nx2 = Cxy, ny2 = Cyy - eig;
+        double M2 = nx2 * nx2 + ny2 * ny2;
+        double nx, ny, M;
+        if (M1 > M2) { nx = nx1; ny = ny1; M = M1; } else { nx = nx2; ny = ny2; M = M2; }
+        double length = sqrt(M);
+        if (length < 1e-12) { lineparm[2] = 0; lineparm[3] = 0; }
+        else { lineparm[2] = nx / length; lineparm[3] = ny / length; }
+    }
+    if (err) *err = (double)N * eig_small;
+    if (mse) *mse = eig_small;
+}
+
+__device__ const double k_smooth[7] = {0.011108996538242306, 0.1353352832366127, 0.6065306597126334, 1.0,
+                                       0.6065306597126334, 0.1353352832366127, 0.011108996538242306};
+
+template <int NTH>
+struct Block {
+    static constexpr int NW = NTH / 64;
+    // inclusive sum over the workgroup of one 64-bit value per thread; scratch: NW+1 values of LDS
+    __device__ static long long scan_incl(long long v, long long *scratch, long long *total) {
+        const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+        long long x = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            long long o = __shfl_up(x, d, 64);
+            if (lane >= d) x += o;
+        }
+        if (NW > 1) {
+            if (lane == 63) scratch[wv] = x;
+            __syncthreads();
+            long long base = 0, tot = 0;
+            for (int k = 0; k < NW; k++) { long long t = scratch[k]; if (k < wv) base += t; tot += t; }
+            x += base;
+            if (total) *total = tot;
+            __syncthreads();
+        } else if (total) *total = __shfl(x, 63, 64);
+        return x;
+    }
+    __device__ static int reduce_min(int v, int *scratch) {
+        const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) v = min(v, __shfl_xor(v, d, 64));
+        if (NW > 1) {
+            if (lane == 0) scratch[wv] = v;
+            __syncthreads();
+            int r = scratch[0];
+            for (int k = 1; k < NW; k++) r = min(r, scratch[k]);
+            __syncthreads();
+            return r;
+        }
+        return v;
+    }
+    __device__ static long long reduce_add(long long v, long long *scratch) {
+        const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+        if (NW > 1) {
+            if (lane == 0) scratch[wv] = v;
+            __syncthreads();
+            long long r = 0;
+            for (int k = 0; k < NW; k++) r += scratch[k];
+            __syncthreads();
+            return r;
+        }
+        return v;
+    }
+    __device__ static void sync() { __syncthreads(); }
+};
+
+__device__ __forceinline__ void key_xy(unsigned long long k, int *x, int *y) { *x = (int)((k >> 13) & 0x1FFF); *y = (int)(k & 0x1FFF); }
+
+// moment contribution of one sorted point
+__device__ __forceinline__ M6 point_moments(const FitArgs &a, const uint8_t *qim, unsigned long long key) {
+    int x, y;
+    key_xy(key, &x, &y);
+    int ix = (x + 1) >> 1, iy = (y + 1) >> 1;
+    long long W = 1;
+    if (ix > 0 && ix + 1 < a.qw && iy > 0 && iy + 1 < a.qh) {
+        int gx = (int)qim[(size_t)iy * a.qstride + ix + 1] - (int)qim[(size_t)iy * a.qstride + ix - 1];
+        int gy = (int)qim[(size_t)(iy + 1) * a.qstride + ix] - (int)qim[(size_t)(iy - 1) * a.qstride + ix];
+        W = (long long)isqrt_u32((uint32_t)(gx * gx + gy * gy)) + 1;
+    }
+    long long X = x + 1, Y = y + 1;
+    M6 m;
+    m.Mx = W * X; m.My = W * Y; m.Mxx = W * X * X; m.Mxy = W * X * Y; m.Myy = W * Y * Y; m.W = W;
+    return m;
+}
+
+// edge refinement of one quad edge: returns the refitted line {Ex,Ey,nx,ny} (oracle refine_edges, per edge)
+__device__ void refine_edge(const FitArgs &a, const uint8_t *im, const double p[4][2], int reversed, int edge, double line[4]) {
+    int ea = edge, eb = (edge + 1) & 3;
+    double nx = p[eb][1] - p[ea][1];
+    double ny = -p[eb][0] + p[ea][0];
+    double mag = sqrt(nx * nx + ny * ny);
+    nx = nx / mag; ny = ny / mag;
+    if (reversed) { nx = -nx; ny = -ny; }
+    int nsamples = (int)(mag / 8.0);
+    if (nsamples < 16) nsamples = 16;
+    double Mx = 0, My = 0, Mxx = 0, Mxy = 0, Myy = 0, N = 0;
+    const int w = a.w, h = a.h;
+    for (int s = 0; s < nsamples; s++) {
+        double alpha = (1.0 + (double)s) / ((double)nsamples + 1.0);
+        double x0 = alpha * p[ea][0] + (1.0 - alpha) * p[eb][0];
+        double y0 = alpha * p[ea][1] + (1.0 - alpha) * p[eb][1];
+        double Mn = 0, Mcount = 0;
+        int range = a.decimate + 1;
+        for (int n = -range; n <= range; n++) {
+            double grange = 1.0;
+            int x1 = (int)(x0 + ((double)n + grange) * nx), y1 = (int)(y0 + ((double)n + grange) * ny);
+            if (x1 < 0 || x1 >= w || y1 < 0 || y1 >= h) continue;
+            int x2 = (int)(x0 + ((double)n - grange) * nx), y2 = (int)(y0 + ((double)n - grange) * ny);
+            if (x2 < 0 || x2 >= w || y2 < 0 || y2 >= h) continue;
+            int g1 = im[(size_t)y1 * a.stride + x1], g2 = im[(size_t)y2 * a.stride + x2];
+            if (g1 < g2) continue;
+            double weight = (double)((g2 - g1) * (g2 - g1));
+            Mn += weight * (double)n;
+            Mcount += weight;
+        }
+        if (Mcount == 0) continue;
+        double n0 = Mn / Mcount;
+        double bx = x0 + n0 * nx, by = y0 + n0 * ny;
+        Mx += bx; My += by; Mxx += bx * bx; Mxy += bx * by; Myy += by * by; N += 1.0;
+    }
+    if (N < 2.0) {
+        line[0] = 0.5 * (p[ea][0] + p[eb][0]); line[1] = 0.5 * (p[ea][1] + p[eb][1]);
+        line[2] = nx; line[3] = ny;
+        return;
+    }
+    double Ex = Mx / N, Ey = My / N;
+    double Cxx = Mxx / N - Ex * Ex, Cxy = Mxy / N - Ex * Ey, Cyy = Myy / N - Ey * Ey;
+    double d = Cxx - Cyy, q = 4.0 * Cxy;
+    double disc = sqrt(d * d + q * Cxy);
+    double eig = 0.5 * (Cxx + Cyy + disc);
+    double nx1 = Cxx - eig, ny1 = Cxy, M1 = nx1 * nx1 + ny1 * ny1;
+    double nx2 = Cxy, ny2 = Cyy - eig, M2 = nx2 * nx2 + ny2 * ny2;
+    double fx, fy, M;
+    if (M1 > M2) { fx = nx1; fy = ny1; M = M1; } else { fx = nx2; fy = ny2; M = M2; }
+    double len = sqrt(M);
+    line[0] = Ex; line[1] = Ey;
+    if (len < 1e-12) { line[2] = nx; line[3] = ny; }
+    else { line[2] = fx / len; line[3] = fy / len; }
+}
+
+constexpr int HALO = 24;   // 20 (window) + 3 (smoothing) + 1 (maxima neighbour)
+constexpr int MAXSEL = 16; // >= max_nmaxima supported
+
+template <int NTH, int CAP, int CH>
+__global__ __launch_bounds__(NTH) void k_fit(FitArgs a) {
+    using B = Block<NTH>;
+    constexpr int SL = CH + 2 * HALO;
+    constexpr int NCH = CAP / CH;
+    __shared__ unsigned long long sKeys[CAP];
+    __shared__ long long sP[6][SL];          // inclusive moment prefix sums over the current span
+    __shared__ double sErr[SL], sSm[SL];
+    __shared__ long long sTot[NCH + 1][6];   // cumulative moments at chunk ends
+    __shared__ long long sScratch[2 * (NTH / 64) + 2];
+    __shared__ int sSelIdx[MAXSEL];
+    __shared__ long long sSelI[MAXSEL][6], sSelE[MAXSEL][6];
+    __shared__ double sRed[NTH / 64 + 1];
+    __shared__ int sRedI[NTH / 64 + 1];
+    __shared__ uint32_t sWork;
+    __shared__ int sNmax, sFlag;
+    __shared__ double sLines[4][4];
+    __shared__ double sQuad[4][2];
+    const int tid = threadIdx.x;
+    const ck_stage_ws &ws = a.ws;
+
+    for (;;) {
+        __syncthreads();
+        if (tid == 0) sWork = atomicAdd(a.head, 1u);
+        __syncthreads();
+        const uint32_t work = sWork;
+        if (work >= *a.list_count) break; // every wave of every workgroup reaches this exit
+        const uint32_t item = a.list[work];
+        const int frame = (int)(item >> 20), ci = (int)(item & 0xFFFFFu);
+        const ck_cluster_t cl = ws.d_clusters[(size_t)frame * ws.cluster_cap + ci];
+        ck_cluster_point_t *pts = ws.d_points + (size_t)frame * ws.point_cap + cl.start;
+        const int sz0 = (int)cl.count;
+        const uint8_t *qim = a.qim + (size_t)frame * a.qpitch;
+        const uint8_t *im = a.im + (size_t)frame * a.pitch;
+        if (sz0 > CAP) continue; // cannot happen: the class lists are built from the counts
+
+        // ---- 1. bounding box + border direction ----------------------------------------------------------
+        int xmin = 1 << 30, xmax = -(1 << 30), ymin = 1 << 30, ymax = -(1 << 30);
+        for (int i = tid; i < sz0; i += NTH) {
+            ck_cluster_point_t p = pts[i];
+            xmin = min(xmin, (int)p.x); xmax = max(xmax, (int)p.x);
+            ymin = min(ymin, (int)p.y); ymax = max(ymax, (int)p.y);
+        }
+        int *iscr = reinterpret_cast<int *>(sScratch);
+        xmin = B::reduce_min(xmin, iscr); xmax = -B::reduce_min(-xmax, iscr);
+        ymin = B::reduce_min(ymin, iscr); ymax = -B::reduce_min(-ymax, iscr);
+        if ((xmax - xmin) * (ymax - ymin) < a.min_tag_width) continue;
+        long long dot = 0;
+        int n2 = 1;
+        while (n2 < sz0) n2 <<= 1;
+        for (int i = tid; i < n2; i += NTH) {
+            unsigned long long key = ~0ull;
+            if (i < sz0) {
+                ck_cluster_point_t p = pts[i];
+                long long dx = 4ll * p.x - 2ll * (xmin + xmax) - 1;
+                long long dy = 4ll * p.y - 2ll * (ymin + ymax) + 1;
+                dot += dx * p.gx + dy * p.gy;
+                key = angle_key(p.x, p.y, xmin, xmax, ymin, ymax);
+            }
+            sKeys[i] = key;
+        }
+        dot = B::reduce_add(dot, sScratch);
+        const int reversed = dot < 0;
+        if (reversed && !a.reversed_ok) continue;
+        if (!reversed && !a.normal_ok) continue;
+
+        // ---- 2. bitonic sort + duplicate removal -------------------------------------------------------------
+        __syncthreads();
+        for (int k = 2; k <= n2; k <<= 1)
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                for (int t = tid; t < (n2 >> 1); t += NTH) {
+                    int i = 2 * t - (t & (j - 1));
+                    int l = i + j;
+                    unsigned long long ka = sKeys[i], kb = sKeys[l];
+                    bool up = (i & k) == 0;
+                    if ((ka > kb) == up) { sKeys[i] = kb; sKeys[l] = ka; }
+                }
+                __syncthreads();
+            }
+        int sz = 0;
+        for (int base = 0; base < sz0; base += NTH) {
+            int i = base + tid;
+            unsigned long long key = 0;
+            int keep = 0;
+            if (i < sz0) { key = sKeys[i]; keep = (i == 0) || (sKeys[i - 1] != key); }
+            long long tot = 0;
+            long long incl = B::scan_incl((long long)keep, sScratch, &tot);
+            __syncthreads();
+            if (keep) sKeys[sz + (int)incl - 1] = key;
+            sz += (int)tot;
+            __syncthreads();
+        }
+        if (sz < 24) continue;
+        const int ksz = sz / 12 < 20 ? sz / 12 : 20;
+        if (ksz < 2) continue;
+
+        // the cluster's slice of the point array is dead from here on: reuse it for the maxima list
+        double *mval = reinterpret_cast<double *>(pts);
+        uint32_t *midx = reinterpret_cast<uint32_t *>(mval + (sz0 + 1) / 2);
+        if (tid == 0) { sNmax = 0; sFlag = 0; }
+        if (tid < 6) sTot[0][tid] = 0;
+        __syncthreads();
+
+        // ---- 3. chunk loop ----------------------------------------------------------------------------------------
+        const int nch = (sz + CH - 1) / CH;
+        for (int c = 0; c < nch; c++) {
+            const int cbase = c * CH;
+            const int chn = min(CH, sz - cbase);
+            const int sl = chn + 2 * HALO;
+            // moments of the span, then an in-place inclusive scan (blocked: EPT consecutive elements per thread)
+            constexpr int EPT = (SL + NTH - 1) / NTH;
+            M6 loc[EPT];
+            M6 run = m6_zero();
+#pragma unroll
+            for (int e = 0; e < EPT; e++) {
+                int j = tid * EPT + e;
+                M6 m = m6_zero();
+                if (j < sl) {
+                    int gi = (cbase - HALO + j) % sz;
+                    if (gi < 0) gi += sz;
+                    m = point_moments(a, qim, sKeys[gi]);
+                }
+                run = m6_add(run, m);
+                loc[e] = run;
+            }
+            long long v[6] = {run.Mx, run.My, run.Mxx, run.Mxy, run.Myy, run.W}, ex[6];
+#pragma unroll
+            for (int q = 0; q < 6; q++) ex[q] = B::scan_incl(v[q], sScratch, nullptr) - v[q];
+#pragma unroll
+            for (int e = 0; e < EPT; e++) {
+                int j = tid * EPT + e;
+                if (j < sl) {
+                    sP[0][j] = loc[e].Mx + ex[0]; sP[1][j] = loc[e].My + ex[1]; sP[2][j] = loc[e].Mxx + ex[2];
+                    sP[3][j] = loc[e].Mxy + ex[3]; sP[4][j] = loc[e].Myy + ex[4]; sP[5][j] = loc[e].W + ex[5];
+                }
+            }
+            __syncthreads();
+            if (tid < 6) sTot[c + 1][tid] = sTot[c][tid] + sP[tid][HALO + chn - 1] - sP[tid][HALO - 1];
+            // windowed line-fit error
+            for (int j = HALO - 4 + tid; j < HALO + chn + 4; j += NTH) {
+                int hi = j + ksz, lo = j - ksz - 1;
+                M6 m = {sP[0][hi], sP[1][hi], sP[2][hi], sP[3][hi], sP[4][hi], sP[5][hi]};
+                if (lo >= 0) { M6 l = {sP[0][lo], sP[1][lo], sP[2][lo], sP[3][lo], sP[4][lo], sP[5][lo]}; m = m6_sub(m, l); }
+                double e;
+                fit_line_m(m, 2 * ksz + 1, nullptr, &e, nullptr);
+                sErr[j] = e;
+            }
+            __syncthreads();
+            for (int j = HALO - 1 + tid; j < HALO + chn + 1; j += NTH) {
+                double acc = 0.0;
+#pragma unroll
+                for (int q = 0; q < 7; q++) acc += sErr[j + q - 3] * k_smooth[q];
+                sSm[j] = acc;
+            }
+            __syncthreads();
+            for (int j = HALO + tid; j < HALO + chn; j += NTH) {
+                double s = sSm[j];
+                if (s > sSm[j + 1] && s > sSm[j - 1]) {
+                    int pos = atomicAdd(&sNmax, 1);
+                    mval[pos] = s;                 // pos < sz/2 <= capacity of the reused slice
+                    midx[pos] = (uint32_t)(cbase + j - HALO);
+                }
+            }
+            __syncthreads();
+        }
+        const int nmax_all = sNmax;
+        if (nmax_all < 4) continue;
+        __threadfence_block();
+
+        // ---- 4a. threshold = (max_nmaxima+1)-th largest smoothed error -----------------------------------------------
+        double thr = -1.0; // keep everything (errors are >= 0 up to rounding; use -inf semantics below)
+        bool use_thr = false;
+        if (nmax_all > a.max_nmaxima) {
+            use_thr = true;
+            double cur = HUGE_VAL;
+            int remaining = a.max_nmaxima + 1;
+            for (int round = 0; round <= a.max_nmaxima; round++) {
+                double m = -HUGE_VAL;
+                for (int i = tid; i < nmax_all; i += NTH) { double v = mval[i]; if (v < cur && v > m) m = v; }
+                // block max
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) { double o = __shfl_xor(m, d, 64); if (o > m) m = o; }
+                if (NTH > 64) {
+                    if ((tid & 63) == 0) sRed[tid >> 6] = m;
+                    __syncthreads();
+                    m = sRed[0];
+                    for (int k = 1; k < NTH / 64; k++) if (sRed[k] > m) m = sRed[k];
+                    __syncthreads();
+                }
+                long long cnt = 0;
+                for (int i = tid; i < nmax_all; i += NTH) cnt += (mval[i] == m);
+                cnt = B::reduce_add(cnt, sScratch);
+                if (cnt >= remaining) { thr = m; break; }
+                remaining -= (int)cnt;
+                cur = m;
+            }
+        }
+        // selected maxima, in increasing index order (rank by index among the survivors)
+        if (tid == 0) sNmax = 0;
+        __syncthreads();
+        for (int i = tid; i < nmax_all; i += NTH) {
+            double v = mval[i];
+            if (use_thr && v <= thr) continue;
+            uint32_t idx = midx[i];
+            int rank = 0;
+            for (int k = 0; k < nmax_all; k++) {
+                double vk = mval[k];
+                if (use_thr && vk <= thr) continue;
+                if (midx[k] < idx) rank++;
+            }
+            if (rank < MAXSEL) sSelIdx[rank] = (int)idx;
+            atomicAdd(&sNmax, 1);
+        }
+        __syncthreads();
+        const int nsel = sNmax;
+        if (nsel < 4 || nsel > MAXSEL) continue;
+
+        // ---- 4b. moment prefix sums at the selected maxima ------------------------------------------------------------------
+        for (int s = 0; s < nsel; s++) {
+            const int gi = sSelIdx[s];
+            const int c = gi / CH, cb = c * CH;
+            M6 part = m6_zero(), self = m6_zero();
+            for (int i = cb + tid; i <= gi; i += NTH) {
+                M6 m = point_moments(a, qim, sKeys[i]);
+                part = m6_add(part, m);
+                if (i == gi) self = m;
+            }
+            long long pv[6] = {part.Mx, part.My, part.Mxx, part.Mxy, part.Myy, part.W};
+            long long sv[6] = {self.Mx, self.My, self.Mxx, self.Mxy, self.Myy, self.W};
+#pragma unroll
+            for (int q = 0; q < 6; q++) {
+                long long t = B::reduce_add(pv[q], sScratch);
+                long long u = B::reduce_add(sv[q], sScratch);
+                if (tid == 0) { sSelI[s][q] = sTot[c][q] + t; sSelE[s][q] = sTot[c][q] + t - u; }
+            }
+        }
+        __syncthreads();
+        const M6 total = {sTot[nch][0], sTot[nch][1], sTot[nch][2], sTot[nch][3], sTot[nch][4], sTot[nch][5]};
+        auto rangeM = [&](int sa, int sb, int *N) { // points from maximum sa to maximum sb inclusive, going forward
+            M6 I = {sSelI[sb][0], sSelI[sb][1], sSelI[sb][2], sSelI[sb][3], sSelI[sb][4], sSelI[sb][5]};
+            M6 E = {sSelE[sa][0], sSelE[sa][1], sSelE[sa][2], sSelE[sa][3], sSelE[sa][4], sSelE[sa][5]};
+            int i0 = sSelIdx[sa], i1 = sSelIdx[sb];
+            if (i0 < i1) { *N = i1 - i0 + 1; return m6_sub(I, E); }
+            *N = sz - i0 + i1 + 1;
+            return m6_add(m6_sub(total, E), I);
+        };
+
+        // ---- 4c. all 4-subsets in parallel; argmin with lexicographic tie-break ---------------------------------------------
+        double best = HUGE_VAL;
+        int bestc = 1 << 30;
+        {
+            int combo = 0;
+            for (int m0 = 0; m0 < nsel - 3; m0++)
+                for (int m1 = m0 + 1; m1 < nsel - 2; m1++)
+                    for (int m2 = m1 + 1; m2 < nsel - 1; m2++)
+                        for (int m3 = m2 + 1; m3 < nsel; m3++, combo++) {
+                            if ((combo % NTH) != tid) continue;
+                            int N;
+                            double p01[4], p12[4], e01, s01, e12, s12, e23, s23, e30, s30;
+                            M6 m = rangeM(m0, m1, &N); fit_line_m(m, N, p01, &e01, &s01);
+                            if (s01 > a.max_mse) continue;
+                            m = rangeM(m1, m2, &N); fit_line_m(m, N, p12, &e12, &s12);
+                            if (s12 > a.max_mse) continue;
+                            double dp = p01[2] * p12[2] + p01[3] * p12[3];
+                            if (fabs(dp) > a.cos_critical) continue;
+                            m = rangeM(m2, m3, &N); fit_line_m(m, N, nullptr, &e23, &s23);
+                            if (s23 > a.max_mse) continue;
+                            m = rangeM(m3, m0, &N); fit_line_m(m, N, nullptr, &e30, &s30);
+                            if (s30 > a.max_mse) continue;
+                            double e = e01 + e12 + e23 + e30;
+                            if (e < best) { best = e; bestc = (m0 << 12) | (m1 << 8) | (m2 << 4) | m3; }
+                        }
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            double ob = __shfl_xor(best, d, 64);
+            int oc = __shfl_xor(bestc, d, 64);
+            if (ob < best || (ob == best && oc < bestc)) { best = ob; bestc = oc; }
+        }
+        if (NTH > 64) {
+            if ((tid & 63) == 0) { sRed[tid >> 6] = best; sRedI[tid >> 6] = bestc; }
+            __syncthreads();
+            best = sRed[0]; bestc = sRedI[0];
+            for (int k = 1; k < NTH / 64; k++)
+                if (sRed[k] < best || (sRed[k] == best && sRedI[k] < bestc)) { best = sRed[k]; bestc = sRedI[k]; }
+            __syncthreads();
+        }
+        if (best == HUGE_VAL) continue;
+        if (best / (double)sz >= a.max_mse) continue;
+
+        // ---- 4d. lines, corners, geometric checks (one lane; sequential like the oracle) ---------------------------------------
+        if (tid == 0) {
+            int sel[4] = {(bestc >> 12) & 15, (bestc >> 8) & 15, (bestc >> 4) & 15, bestc & 15};
+            double lines[4][4];
+            int ok = 1;
+            for (int i = 0; i < 4 && ok; i++) {
+                int N;
+                double mse;
+                M6 m = rangeM(sel[i], sel[(i + 1) & 3], &N);
+                fit_line_m(m, N, lines[i], nullptr, &mse);
+                if (mse > a.max_mse) ok = 0;
+            }
+            double P[4][2];
+            for (int i = 0; i < 4 && ok; i++) {
+                int j = (i + 1) & 3;
+                double A00 = lines[i][3], A01 = -lines[j][3], A10 = -lines[i][2], A11 = lines[j][2];
+                double B0 = -lines[i][0] + lines[j][0], B1 = -lines[i][1] + lines[j][1];
+                double det = A00 * A11 - A10 * A01;
+                if (fabs(det) < 0.001) { ok = 0; break; }
+                double W00 = A11 / det, W01 = -A01 / det;
+                double L0 = W00 * B0 + W01 * B1;
+                P[i][0] = lines[i][0] + L0 * A00;
+                P[i][1] = lines[i][1] + L0 * A10;
+            }
+            if (ok) {
+                double area = 0.0;
+                const int tri[2][3] = {{0, 1, 2}, {2, 3, 0}};
+                for (int t = 0; t < 2; t++) {
+                    double len[3];
+                    for (int i = 0; i < 3; i++) {
+                        int pa = tri[t][i], pb = tri[t][(i + 1) % 3];
+                        double ddx = P[pb][0] - P[pa][0], ddy = P[pb][1] - P[pa][1];
+                        len[i] = sqrt(ddx * ddx + ddy * ddy);
+                    }
+                    double pp = (len[0] + len[1] + len[2]) / 2.0;
+                    area += sqrt(pp * (pp - len[0]) * (pp - len[1]) * (pp - len[2]));
+                }
+                double tw = (double)a.min_tag_width;
+                if (area < 0.95 * tw * tw) ok = 0;
+            }
+            for (int i = 0; i < 4 && ok; i++) {
+                int i0 = i, i1 = (i + 1) & 3, i2 = (i + 2) & 3;
+                double dx1 = P[i1][0] - P[i0][0], dy1 = P[i1][1] - P[i0][1];
+                double dx2 = P[i2][0] - P[i1][0], dy2 = P[i2][1] - P[i1][1];
+                double cs = (dx1 * dx2 + dy1 * dy2) / sqrt((dx1 * dx1 + dy1 * dy1) * (dx2 * dx2 + dy2 * dy2));
+                if (cs > a.cos_critical || cs < -a.cos_critical) ok = 0;
+                if (dx1 * dy2 < dy1 * dx2) ok = 0;
+            }
+            if (ok && a.decimate > 1)
+                for (int i = 0; i < 4; i++) {
+                    P[i][0] = (P[i][0] - 0.5) * (double)a.decimate + 0.5;
+                    P[i][1] = (P[i][1] - 0.5) * (double)a.decimate + 0.5;
+                }
+            for (int i = 0; i < 4; i++) { sQuad[i][0] = P[i][0]; sQuad[i][1] = P[i][1]; }
+            sFlag = ok;
+        }
+        __syncthreads();
+        if (!sFlag) continue;
+        if (a.refine) {
+            if (tid < 4) {
+                double P[4][2], line[4];
+                for (int i = 0; i < 4; i++) { P[i][0] = sQuad[i][0]; P[i][1] = sQuad[i][1]; }
+                refine_edge(a, im, P, reversed, tid, line);
+                for (int q = 0; q < 4; q++) sLines[tid][q] = line[q];
+            }
+            __syncthreads();
+            if (tid == 0)
+                for (int i = 0; i < 4; i++) {
+                    int j = (i + 1) & 3;
+                    double A00 = sLines[i][3], A01 = -sLines[j][3], A10 = -sLines[i][2], A11 = sLines[j][2];
+                    double B0 = -sLines[i][0] + sLines[j][0], B1 = -sLines[i][1] + sLines[j][1];
+                    double det = A00 * A11 - A10 * A01;
+                    if (fabs(det) > 0.001) {
+                        double W00 = A11 / det, W01 = -A01 / det;
+                        double L0 = W00 * B0 + W01 * B1;
+                        sQuad[j][0] = sLines[i][0] + L0 * A00;
+                        sQuad[j][1] = sLines[i][1] + L0 * A10;
+                    }
+                }
+        }
+        if (tid == 0) {
+            uint32_t *counters = ws.d_counters + (size_t)frame * CK_CNT_STRIDE;
+            uint32_t qi = atomicAdd(&counters[CK_CNT_QUADS], 1u);
+            if (qi < (uint32_t)ws.quad_cap) {
+                ck_quad_t q;
+                for (int i = 0; i < 4; i++) { q.p[i][0] = sQuad[i][0]; q.p[i][1] = sQuad[i][1]; }
+                q.reversed_border = reversed; q.rep0 = cl.rep0; q.rep1 = cl.rep1;
+                ws.d_quads[(size_t)frame * ws.quad_cap + qi] = q;
+            } else atomicOr(&counters[CK_CNT_STATUS], (uint32_t)CK_FRAME_QUADS_OVERFLOW);
+        }
+    }
+}
+
+// builds the three per-size-class work lists from the cluster tables
+__global__ __launch_bounds__(256) void k_classify(ck_stage_ws ws, int n, uint32_t *lists, uint32_t *list_counts, int list_cap) {
+    const int frame = blockIdx.y;
+    const uint32_t *counters = ws.d_counters + (size_t)frame * CK_CNT_STRIDE;
+    const uint32_t nc = counters[CK_CNT_CLUSTERS];
+    const ck_cluster_t *cls = ws.d_clusters + (size_t)frame * ws.cluster_cap;
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < nc; i += gridDim.x * 256) {
+        uint32_t c = cls[i].count;
+        int k = c <= 512 ? 0 : (c <= 4096 ? 1 : 2);
+        uint32_t pos = atomicAdd(&list_counts[k], 1u);
+        if (pos < (uint32_t)list_cap) lists[(size_t)k * list_cap + pos] = ((uint32_t)frame << 20) | i;
+    }
+}
+__global__ void k_clamp_counts(uint32_t *list_counts, int list_cap, ck_stage_ws ws, int n) {
+    int t = threadIdx.x;
+    if (t < 3 && list_counts[t] > (uint32_t)list_cap) list_counts[t] = (uint32_t)list_cap;
+    for (int f = t; f < n; f += blockDim.x) {
+        uint32_t *c = ws.d_counters + (size_t)f * CK_CNT_STRIDE;
+        if (c[CK_CNT_QUADS] > (uint32_t)ws.quad_cap) c[CK_CNT_QUADS] = (uint32_t)ws.quad_cap;
+    }
+}
+
+} // namespace
+
+int ck_launch_fit_quads(ck_handle *h, const uint8_t *qframes, int qstride, size_t qpitch, const uint8_t *frames, int stride,
+                        size_t pitch, int n) {
+    ck_stage_ws &ws = h->ws;
+    if (n > 4095 || ws.cluster_cap > (1 << 20)) return CK_EINVAL;
+    // work lists live in the fit scratch: [3][list_cap] entries + 3 counts + 3 heads
+    const int list_cap = ws.cluster_cap * h->cfg.max_batch;
+    uint32_t *lists = reinterpret_cast<uint32_t *>(ws.d_fit_scratch);
+    uint32_t *list_counts = lists + (size_t)3 * list_cap;
+    uint32_t *heads = list_counts + 4;
+    CK_HIP(hipMemsetAsync(list_counts, 0, sizeof(uint32_t) * 8, h->stream));
+    unsigned bx = (unsigned)((ws.cluster_cap + 255) / 256);
+    if (bx > 64) bx = 64;
+    hipLaunchKernelGGL(k_classify, dim3(bx, (unsigned)n), dim3(256), 0, h->stream, ws, n, lists, list_counts, list_cap);
+    hipLaunchKernelGGL(k_clamp_counts, dim3(1), dim3(64), 0, h->stream, list_counts, list_cap, ws, 0);
+    FitArgs a;
+    a.qim = qframes; a.qw = h->qw; a.qh = h->qh; a.qstride = qstride; a.qpitch = qpitch;
+    a.im = frames; a.w = h->w; a.h = h->h; a.stride = stride; a.pitch = pitch;
+    a.decimate = h->cfg.quad_decimate; a.refine = h->cfg.refine_edges; a.max_nmaxima = h->cfg.max_nmaxima;
+    a.cos_critical = h->cfg.cos_critical_rad; a.max_mse = h->cfg.max_line_fit_mse;
+    a.normal_ok = 0; a.reversed_ok = 0; a.min_tag_width = 1 << 30;
+    for (int f = 0; f < h->cfg.n_families; f++) {
+        const ck_family_t *fam = h->cfg.families[f];
+        if (fam->width_at_border < a.min_tag_width) a.min_tag_width = fam->width_at_border;
+        if (fam->reversed_border) a.reversed_ok = 1; else a.normal_ok = 1;
+    }
+    a.min_tag_width /= h->cfg.quad_decimate;
+    if (a.min_tag_width < 3) a.min_tag_width = 3;
+    a.ws = ws;
+    int cus = 256;
+    a.list = lists; a.list_count = list_counts; a.head = heads;
+    hipLaunchKernelGGL((k_fit<64, 512, 128>), dim3((unsigned)(cus * 8)), dim3(64), 0, h->stream, a);
+    a.list = lists + list_cap; a.list_count = list_counts + 1; a.head = heads + 1;
+    hipLaunchKernelGGL((k_fit<256, 4096, 256>), dim3((unsigned)(cus * 2)), dim3(256), 0, h->stream, a);
+    a.list = lists + 2 * (size_t)list_cap; a.list_count = list_counts + 2; a.head = heads + 2;
+    hipLaunchKernelGGL((k_fit<1024, 16384, 256>), dim3((unsigned)cus), dim3(1024), 0, h->stream, a);
+    hipLaunchKernelGGL(k_clamp_counts, dim3(1), dim3(64), 0, h->stream, list_counts, list_cap, ws, n);
+    CK_HIP(hipGetLastError());
+    return CK_OK;
+}

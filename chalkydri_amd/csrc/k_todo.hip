@@ -1,15 +1,8 @@
 // Entry points whose kernels are not built yet: they exist so the ABI is complete and fail loudly.
 #include "ck_internal.h"
 
-int ck_stage_alloc(ck_handle *) { return CK_OK; }
-void ck_stage_free(ck_handle *) {}
 
 extern "C" {
-int ck_detect_batch(ck_handle_t *, const ck_image_u8_t *, int32_t, ck_detection_t *, int32_t, int32_t *, uint32_t *) { return CK_EUNSUPPORTED; }
-int ck_detect_batch_device(ck_handle_t *, const uint8_t *, int32_t, int32_t, int64_t, ck_detection_t *, int32_t, int32_t *, uint32_t *) { return CK_EUNSUPPORTED; }
-int ck_detect_uploaded(ck_handle_t *, int32_t, ck_detection_t *, int32_t, int32_t *, uint32_t *) { return CK_EUNSUPPORTED; }
-int ck_clusters_batch(ck_handle_t *, const ck_image_u8_t *, int32_t, ck_cluster_t *, int32_t, int32_t *, ck_cluster_point_t *, int32_t, int32_t *) { return CK_EUNSUPPORTED; }
-int ck_quads_batch(ck_handle_t *, const ck_image_u8_t *, int32_t, ck_quad_t *, int32_t, int32_t *) { return CK_EUNSUPPORTED; }
 int ck_cat_calc_otsu(ck_handle_t *, const uint8_t *, int32_t, int32_t, uint8_t *) { return CK_EUNSUPPORTED; }
 int ck_cat_thresh(ck_handle_t *, const uint8_t *, int32_t, int32_t, uint8_t *) { return CK_EUNSUPPORTED; }
 int ck_cat_detect_corners(ck_handle_t *, const uint8_t *, int32_t, int32_t, uint32_t *, int32_t, int32_t *) { return CK_EUNSUPPORTED; }

@@ -808,7 +808,7 @@ int ora_detect(const uint8_t *img, int w, int h, int stride, const ck_config_t *
     uint32_t *labels = (uint32_t *)malloc(n * 4), *sizes = (uint32_t *)malloc(n * 4);
     ora_threshold(q, qw, qh, qstride, cfg->min_white_black_diff, th);
     ora_segment(th, qw, qh, labels, sizes);
-    int pcap = cfg->max_points_per_frame > 0 ? cfg->max_points_per_frame : (int)(n);
+    int pcap = cfg->max_points_per_frame > 0 ? cfg->max_points_per_frame : (int)(2 * n);
     int ccap = cfg->max_clusters_per_frame > 0 ? cfg->max_clusters_per_frame : (int)(n / 8 + 1024);
     int qcap = cfg->max_quads_per_frame > 0 ? cfg->max_quads_per_frame : 1024;
     ck_cluster_t *cl = (ck_cluster_t *)malloc((size_t)ccap * sizeof *cl);

@@ -54,7 +54,7 @@ def segment(thresh):
 def clusters(thresh, labels, sizes, min_component_px=25):
     t, p = _u8(thresh)
     h, w = t.shape
-    pcap, ccap = w * h, w * h // 4 + 1024
+    pcap, ccap = 4 * w * h, w * h // 4 + 1024
     cl = (A.Cluster * ccap)()
     pts = (A.ClusterPoint * pcap)()
     nc, npn = C.c_int(0), C.c_int(0)
