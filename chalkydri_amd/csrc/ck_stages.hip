@@ -22,7 +22,7 @@ int ck_stage_alloc(ck_handle *h) {
     if (ws.ht_size < 1024) ws.ht_size = 1024;
     ws.max_cluster_points = 3 * (2 * h->qw + 2 * h->qh);
     if (ws.max_cluster_points > 16384) ws.max_cluster_points = 16384;
-    if (cfg.max_nmaxima < 4 || cfg.max_nmaxima > 15) return CK_EINVAL;
+    if (cfg.max_nmaxima < 4 || cfg.max_nmaxima > 12) return CK_EINVAL;
     CK_HIP(hipMalloc(&ws.d_ht_keys, sizeof(unsigned long long) * (size_t)ws.ht_size * nb));
     CK_HIP(hipMalloc(&ws.d_ht_count, sizeof(uint32_t) * (size_t)ws.ht_size * nb));
     CK_HIP(hipMalloc(&ws.d_ht_off, sizeof(uint32_t) * (size_t)ws.ht_size * nb));

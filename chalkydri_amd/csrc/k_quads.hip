@@ -52,9 +52,9 @@ __device__ __forceinline__ unsigned long long angle_key(int x, int y, int xmin, 
     return ((unsigned long long)oct << 57) | (frac << 26) | ((unsigned long long)x << 13) | (unsigned long long)y;
 }
 __device__ __forceinline__ uint32_t isqrt_u32(uint32_t v) {
-    uint32_t r = (uint32_t)sqrt((double)v);
-    while ((unsigned long long)r * r > v) r--;
-    while ((unsigned long long)(r + 1) * (r + 1) <= v) r++;
+    uint32_t r = (uint32_t)__fsqrt_rn((float)v); // v <= 2*255^2: exact after the +-1 correction
+    if (r * r > v) r--;
+    if ((r + 1) * (r + 1) <= v) r++;
     return r;
 }
 
@@ -220,18 +220,51 @@ __device__ void refine_edge(const FitArgs &a, const uint8_t *im, const double p[
 }
 
 constexpr int HALO = 24;   // 20 (window) + 3 (smoothing) + 1 (maxima neighbour)
-constexpr int MAXSEL = 16; // >= max_nmaxima supported
+constexpr int MAXSEL = 12; // largest max_nmaxima supported
 
-template <int NTH, int CAP, int CH>
+struct PairFit { double err, mse, nx, ny; };
+
+__device__ __forceinline__ int wrap_index(int i, int sz) { // i in [-HALO, sz + CH + HALO): bring into [0, sz)
+    while (i < 0) i += sz;
+    while (i >= sz) i -= sz;
+    return i;
+}
+// gradient-magnitude weight of a sorted point (x,y in half pixels)
+__device__ __forceinline__ uint32_t point_weight(const FitArgs &a, const uint8_t *qim, uint32_t xy) {
+    int x = (int)(xy >> 13), y = (int)(xy & 0x1FFF);
+    int ix = (x + 1) >> 1, iy = (y + 1) >> 1;
+    uint32_t W = 1;
+    if (ix > 0 && ix + 1 < a.qw && iy > 0 && iy + 1 < a.qh) {
+        const uint8_t *row = qim + (size_t)iy * a.qstride + ix;
+        int gx = (int)row[1] - (int)row[-1];
+        int gy = (int)row[a.qstride] - (int)row[-a.qstride];
+        W = isqrt_u32((uint32_t)(gx * gx + gy * gy)) + 1;
+    }
+    return W;
+}
+__device__ __forceinline__ M6 moments_of(uint32_t xy, uint32_t Wt) {
+    long long X = (long long)(xy >> 13) + 1, Y = (long long)(xy & 0x1FFF) + 1, W = Wt;
+    M6 m;
+    m.Mx = W * X; m.My = W * Y; m.Mxx = W * X * X; m.Mxy = W * X * Y; m.Myy = W * Y * Y; m.W = W;
+    return m;
+}
+
+// NTH threads per cluster, up to CAP points, chunks of CH points; MLDS: the maxima list fits in LDS
+template <int NTH, int CAP, int CH, bool MLDS>
 __global__ __launch_bounds__(NTH) void k_fit(FitArgs a) {
     using B = Block<NTH>;
     constexpr int SL = CH + 2 * HALO;
     constexpr int NCH = CAP / CH;
+    constexpr int MAXM = MLDS ? CAP / 2 : 1;
+    // sKeys holds the 64-bit sort keys; after duplicate removal its first half is reused for the packed
+    // coordinates (x<<13|y, u32) and the third quarter for the u16 weights.
     __shared__ unsigned long long sKeys[CAP];
-    __shared__ long long sP[6][SL];          // inclusive moment prefix sums over the current span
+    __shared__ long long sP[6][SL];          // inclusive moment prefix sums over the current span; later the pair-fit table
     __shared__ double sErr[SL], sSm[SL];
     __shared__ long long sTot[NCH + 1][6];   // cumulative moments at chunk ends
     __shared__ long long sScratch[2 * (NTH / 64) + 2];
+    __shared__ double sMaxVal[MAXM];
+    __shared__ uint16_t sMaxIdx[MAXM];
     __shared__ int sSelIdx[MAXSEL];
     __shared__ long long sSelI[MAXSEL][6], sSelE[MAXSEL][6];
     __shared__ double sRed[NTH / 64 + 1];
@@ -240,8 +273,11 @@ __global__ __launch_bounds__(NTH) void k_fit(FitArgs a) {
     __shared__ int sNmax, sFlag;
     __shared__ double sLines[4][4];
     __shared__ double sQuad[4][2];
+    static_assert(sizeof(PairFit) * MAXSEL * MAXSEL <= sizeof(long long) * 6 * SL, "pair-fit table must fit in sP");
     const int tid = threadIdx.x;
     const ck_stage_ws &ws = a.ws;
+    uint32_t *sXY = reinterpret_cast<uint32_t *>(sKeys);
+    uint16_t *sW = reinterpret_cast<uint16_t *>(sKeys) + 2 * CAP; // bytes [4*CAP, 6*CAP)
 
     for (;;) {
         __syncthreads();
@@ -288,7 +324,7 @@ __global__ __launch_bounds__(NTH) void k_fit(FitArgs a) {
         if (reversed && !a.reversed_ok) continue;
         if (!reversed && !a.normal_ok) continue;
 
-        // ---- 2. bitonic sort + duplicate removal -------------------------------------------------------------
+        // ---- 2. bitonic sort, duplicate removal, packing to (x,y) ---------------------------------------------
         __syncthreads();
         for (int k = 2; k <= n2; k <<= 1)
             for (int j = k >> 1; j > 0; j >>= 1) {
@@ -301,6 +337,8 @@ __global__ __launch_bounds__(NTH) void k_fit(FitArgs a) {
                 }
                 __syncthreads();
             }
+        // compaction writes u32 (x<<13|y) at index <= i into the first half of the same buffer: a round only
+        // overwrites bytes below 4*(base+NTH) while unread keys start at byte 8*(base+NTH)
         int sz = 0;
         for (int base = 0; base < sz0; base += NTH) {
             int i = base + tid;
@@ -310,7 +348,7 @@ __global__ __launch_bounds__(NTH) void k_fit(FitArgs a) {
             long long tot = 0;
             long long incl = B::scan_incl((long long)keep, sScratch, &tot);
             __syncthreads();
-            if (keep) sKeys[sz + (int)incl - 1] = key;
+            if (keep) sXY[sz + (int)incl - 1] = (uint32_t)(key & 0x3FFFFFFu);
             sz += (int)tot;
             __syncthreads();
         }
@@ -318,33 +356,31 @@ __global__ __launch_bounds__(NTH) void k_fit(FitArgs a) {
         const int ksz = sz / 12 < 20 ? sz / 12 : 20;
         if (ksz < 2) continue;
 
-        // the cluster's slice of the point array is dead from here on: reuse it for the maxima list
-        double *mval = reinterpret_cast<double *>(pts);
-        uint32_t *midx = reinterpret_cast<uint32_t *>(mval + (sz0 + 1) / 2);
+        // ---- 3. gradient weights: one image gather per point, all in flight together ---------------------------------
+        for (int i = tid; i < sz; i += NTH) sW[i] = (uint16_t)point_weight(a, qim, sXY[i]);
+        // the cluster's slice of the point array is dead from here on; the large class keeps its maxima there
+        double *gval = reinterpret_cast<double *>(pts);
+        uint32_t *gidx = reinterpret_cast<uint32_t *>(gval + (sz0 + 1) / 2);
         if (tid == 0) { sNmax = 0; sFlag = 0; }
         if (tid < 6) sTot[0][tid] = 0;
         __syncthreads();
 
-        // ---- 3. chunk loop ----------------------------------------------------------------------------------------
+        // ---- 4. chunk loop: moment prefix sums, windowed error, smoothing, maxima ----------------------------------------
         const int nch = (sz + CH - 1) / CH;
         for (int c = 0; c < nch; c++) {
             const int cbase = c * CH;
             const int chn = min(CH, sz - cbase);
             const int sl = chn + 2 * HALO;
-            // moments of the span, then an in-place inclusive scan (blocked: EPT consecutive elements per thread)
             constexpr int EPT = (SL + NTH - 1) / NTH;
             M6 loc[EPT];
             M6 run = m6_zero();
 #pragma unroll
             for (int e = 0; e < EPT; e++) {
                 int j = tid * EPT + e;
-                M6 m = m6_zero();
                 if (j < sl) {
-                    int gi = (cbase - HALO + j) % sz;
-                    if (gi < 0) gi += sz;
-                    m = point_moments(a, qim, sKeys[gi]);
+                    int gi = wrap_index(cbase - HALO + j, sz);
+                    run = m6_add(run, moments_of(sXY[gi], sW[gi]));
                 }
-                run = m6_add(run, m);
                 loc[e] = run;
             }
             long long v[6] = {run.Mx, run.My, run.Mxx, run.Mxy, run.Myy, run.W}, ex[6];
@@ -360,7 +396,6 @@ __global__ __launch_bounds__(NTH) void k_fit(FitArgs a) {
             }
             __syncthreads();
             if (tid < 6) sTot[c + 1][tid] = sTot[c][tid] + sP[tid][HALO + chn - 1] - sP[tid][HALO - 1];
-            // windowed line-fit error
             for (int j = HALO - 4 + tid; j < HALO + chn + 4; j += NTH) {
                 int hi = j + ksz, lo = j - ksz - 1;
                 M6 m = {sP[0][hi], sP[1][hi], sP[2][hi], sP[3][hi], sP[4][hi], sP[5][hi]};
@@ -380,19 +415,20 @@ __global__ __launch_bounds__(NTH) void k_fit(FitArgs a) {
             for (int j = HALO + tid; j < HALO + chn; j += NTH) {
                 double s = sSm[j];
                 if (s > sSm[j + 1] && s > sSm[j - 1]) {
-                    int pos = atomicAdd(&sNmax, 1);
-                    mval[pos] = s;                 // pos < sz/2 <= capacity of the reused slice
-                    midx[pos] = (uint32_t)(cbase + j - HALO);
+                    int pos = atomicAdd(&sNmax, 1); // pos < sz/2
+                    if (MLDS) { sMaxVal[pos] = s; sMaxIdx[pos] = (uint16_t)(cbase + j - HALO); }
+                    else { gval[pos] = s; gidx[pos] = (uint32_t)(cbase + j - HALO); }
                 }
             }
             __syncthreads();
         }
         const int nmax_all = sNmax;
         if (nmax_all < 4) continue;
-        __threadfence_block();
+        auto mval = [&](int i) -> double { return MLDS ? sMaxVal[i] : gval[i]; };
+        auto midx = [&](int i) -> int { return MLDS ? (int)sMaxIdx[i] : (int)gidx[i]; };
 
-        // ---- 4a. threshold = (max_nmaxima+1)-th largest smoothed error -----------------------------------------------
-        double thr = -1.0; // keep everything (errors are >= 0 up to rounding; use -inf semantics below)
+        // ---- 5a. threshold = (max_nmaxima+1)-th largest smoothed error ---------------------------------------------------
+        double thr = 0.0;
         bool use_thr = false;
         if (nmax_all > a.max_nmaxima) {
             use_thr = true;
@@ -400,8 +436,7 @@ __global__ __launch_bounds__(NTH) void k_fit(FitArgs a) {
             int remaining = a.max_nmaxima + 1;
             for (int round = 0; round <= a.max_nmaxima; round++) {
                 double m = -HUGE_VAL;
-                for (int i = tid; i < nmax_all; i += NTH) { double v = mval[i]; if (v < cur && v > m) m = v; }
-                // block max
+                for (int i = tid; i < nmax_all; i += NTH) { double v = mval(i); if (v < cur && v > m) m = v; }
 #pragma unroll
                 for (int d = 32; d >= 1; d >>= 1) { double o = __shfl_xor(m, d, 64); if (o > m) m = o; }
                 if (NTH > 64) {
@@ -412,50 +447,49 @@ __global__ __launch_bounds__(NTH) void k_fit(FitArgs a) {
                     __syncthreads();
                 }
                 long long cnt = 0;
-                for (int i = tid; i < nmax_all; i += NTH) cnt += (mval[i] == m);
+                for (int i = tid; i < nmax_all; i += NTH) cnt += (mval(i) == m);
                 cnt = B::reduce_add(cnt, sScratch);
                 if (cnt >= remaining) { thr = m; break; }
                 remaining -= (int)cnt;
                 cur = m;
             }
         }
-        // selected maxima, in increasing index order (rank by index among the survivors)
+        // survivors (at most max_nmaxima of them), then put them in increasing index order
+        __syncthreads();
         if (tid == 0) sNmax = 0;
         __syncthreads();
         for (int i = tid; i < nmax_all; i += NTH) {
-            double v = mval[i];
-            if (use_thr && v <= thr) continue;
-            uint32_t idx = midx[i];
-            int rank = 0;
-            for (int k = 0; k < nmax_all; k++) {
-                double vk = mval[k];
-                if (use_thr && vk <= thr) continue;
-                if (midx[k] < idx) rank++;
-            }
-            if (rank < MAXSEL) sSelIdx[rank] = (int)idx;
-            atomicAdd(&sNmax, 1);
+            if (use_thr && mval(i) <= thr) continue;
+            int pos = atomicAdd(&sNmax, 1);
+            if (pos < MAXSEL) sSelIdx[pos] = midx(i);
         }
         __syncthreads();
         const int nsel = sNmax;
         if (nsel < 4 || nsel > MAXSEL) continue;
+        if (tid == 0)
+            for (int i = 1; i < nsel; i++) {
+                int v = sSelIdx[i], j = i - 1;
+                while (j >= 0 && sSelIdx[j] > v) { sSelIdx[j + 1] = sSelIdx[j]; j--; }
+                sSelIdx[j + 1] = v;
+            }
+        __syncthreads();
 
-        // ---- 4b. moment prefix sums at the selected maxima ------------------------------------------------------------------
+        // ---- 5b. moment prefix sums at the selected maxima (chunk totals + partial sums inside the chunk) ------------------
         for (int s = 0; s < nsel; s++) {
             const int gi = sSelIdx[s];
             const int c = gi / CH, cb = c * CH;
-            M6 part = m6_zero(), self = m6_zero();
-            for (int i = cb + tid; i <= gi; i += NTH) {
-                M6 m = point_moments(a, qim, sKeys[i]);
-                part = m6_add(part, m);
-                if (i == gi) self = m;
-            }
+            M6 part = m6_zero();
+            for (int i = cb + tid; i <= gi; i += NTH) part = m6_add(part, moments_of(sXY[i], sW[i]));
             long long pv[6] = {part.Mx, part.My, part.Mxx, part.Mxy, part.Myy, part.W};
-            long long sv[6] = {self.Mx, self.My, self.Mxx, self.Mxy, self.Myy, self.W};
 #pragma unroll
             for (int q = 0; q < 6; q++) {
                 long long t = B::reduce_add(pv[q], sScratch);
-                long long u = B::reduce_add(sv[q], sScratch);
-                if (tid == 0) { sSelI[s][q] = sTot[c][q] + t; sSelE[s][q] = sTot[c][q] + t - u; }
+                if (tid == 0) sSelI[s][q] = sTot[c][q] + t;
+            }
+            if (tid == 0) {
+                M6 self = moments_of(sXY[gi], sW[gi]);
+                long long sv[6] = {self.Mx, self.My, self.Mxx, self.Mxy, self.Myy, self.W};
+                for (int q = 0; q < 6; q++) sSelE[s][q] = sSelI[s][q] - sv[q];
             }
         }
         __syncthreads();
@@ -469,7 +503,19 @@ __global__ __launch_bounds__(NTH) void k_fit(FitArgs a) {
             return m6_add(m6_sub(total, E), I);
         };
 
-        // ---- 4c. all 4-subsets in parallel; argmin with lexicographic tie-break ---------------------------------------------
+        // ---- 5c. one line fit per ordered pair of maxima; the 4-subset search is then table lookups ------------------------
+        PairFit *sF = reinterpret_cast<PairFit *>(&sP[0][0]);
+        for (int pr = tid; pr < nsel * nsel; pr += NTH) {
+            int sa = pr / nsel, sb = pr - sa * nsel;
+            if (sa == sb) continue;
+            int N;
+            double lp[4], e, ms;
+            M6 m = rangeM(sa, sb, &N);
+            fit_line_m(m, N, lp, &e, &ms);
+            PairFit f; f.err = e; f.mse = ms; f.nx = lp[2]; f.ny = lp[3];
+            sF[sa * MAXSEL + sb] = f;
+        }
+        __syncthreads();
         double best = HUGE_VAL;
         int bestc = 1 << 30;
         {
@@ -479,19 +525,17 @@ __global__ __launch_bounds__(NTH) void k_fit(FitArgs a) {
                     for (int m2 = m1 + 1; m2 < nsel - 1; m2++)
                         for (int m3 = m2 + 1; m3 < nsel; m3++, combo++) {
                             if ((combo % NTH) != tid) continue;
-                            int N;
-                            double p01[4], p12[4], e01, s01, e12, s12, e23, s23, e30, s30;
-                            M6 m = rangeM(m0, m1, &N); fit_line_m(m, N, p01, &e01, &s01);
-                            if (s01 > a.max_mse) continue;
-                            m = rangeM(m1, m2, &N); fit_line_m(m, N, p12, &e12, &s12);
-                            if (s12 > a.max_mse) continue;
-                            double dp = p01[2] * p12[2] + p01[3] * p12[3];
+                            const PairFit f01 = sF[m0 * MAXSEL + m1];
+                            if (f01.mse > a.max_mse) continue;
+                            const PairFit f12 = sF[m1 * MAXSEL + m2];
+                            if (f12.mse > a.max_mse) continue;
+                            double dp = f01.nx * f12.nx + f01.ny * f12.ny;
                             if (fabs(dp) > a.cos_critical) continue;
-                            m = rangeM(m2, m3, &N); fit_line_m(m, N, nullptr, &e23, &s23);
-                            if (s23 > a.max_mse) continue;
-                            m = rangeM(m3, m0, &N); fit_line_m(m, N, nullptr, &e30, &s30);
-                            if (s30 > a.max_mse) continue;
-                            double e = e01 + e12 + e23 + e30;
+                            const PairFit f23 = sF[m2 * MAXSEL + m3];
+                            if (f23.mse > a.max_mse) continue;
+                            const PairFit f30 = sF[m3 * MAXSEL + m0];
+                            if (f30.mse > a.max_mse) continue;
+                            double e = f01.err + f12.err + f23.err + f30.err;
                             if (e < best) { best = e; bestc = (m0 << 12) | (m1 << 8) | (m2 << 4) | m3; }
                         }
         }
@@ -512,7 +556,7 @@ __global__ __launch_bounds__(NTH) void k_fit(FitArgs a) {
         if (best == HUGE_VAL) continue;
         if (best / (double)sz >= a.max_mse) continue;
 
-        // ---- 4d. lines, corners, geometric checks (one lane; sequential like the oracle) ---------------------------------------
+        // ---- 5d. lines, corners, geometric checks (one lane; sequential like the oracle) ---------------------------------------
         if (tid == 0) {
             int sel[4] = {(bestc >> 12) & 15, (bestc >> 8) & 15, (bestc >> 4) & 15, bestc & 15};
             double lines[4][4];
@@ -565,7 +609,7 @@ __global__ __launch_bounds__(NTH) void k_fit(FitArgs a) {
                     P[i][0] = (P[i][0] - 0.5) * (double)a.decimate + 0.5;
                     P[i][1] = (P[i][1] - 0.5) * (double)a.decimate + 0.5;
                 }
-            for (int i = 0; i < 4; i++) { sQuad[i][0] = P[i][0]; sQuad[i][1] = P[i][1]; }
+            if (ok) for (int i = 0; i < 4; i++) { sQuad[i][0] = P[i][0]; sQuad[i][1] = P[i][1]; }
             sFlag = ok;
         }
         __syncthreads();
@@ -611,11 +655,23 @@ __global__ __launch_bounds__(256) void k_classify(ck_stage_ws ws, int n, uint32_
     const uint32_t *counters = ws.d_counters + (size_t)frame * CK_CNT_STRIDE;
     const uint32_t nc = counters[CK_CNT_CLUSTERS];
     const ck_cluster_t *cls = ws.d_clusters + (size_t)frame * ws.cluster_cap;
-    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < nc; i += gridDim.x * 256) {
-        uint32_t c = cls[i].count;
-        int k = c <= 512 ? 0 : (c <= 4096 ? 1 : 2);
-        uint32_t pos = atomicAdd(&list_counts[k], 1u);
-        if (pos < (uint32_t)list_cap) lists[(size_t)k * list_cap + pos] = ((uint32_t)frame << 20) | i;
+    const int lane = threadIdx.x & 63;
+    for (uint32_t i0 = blockIdx.x * 256; i0 < nc; i0 += gridDim.x * 256) {
+        uint32_t i = i0 + threadIdx.x;
+        int k = -1;
+        if (i < nc) { uint32_t c = cls[i].count; k = c <= 512 ? 0 : (c <= 4096 ? 1 : 2); }
+        for (int kk = 0; kk < 3; kk++) { // one atomic per wave and class (ballot + prefix popcount)
+            unsigned long long m = __ballot(k == kk);
+            if (!m) continue;
+            uint32_t base = 0;
+            int leader = __builtin_ctzll(m);
+            if (lane == leader) base = atomicAdd(&list_counts[kk], (uint32_t)__popcll(m));
+            base = __shfl(base, leader, 64);
+            if (k == kk) {
+                uint32_t pos = base + (uint32_t)__popcll(m & ((1ull << lane) - 1));
+                if (pos < (uint32_t)list_cap) lists[(size_t)kk * list_cap + pos] = ((uint32_t)frame << 20) | i;
+            }
+        }
     }
 }
 __global__ void k_clamp_counts(uint32_t *list_counts, int list_cap, ck_stage_ws ws, int n) {
@@ -659,11 +715,11 @@ int ck_launch_fit_quads(ck_handle *h, const uint8_t *qframes, int qstride, size_
     a.ws = ws;
     int cus = 256;
     a.list = lists; a.list_count = list_counts; a.head = heads;
-    hipLaunchKernelGGL((k_fit<64, 512, 128>), dim3((unsigned)(cus * 8)), dim3(64), 0, h->stream, a);
+    hipLaunchKernelGGL((k_fit<64, 512, 128, true>), dim3((unsigned)(cus * 8)), dim3(64), 0, h->stream, a);
     a.list = lists + list_cap; a.list_count = list_counts + 1; a.head = heads + 1;
-    hipLaunchKernelGGL((k_fit<256, 4096, 256>), dim3((unsigned)(cus * 2)), dim3(256), 0, h->stream, a);
+    hipLaunchKernelGGL((k_fit<256, 4096, 256, true>), dim3((unsigned)(cus * 2)), dim3(256), 0, h->stream, a);
     a.list = lists + 2 * (size_t)list_cap; a.list_count = list_counts + 2; a.head = heads + 2;
-    hipLaunchKernelGGL((k_fit<1024, 16384, 256>), dim3((unsigned)cus), dim3(1024), 0, h->stream, a);
+    hipLaunchKernelGGL((k_fit<1024, 16384, 256, false>), dim3((unsigned)cus), dim3(1024), 0, h->stream, a);
     hipLaunchKernelGGL(k_clamp_counts, dim3(1), dim3(64), 0, h->stream, list_counts, list_cap, ws, n);
     CK_HIP(hipGetLastError());
     return CK_OK;

@@ -280,15 +280,21 @@ static int dbl_desc(const void *a, const void *b) {
     return x > y ? -1 : x < y ? 1 : 0;
 }
 
+/* debug statistics: where clusters leave fit_quad (read through ora_fit_stats) */
+static long g_fit_stats[16];
+void ora_fit_stats(long *out, int reset) { for (int i = 0; i < 16; i++) { out[i] = g_fit_stats[i]; if (reset) g_fit_stats[i] = 0; } }
+#define FIT_STAT(k) (g_fit_stats[k]++)
+
 static int fit_quad(const fitctx_t *c, const ck_cluster_point_t *pts, int sz0, ck_quad_t *quad) {
-    if (sz0 < c->cfg->min_cluster_pixels || sz0 < 24) return 0;
-    if (sz0 > c->max_cluster_points) return 0;
+    FIT_STAT(0);
+    if (sz0 < c->cfg->min_cluster_pixels || sz0 < 24) { FIT_STAT(1); return 0; }
+    if (sz0 > c->max_cluster_points) { FIT_STAT(2); return 0; }
     int xmin = pts[0].x, xmax = pts[0].x, ymin = pts[0].y, ymax = pts[0].y;
     for (int i = 1; i < sz0; i++) {
         if (pts[i].x < xmin) xmin = pts[i].x; if (pts[i].x > xmax) xmax = pts[i].x;
         if (pts[i].y < ymin) ymin = pts[i].y; if (pts[i].y > ymax) ymax = pts[i].y;
     }
-    if ((xmax - xmin) * (ymax - ymin) < c->min_tag_width) return 0;
+    if ((xmax - xmin) * (ymax - ymin) < c->min_tag_width) { FIT_STAT(3); return 0; }
     /* border direction: sum over points of (p - centre) . gradient, exact in integers */
     int64_t dot = 0;
     for (int i = 0; i < sz0; i++) {
@@ -297,8 +303,8 @@ static int fit_quad(const fitctx_t *c, const ck_cluster_point_t *pts, int sz0, c
         dot += dx * pts[i].gx + dy * pts[i].gy;
     }
     int reversed = dot < 0;
-    if (reversed && !c->reversed_ok) return 0;
-    if (!reversed && !c->normal_ok) return 0;
+    if (reversed && !c->reversed_ok) { FIT_STAT(4); return 0; }
+    if (!reversed && !c->normal_ok) { FIT_STAT(4); return 0; }
     /* sort by angle, drop duplicate coordinates */
     uint64_t *keys = (uint64_t *)malloc((size_t)sz0 * sizeof(uint64_t));
     for (int i = 0; i < sz0; i++) keys[i] = angle_key(pts[i].x, pts[i].y, xmin, xmax, ymin, ymax);
@@ -308,7 +314,7 @@ static int fit_quad(const fitctx_t *c, const ck_cluster_point_t *pts, int sz0, c
         if (i == 0 || keys[i] != keys[i - 1]) keys[sz++] = keys[i];
     int ok = 0;
     lfps_t *lf = NULL; double *errs = NULL, *sm = NULL; int *maxima = NULL; double *maxima_errs = NULL;
-    if (sz < 24) goto done;
+    if (sz < 24) { FIT_STAT(5); goto done; }
     /* line-fit prefix sums */
     lf = (lfps_t *)malloc((size_t)sz * sizeof(lfps_t));
     {
@@ -330,7 +336,7 @@ static int fit_quad(const fitctx_t *c, const ck_cluster_point_t *pts, int sz0, c
     }
     /* corner candidates: local maxima of the smoothed line-fit error */
     int ksz = sz / 12 < 20 ? sz / 12 : 20;
-    if (ksz < 2) goto done;
+    if (ksz < 2) { FIT_STAT(5); goto done; }
     errs = (double *)malloc((size_t)sz * sizeof(double));
     sm = (double *)malloc((size_t)sz * sizeof(double));
     for (int i = 0; i < sz; i++) fit_line(lf, sz, (i + sz - ksz) % sz, (i + ksz) % sz, NULL, &errs[i], NULL);
@@ -344,7 +350,7 @@ static int fit_quad(const fitctx_t *c, const ck_cluster_point_t *pts, int sz0, c
     int nmax = 0;
     for (int i = 0; i < sz; i++)
         if (sm[i] > sm[(i + 1) % sz] && sm[i] > sm[(i + sz - 1) % sz]) { maxima[nmax] = i; maxima_errs[nmax] = sm[i]; nmax++; }
-    if (nmax < 4) goto done;
+    if (nmax < 4) { FIT_STAT(6); goto done; }
     int max_nmaxima = c->cfg->max_nmaxima;
     if (nmax > max_nmaxima) {
         double *cp = (double *)malloc((size_t)nmax * sizeof(double));
@@ -390,21 +396,21 @@ static int fit_quad(const fitctx_t *c, const ck_cluster_point_t *pts, int sz0, c
             }
         }
     }
-    if (best_error == HUGE_VAL) goto done;
-    if (best_error / (double)sz >= max_mse) goto done;
+    if (best_error == HUGE_VAL) { FIT_STAT(7); goto done; }
+    if (best_error / (double)sz >= max_mse) { FIT_STAT(8); goto done; }
     {
         double lines[4][4];
         for (int i = 0; i < 4; i++) {
             double mse;
             fit_line(lf, sz, best[i], best[(i + 1) & 3], lines[i], NULL, &mse);
-            if (mse > max_mse) goto done;
+            if (mse > max_mse) { FIT_STAT(9); goto done; }
         }
         for (int i = 0; i < 4; i++) {
             int j = (i + 1) & 3;
             double A00 = lines[i][3], A01 = -lines[j][3], A10 = -lines[i][2], A11 = lines[j][2];
             double B0 = -lines[i][0] + lines[j][0], B1 = -lines[i][1] + lines[j][1];
             double det = A00 * A11 - A10 * A01;
-            if (fabs(det) < 0.001) goto done;
+            if (fabs(det) < 0.001) { FIT_STAT(10); goto done; }
             double W00 = A11 / det, W01 = -A01 / det;
             double L0 = W00 * B0 + W01 * B1;
             quad->p[i][0] = lines[i][0] + L0 * A00;
@@ -426,7 +432,7 @@ static int fit_quad(const fitctx_t *c, const ck_cluster_point_t *pts, int sz0, c
             area += sqrt(p * (p - len[0]) * (p - len[1]) * (p - len[2]));
         }
         double tw = (double)c->min_tag_width;
-        if (area < 0.95 * tw * tw) goto done;
+        if (area < 0.95 * tw * tw) { FIT_STAT(11); goto done; }
     }
     /* corner angles and winding */
     for (int i = 0; i < 4; i++) {
@@ -434,10 +440,11 @@ static int fit_quad(const fitctx_t *c, const ck_cluster_point_t *pts, int sz0, c
         double dx1 = quad->p[i1][0] - quad->p[i0][0], dy1 = quad->p[i1][1] - quad->p[i0][1];
         double dx2 = quad->p[i2][0] - quad->p[i1][0], dy2 = quad->p[i2][1] - quad->p[i1][1];
         double cs = (dx1 * dx2 + dy1 * dy2) / sqrt((dx1 * dx1 + dy1 * dy1) * (dx2 * dx2 + dy2 * dy2));
-        if (cs > c->cfg->cos_critical_rad || cs < -c->cfg->cos_critical_rad) goto done;
-        if (dx1 * dy2 < dy1 * dx2) goto done;
+        if (cs > c->cfg->cos_critical_rad || cs < -c->cfg->cos_critical_rad) { FIT_STAT(12); goto done; }
+        if (dx1 * dy2 < dy1 * dx2) { FIT_STAT(13); goto done; }
     }
     quad->reversed_border = reversed;
+    FIT_STAT(14);
     ok = 1;
 done:
     free(keys); free(lf); free(errs); free(sm); free(maxima); free(maxima_errs);
