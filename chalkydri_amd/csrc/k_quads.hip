@@ -47,7 +47,11 @@ __device__ __forceinline__ unsigned long long angle_key(int x, int y, int xmin, 
         if (dx > 0) { if (ay <= ax) { oct = 4; inv = 0; num = ay; den = ax; } else { oct = 5; inv = 1; num = ax; den = ay; } }
         else        { if (ay > ax)  { oct = 6; inv = 0; num = ax; den = ay; } else { oct = 7; inv = 1; num = ay; den = ax; } }
     }
-    unsigned long long frac = ((unsigned long long)num << 30) / (unsigned long long)den;
+    // floor(num * 2^30 / den) by two 15-bit long-division steps (num <= den < 2^15): exact, 32-bit only
+    uint32_t n32 = (uint32_t)num, d32 = (uint32_t)den;
+    uint32_t q1 = (n32 << 15) / d32, r1 = (n32 << 15) - q1 * d32;
+    uint32_t q2 = (r1 << 15) / d32;
+    unsigned long long frac = ((unsigned long long)q1 << 15) + q2;
     if (inv) frac = (1ull << 30) - frac;
     return ((unsigned long long)oct << 57) | (frac << 26) | ((unsigned long long)x << 13) | (unsigned long long)y;
 }
@@ -219,10 +223,23 @@ __device__ void refine_edge(const FitArgs &a, const uint8_t *im, const double p[
     else { line[2] = fx / len; line[3] = fy / len; }
 }
 
+// Diagnostic build only (-DCK_FIT_PROFILE): per-phase cycle totals of k_fit, written to a buffer of their own.
+#ifdef CK_FIT_PROFILE
+__device__ unsigned long long g_fit_prof[3][16];
+#define PROF_DECL unsigned long long prof_t0 = __builtin_readcyclecounter(); const int prof_cls = (CAP == 512) ? 0 : (CAP == 4096 ? 1 : 2)
+#define PROF(k) do { unsigned long long t_ = __builtin_readcyclecounter(); if (tid == 0) atomicAdd(&g_fit_prof[prof_cls][k], t_ - prof_t0); prof_t0 = t_; } while (0)
+#else
+#define PROF_DECL
+#define PROF(k)
+#endif
+
 constexpr int HALO = 24;   // 20 (window) + 3 (smoothing) + 1 (maxima neighbour)
 constexpr int MAXSEL = 12; // largest max_nmaxima supported
 
 struct PairFit { double err, mse, nx, ny; };
+
+// all 4-subsets of {0..MAXSEL-1}, packed m0<<12|m1<<8|m2<<4|m3 (filled once per handle by ck_launch_fit_quads)
+__device__ uint16_t g_combos[495];
 
 __device__ __forceinline__ int wrap_index(int i, int sz) { // i in [-HALO, sz + CH + HALO): bring into [0, sz)
     while (i < 0) i += sz;
@@ -250,8 +267,8 @@ __device__ __forceinline__ M6 moments_of(uint32_t xy, uint32_t Wt) {
 }
 
 // NTH threads per cluster, up to CAP points, chunks of CH points; MLDS: the maxima list fits in LDS
-template <int NTH, int CAP, int CH, bool MLDS>
-__global__ __launch_bounds__(NTH) void k_fit(FitArgs a) {
+template <int NTH, int CAP, int CH, bool MLDS, int WPS>
+__global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(WPS, 8))) void k_fit(FitArgs a) {
     using B = Block<NTH>;
     constexpr int SL = CH + 2 * HALO;
     constexpr int NCH = CAP / CH;
@@ -293,13 +310,17 @@ __global__ __launch_bounds__(NTH) void k_fit(FitArgs a) {
         const uint8_t *qim = a.qim + (size_t)frame * a.qpitch;
         const uint8_t *im = a.im + (size_t)frame * a.pitch;
         if (sz0 > CAP) continue; // cannot happen: the class lists are built from the counts
+        PROF_DECL;
+        PROF(15);
 
         // ---- 1. bounding box + border direction ----------------------------------------------------------
         int xmin = 1 << 30, xmax = -(1 << 30), ymin = 1 << 30, ymax = -(1 << 30);
-        for (int i = tid; i < sz0; i += NTH) {
-            ck_cluster_point_t p = pts[i];
-            xmin = min(xmin, (int)p.x); xmax = max(xmax, (int)p.x);
-            ymin = min(ymin, (int)p.y); ymax = max(ymax, (int)p.y);
+        for (int i = tid; i < sz0; i += NTH) { // one coalesced pass; the raw 8-byte points wait in the key buffer
+            unsigned long long raw = reinterpret_cast<const unsigned long long *>(pts)[i];
+            sKeys[i] = raw;
+            int px = (int)(raw & 0xFFFF), py = (int)((raw >> 16) & 0xFFFF);
+            xmin = min(xmin, px); xmax = max(xmax, px);
+            ymin = min(ymin, py); ymax = max(ymax, py);
         }
         int *iscr = reinterpret_cast<int *>(sScratch);
         xmin = B::reduce_min(xmin, iscr); xmax = -B::reduce_min(-xmax, iscr);
@@ -308,19 +329,22 @@ __global__ __launch_bounds__(NTH) void k_fit(FitArgs a) {
         long long dot = 0;
         int n2 = 1;
         while (n2 < sz0) n2 <<= 1;
-        for (int i = tid; i < n2; i += NTH) {
+        for (int i = tid; i < n2; i += NTH) { // each thread rewrites only the entries it staged itself
             unsigned long long key = ~0ull;
             if (i < sz0) {
-                ck_cluster_point_t p = pts[i];
-                long long dx = 4ll * p.x - 2ll * (xmin + xmax) - 1;
-                long long dy = 4ll * p.y - 2ll * (ymin + ymax) + 1;
-                dot += dx * p.gx + dy * p.gy;
-                key = angle_key(p.x, p.y, xmin, xmax, ymin, ymax);
+                unsigned long long raw = sKeys[i];
+                int px = (int)(raw & 0xFFFF), py = (int)((raw >> 16) & 0xFFFF);
+                int pgx = (int)(signed char)((raw >> 32) & 0xFF), pgy = (int)(signed char)((raw >> 40) & 0xFF);
+                long long dx = 4ll * px - 2ll * (xmin + xmax) - 1;
+                long long dy = 4ll * py - 2ll * (ymin + ymax) + 1;
+                dot += dx * pgx + dy * pgy;
+                key = angle_key(px, py, xmin, xmax, ymin, ymax);
             }
             sKeys[i] = key;
         }
         dot = B::reduce_add(dot, sScratch);
         const int reversed = dot < 0;
+        PROF(0);
         if (reversed && !a.reversed_ok) continue;
         if (!reversed && !a.normal_ok) continue;
 
@@ -337,6 +361,7 @@ __global__ __launch_bounds__(NTH) void k_fit(FitArgs a) {
                 }
                 __syncthreads();
             }
+        PROF(1);
         // compaction writes u32 (x<<13|y) at index <= i into the first half of the same buffer: a round only
         // overwrites bytes below 4*(base+NTH) while unread keys start at byte 8*(base+NTH)
         int sz = 0;
@@ -352,6 +377,7 @@ __global__ __launch_bounds__(NTH) void k_fit(FitArgs a) {
             sz += (int)tot;
             __syncthreads();
         }
+        PROF(2);
         if (sz < 24) continue;
         const int ksz = sz / 12 < 20 ? sz / 12 : 20;
         if (ksz < 2) continue;
@@ -365,6 +391,7 @@ __global__ __launch_bounds__(NTH) void k_fit(FitArgs a) {
         if (tid < 6) sTot[0][tid] = 0;
         __syncthreads();
 
+        PROF(3);
         // ---- 4. chunk loop: moment prefix sums, windowed error, smoothing, maxima ----------------------------------------
         const int nch = (sz + CH - 1) / CH;
         for (int c = 0; c < nch; c++) {
@@ -422,6 +449,7 @@ __global__ __launch_bounds__(NTH) void k_fit(FitArgs a) {
             }
             __syncthreads();
         }
+        PROF(4);
         const int nmax_all = sNmax;
         if (nmax_all < 4) continue;
         auto mval = [&](int i) -> double { return MLDS ? sMaxVal[i] : gval[i]; };
@@ -454,6 +482,7 @@ __global__ __launch_bounds__(NTH) void k_fit(FitArgs a) {
                 cur = m;
             }
         }
+        PROF(5);
         // survivors (at most max_nmaxima of them), then put them in increasing index order
         __syncthreads();
         if (tid == 0) sNmax = 0;
@@ -474,6 +503,7 @@ __global__ __launch_bounds__(NTH) void k_fit(FitArgs a) {
             }
         __syncthreads();
 
+        PROF(6);
         // ---- 5b. moment prefix sums at the selected maxima (chunk totals + partial sums inside the chunk) ------------------
         for (int s = 0; s < nsel; s++) {
             const int gi = sSelIdx[s];
@@ -503,6 +533,7 @@ __global__ __launch_bounds__(NTH) void k_fit(FitArgs a) {
             return m6_add(m6_sub(total, E), I);
         };
 
+        PROF(7);
         // ---- 5c. one line fit per ordered pair of maxima; the 4-subset search is then table lookups ------------------------
         PairFit *sF = reinterpret_cast<PairFit *>(&sP[0][0]);
         for (int pr = tid; pr < nsel * nsel; pr += NTH) {
@@ -519,12 +550,13 @@ __global__ __launch_bounds__(NTH) void k_fit(FitArgs a) {
         double best = HUGE_VAL;
         int bestc = 1 << 30;
         {
-            int combo = 0;
-            for (int m0 = 0; m0 < nsel - 3; m0++)
-                for (int m1 = m0 + 1; m1 < nsel - 2; m1++)
-                    for (int m2 = m1 + 1; m2 < nsel - 1; m2++)
-                        for (int m3 = m2 + 1; m3 < nsel; m3++, combo++) {
-                            if ((combo % NTH) != tid) continue;
+            for (int cb = tid; cb < 495; cb += NTH) { // every lane walks its own subsets; ties resolved by the packed index
+                const int pk = g_combos[cb];
+                const int m0 = pk >> 12, m1 = (pk >> 8) & 15, m2 = (pk >> 4) & 15, m3 = pk & 15;
+                if (m3 >= nsel) continue;
+                {
+                    {
+                        {
                             const PairFit f01 = sF[m0 * MAXSEL + m1];
                             if (f01.mse > a.max_mse) continue;
                             const PairFit f12 = sF[m1 * MAXSEL + m2];
@@ -536,8 +568,11 @@ __global__ __launch_bounds__(NTH) void k_fit(FitArgs a) {
                             const PairFit f30 = sF[m3 * MAXSEL + m0];
                             if (f30.mse > a.max_mse) continue;
                             double e = f01.err + f12.err + f23.err + f30.err;
-                            if (e < best) { best = e; bestc = (m0 << 12) | (m1 << 8) | (m2 << 4) | m3; }
+                            if (e < best || (e == best && pk < bestc)) { best = e; bestc = pk; }
                         }
+                    }
+                }
+            }
         }
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) {
@@ -553,6 +588,7 @@ __global__ __launch_bounds__(NTH) void k_fit(FitArgs a) {
                 if (sRed[k] < best || (sRed[k] == best && sRedI[k] < bestc)) { best = sRed[k]; bestc = sRedI[k]; }
             __syncthreads();
         }
+        PROF(8);
         if (best == HUGE_VAL) continue;
         if (best / (double)sz >= a.max_mse) continue;
 
@@ -613,6 +649,7 @@ __global__ __launch_bounds__(NTH) void k_fit(FitArgs a) {
             sFlag = ok;
         }
         __syncthreads();
+        PROF(9);
         if (!sFlag) continue;
         if (a.refine) {
             if (tid < 4) {
@@ -646,6 +683,7 @@ __global__ __launch_bounds__(NTH) void k_fit(FitArgs a) {
                 ws.d_quads[(size_t)frame * ws.quad_cap + qi] = q;
             } else atomicOr(&counters[CK_CNT_STATUS], (uint32_t)CK_FRAME_QUADS_OVERFLOW);
         }
+        PROF(10);
     }
 }
 
@@ -685,6 +723,15 @@ __global__ void k_clamp_counts(uint32_t *list_counts, int list_cap, ck_stage_ws 
 
 } // namespace
 
+#ifdef CK_FIT_PROFILE
+extern "C" int ck_fit_profile_read(unsigned long long *out, int reset) {
+    unsigned long long z[3][16] = {};
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fit_prof), sizeof z) != hipSuccess) return -1;
+    if (reset && hipMemcpyToSymbol(HIP_SYMBOL(g_fit_prof), z, sizeof z) != hipSuccess) return -1;
+    return 0;
+}
+#endif
+
 int ck_launch_fit_quads(ck_handle *h, const uint8_t *qframes, int qstride, size_t qpitch, const uint8_t *frames, int stride,
                         size_t pitch, int n) {
     ck_stage_ws &ws = h->ws;
@@ -713,13 +760,26 @@ int ck_launch_fit_quads(ck_handle *h, const uint8_t *qframes, int qstride, size_
     a.min_tag_width /= h->cfg.quad_decimate;
     if (a.min_tag_width < 3) a.min_tag_width = 3;
     a.ws = ws;
+    {
+        static bool combos_ready = false; // process-wide table, written once
+        if (!combos_ready) {
+            uint16_t tab[495];
+            int k = 0;
+            for (int m0 = 0; m0 < MAXSEL - 3; m0++)
+                for (int m1 = m0 + 1; m1 < MAXSEL - 2; m1++)
+                    for (int m2 = m1 + 1; m2 < MAXSEL - 1; m2++)
+                        for (int m3 = m2 + 1; m3 < MAXSEL; m3++) tab[k++] = (uint16_t)((m0 << 12) | (m1 << 8) | (m2 << 4) | m3);
+            CK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_combos), tab, sizeof tab));
+            combos_ready = true;
+        }
+    }
     int cus = 256;
     a.list = lists; a.list_count = list_counts; a.head = heads;
-    hipLaunchKernelGGL((k_fit<64, 512, 128, true>), dim3((unsigned)(cus * 8)), dim3(64), 0, h->stream, a);
+    hipLaunchKernelGGL((k_fit<64, 512, 64, true, 4>), dim3((unsigned)(cus * 12)), dim3(64), 0, h->stream, a);
     a.list = lists + list_cap; a.list_count = list_counts + 1; a.head = heads + 1;
-    hipLaunchKernelGGL((k_fit<256, 4096, 256, true>), dim3((unsigned)(cus * 2)), dim3(256), 0, h->stream, a);
+    hipLaunchKernelGGL((k_fit<256, 4096, 256, true, 2>), dim3((unsigned)(cus * 2)), dim3(256), 0, h->stream, a);
     a.list = lists + 2 * (size_t)list_cap; a.list_count = list_counts + 2; a.head = heads + 2;
-    hipLaunchKernelGGL((k_fit<1024, 16384, 256, false>), dim3((unsigned)cus), dim3(1024), 0, h->stream, a);
+    hipLaunchKernelGGL((k_fit<1024, 16384, 256, false, 4>), dim3((unsigned)cus), dim3(1024), 0, h->stream, a);
     hipLaunchKernelGGL(k_clamp_counts, dim3(1), dim3(64), 0, h->stream, list_counts, list_cap, ws, n);
     CK_HIP(hipGetLastError());
     return CK_OK;
