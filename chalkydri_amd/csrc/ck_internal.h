@@ -126,5 +126,8 @@ int ck_launch_clusters(ck_handle *h, int n);
 int ck_launch_fit_quads(ck_handle *h, const uint8_t *qframes, int qstride, size_t qpitch, const uint8_t *frames, int stride,
                         size_t pitch, int n);
 int ck_launch_decode(ck_handle *h, const uint8_t *frames, int stride, size_t pitch, int n);
+// glue + SQPnP + measurement on the detections left on the device by the last pipeline run
+int ck_run_pose(ck_handle *h, int n, const ck_process_params_t *pp, const double *gyro, const uint8_t *has_gyro,
+                ck_vision_measurement_t *out, int32_t *valid);
 
 #endif

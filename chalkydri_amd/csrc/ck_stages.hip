@@ -193,3 +193,40 @@ extern "C" int ck_quads_batch(ck_handle_t *h, const ck_image_u8_t *imgs, int32_t
     }
     return CK_OK;
 }
+
+static int process_common(ck_handle *h, const uint8_t *frames, int stride, size_t pitch, int n, const ck_process_params_t *pp,
+                          const double *gyro, const uint8_t *has_gyro, ck_vision_measurement_t *out, int32_t *valid) {
+    if (!pp || !gyro || !has_gyro || !out || !valid || (pp->n_field > 0 && !pp->field) || pp->n_field < 0) return CK_EINVAL;
+    CK_HIP(hipEventRecord(h->ev[0], h->stream));
+    int rc = run_pipeline(h, frames, stride, pitch, n, 3);
+    if (rc != CK_OK) return rc;
+    rc = ck_run_pose(h, n, pp, gyro, has_gyro, out, valid);
+    CK_HIP(hipEventRecord(h->ev[6], h->stream));
+    CK_HIP(hipStreamSynchronize(h->stream));
+    ck_stage_ms_t &ms = h->last_ms;
+    float t;
+    auto el = [&](int a, int b) { t = 0; (void)hipEventElapsedTime(&t, h->ev[a], h->ev[b]); return t; };
+    ms.h2d = el(0, 1); ms.threshold = el(1, 2); ms.segment = 0; ms.clusters = el(2, 3); ms.quads = el(3, 4);
+    ms.decode = el(4, 5); ms.d2h = el(5, 6); ms.total = el(0, 6); // d2h slot = glue + SQPnP + 64-byte records back
+    return rc;
+}
+
+extern "C" int ck_process_uploaded(ck_handle_t *h, int32_t n, const ck_process_params_t *pp, const double *gyro, const uint8_t *has_gyro,
+                                   ck_vision_measurement_t *out, int32_t *valid) {
+    if (!h || n < 0 || n > h->n_staged) return CK_EINVAL;
+    if (n == 0) return CK_OK;
+    CK_HIP(hipSetDevice(h->device));
+    return process_common(h, h->d_frames, h->frame_stride, h->frame_pitch, n, pp, gyro, has_gyro, out, valid);
+}
+
+extern "C" int ck_process_batch_device(ck_handle_t *h, const uint8_t *d_frames, int32_t n, int32_t stride, int64_t frame_pitch,
+                                       const ck_process_params_t *pp, const double *gyro, const uint8_t *has_gyro,
+                                       ck_vision_measurement_t *out, int32_t *valid) {
+    if (!h) return CK_EINVAL;
+    if (n == 0) return CK_OK;
+    CK_HIP(hipSetDevice(h->device));
+    const uint8_t *use; int us; size_t up;
+    int rc = ck_stage_device_frames(h, d_frames, n, stride, frame_pitch, &use, &us, &up);
+    if (rc != CK_OK) return rc;
+    return process_common(h, use, us, up, n, pp, gyro, has_gyro, out, valid);
+}

@@ -109,3 +109,52 @@ def dets_to_list(dets, n):
                     "c": np.array([d.c[0], d.c[1]]),
                     "p": np.array([[d.p[k][0], d.p[k][1]] for k in range(4)])})
     return out
+
+
+# ---- SQPnP ---------------------------------------------------------------------------------------------
+def _iso(R, t):
+    from np_sqpnp import mat_to_quat
+    iso = A.Iso3()
+    q = mat_to_quat(np.asarray(R, float))
+    for k in range(3):
+        iso.t[k] = float(t[k])
+    for k in range(4):
+        iso.q[k] = float(q[k])
+    return iso
+
+
+def sqpnp_solve(tags, bearings, robot_to_cam, gyro, sign_change_error=600.0, max_iter=15, tol_sq=1e-16):
+    L = lib()
+    prm = A.SqpnpParams(max_iter, tol_sq)
+    isos = (A.Iso3 * max(len(tags), 1))(*[_iso(R, t) for R, t in tags])
+    b = np.ascontiguousarray(bearings, np.float64)
+    rtc = _iso(*robot_to_cam)
+    res = A.SqpnpResult()
+    L.ora_sqpnp_solve_robot_pose.restype = C.c_int
+    L.ora_sqpnp_solve_robot_pose.argtypes = [C.POINTER(A.SqpnpParams), C.POINTER(A.Iso3), C.c_int, C.c_void_p, C.c_int,
+                                             C.POINTER(A.Iso3), C.c_double, C.c_double, C.POINTER(A.SqpnpResult)]
+    ok = L.ora_sqpnp_solve_robot_pose(C.byref(prm), isos, len(tags), b.ctypes.data, len(b), C.byref(rtc), gyro,
+                                      sign_change_error, C.byref(res))
+    if not ok:
+        return None
+    return {"rot": np.array(res.rot[:]).reshape(3, 3), "pos": np.array(res.pos[:]), "std": np.array(res.std_devs[:]),
+            "yaw": res.yaw, "energy": res.energy}
+
+
+def create_solver_camera_transform(*args):
+    L = lib()
+    out = A.Iso3()
+    L.ora_sqpnp_create_solver_camera_transform.restype = None
+    L.ora_sqpnp_create_solver_camera_transform.argtypes = [C.c_double] * 6 + [C.POINTER(A.Iso3)]
+    L.ora_sqpnp_create_solver_camera_transform(*[float(a) for a in args], C.byref(out))
+    return np.array(out.t[:]), np.array(out.q[:])
+
+
+def unproject_opencv5(cam, px):
+    L = lib()
+    px = np.ascontiguousarray(px, np.float64).reshape(-1, 2)
+    out = np.empty((len(px), 3))
+    ok = np.empty(len(px), np.uint8)
+    c = A.OpenCV5(*[float(v) for v in cam])
+    L.ora_unproject_opencv5(C.byref(c), C.c_void_p(px.ctypes.data), len(px), C.c_void_p(out.ctypes.data), C.c_void_p(ok.ctypes.data))
+    return out, ok.astype(bool)

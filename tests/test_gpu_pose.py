@@ -1,0 +1,113 @@
+"""GPU parity for SQPnP and the AprilTags::process glue: HIP vs oracle within the stated float tolerance
+(|dR|,|dt| <= 1e-9 for the solver; end-to-end pose: position 1e-6 m, yaw 1e-7 rad) and vs synthetic ground truth."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import np_sqpnp as N
+import scenes
+from chalkydri_amd import _abi as A
+from chalkydri_amd import default_config
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-9
+
+
+def _iso(R, t):
+    from chalkydri_amd.sqpnp import iso3
+    return iso3(t, N.mat_to_quat(np.asarray(R)))
+
+
+def test_sqpnp_batch_matches_oracle(oracle):
+    from chalkydri_amd.detector import AprilTagDetector
+    from chalkydri_amd.sqpnp import SqPnP
+    det = AprilTagDetector(64, 64)
+    solver = SqPnP(det)
+    rng = np.random.default_rng(7)
+    probs, want = [], []
+    for k in range(64):
+        n_tags = int(rng.integers(1, 31))
+        tags, b, rtc, truth = N.make_scene(rng, n_tags, noise_px=0.25 if k % 2 else 0.0)
+        gyro = truth["yaw"] + rng.uniform(-0.6, 0.6)
+        probs.append(([_iso(R, t) for R, t in tags], b, _iso(*rtc), gyro, 600.0))
+        want.append(oracle.sqpnp_solve(tags, b, rtc, gyro))
+    got = solver.solve_batch(probs)
+    n_valid = 0
+    for g, w in zip(got, want):
+        assert (g is None) == (w is None)
+        if g is None:
+            continue
+        n_valid += 1
+        assert np.abs(g["rot"] - w["rot"]).max() < TOL and np.abs(g["pos"] - w["pos"]).max() < TOL
+        assert abs(g["yaw"] - w["yaw"]) < TOL
+        if w["energy"] > 1e-13:
+            assert np.allclose(g["std_devs"], w["std"], rtol=1e-9, atol=0)
+        R = g["rot"]
+        assert np.abs(R.T @ R - np.eye(3)).max() < 1e-9 and abs(np.linalg.det(R) - 1) < 1e-9
+    assert n_valid >= 60
+    # guards (lib.rs:255)
+    tags, b, rtc, truth = N.make_scene(rng, 2)
+    bad = solver.solve_batch([([_iso(R, t) for R, t in tags], b[:-1], _iso(*rtc), 0.0, 600.0), ([], np.zeros((0, 3)), _iso(*rtc), 0.0, 600.0)])
+    assert bad == [None, None]
+    det.close()
+
+
+def test_builders_and_transform(oracle):
+    from chalkydri_amd.sqpnp import SqPnP
+    s = SqPnP().max_iter(3).tolerance(1e-4)
+    assert s._prm.max_iter == 3 and abs(s._prm.tol_sq - 1e-8) < 1e-20
+    for args in [(0, 0, 0, 0, 0, 0), (0.3, -0.2, 0.5, 3.0, -10.0, 25.0), (0, 0, 0, 0, 0, 180.0)]:
+        iso = SqPnP.create_solver_camera_transform(*args)
+        t, q = oracle.create_solver_camera_transform(*args)
+        assert np.abs(np.array(iso.t[:]) - t).max() < 1e-15 and np.abs(np.array(iso.q[:]) - q).max() < 1e-15
+
+
+def test_unproject_matches_oracle(oracle):
+    from chalkydri_amd.sqpnp import unproject_opencv5
+    m = scenes.REF_CALIB["OpenCVModel5"]
+    cam = tuple(m[k] for k in ("fx", "fy", "cx", "cy", "k1", "k2", "p1", "p2", "k3"))
+    px = np.random.default_rng(0).uniform(0, 1600, (500, 2))
+    b, ok = unproject_opencv5(cam, px)
+    ob, ook = oracle.unproject_opencv5(cam, px)
+    assert np.array_equal(ok, ook) and np.abs(b - ob).max() < 1e-14
+
+
+@pytest.mark.parametrize("calib_kind", ["pinhole", "reference"])
+def test_process_end_to_end(oracle, calib_kind):
+    """AprilTags::process on rendered 3-D scenes: device records == oracle records (tolerance) and ~ ground truth."""
+    from chalkydri_amd.apriltags import AprilTags
+    w, h, f = 1280, 800, 1100.0
+    layout = scenes.wall_layout(12)
+    r2c = {"roll": 0.0, "pitch": 0.0, "yaw": 0.0, "x": 0.2, "y": 0.0, "z": 0.6}
+    calib = scenes.pinhole_calib(f, w / 2.0, h / 2.0) if calib_kind == "pinhole" else scenes.REF_CALIB
+    rng = np.random.default_rng(3)
+    frames, truths, gyros = [], [], []
+    for i in range(4):
+        pose = (rng.uniform(1.0, 2.5), rng.uniform(-0.6, 0.6), rng.uniform(-0.25, 0.25))
+        fr, tr = scenes.render_view(1000 + i, w, h, f, layout, pose, r2c, noise_amp=1)
+        frames.append(fr); truths.append(tr); gyros.append(pose[2] + rng.uniform(-0.02, 0.02))
+    frames = np.stack(frames)
+    gyros[3] = None   # "no gyro, no solve" gate (apriltags/src/lib.rs:330)
+    task = AprilTags(w, h, layout, calib, r2c, cam_id=7, max_batch=4)
+    recs, valid = task.process_batch(frames, gyros)
+    cfg = default_config(w, h)
+    for i in range(4):
+        out = A.VisionMeasurement()
+        v = C.c_int(0)
+        oracle.lib().ora_process_frame(C.c_void_p(frames[i].ctypes.data), w, h, w, C.byref(cfg), C.byref(task._pp),
+                                       C.c_double(gyros[i] or 0.0), 0 if gyros[i] is None else 1, C.byref(out), C.byref(v))
+        assert bool(v.value) == bool(valid[i])
+        r = recs[i]
+        assert (r.camera_id, r.tag_count) == (out.camera_id, out.tag_count)
+        if not valid[i]:
+            assert bytes(r) == bytes(out)  # the empty heartbeat record (lib.rs:365-376)
+            continue
+        assert abs(r.pose_x - out.pose_x) < 1e-6 and abs(r.pose_y - out.pose_y) < 1e-6 and abs(r.pose_rot - out.pose_rot) < 1e-7
+        assert np.allclose([r.std_x, r.std_y, r.std_rot], [out.std_x, out.std_y, out.std_rot], rtol=1e-6)
+        assert r.tag_count >= 6
+        if calib_kind == "pinhole":   # the renderer is distortion-free, so only this calibration can recover truth
+            assert abs(r.pose_x - truths[i]["twr"][0]) < 0.03 and abs(r.pose_y - truths[i]["twr"][1]) < 0.03
+            assert abs((r.pose_rot - truths[i]["yaw"] + np.pi) % (2 * np.pi) - np.pi) < 0.03
+    assert valid[:3].all() and not valid[3]
+    task.detector.close()

@@ -1,0 +1,86 @@
+"""Pins oracle/sqpnp.c: independent numpy restatement (1e-9), algebraic invariants, exact recovery on noise-free
+scenes (the reference holds no fixture for this crate)."""
+import numpy as np
+import pytest
+
+import np_sqpnp as N
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_oracle_matches_numpy_and_recovers_truth(oracle, seed):
+    rng = np.random.default_rng(seed)
+    n_tags = int(rng.integers(1, 8))
+    tags, b, rtc, truth = N.make_scene(rng, n_tags)
+    gyro = truth["yaw"] + rng.uniform(-0.03, 0.03)
+    ref = N.solve_robot_pose(tags, b, rtc, gyro)
+    got = oracle.sqpnp_solve(tags, b, rtc, gyro)
+    assert ref is not None and got is not None
+    assert np.abs(got["rot"] - ref["rot"]).max() < 1e-9
+    assert np.abs(got["pos"] - ref["pos"]).max() < 1e-9
+    if ref["energy"] > 1e-13 and got["energy"] > 1e-13:   # below that the sign of the round-off decides NaN vs clamp
+        assert np.allclose(got["std"], ref["std"], rtol=1e-6, atol=1e-12)
+    assert abs(got["yaw"] - ref["yaw"]) < 1e-9
+    # invariants: proper rotation, energy ~ 0 on exact data
+    R = got["rot"]
+    assert np.abs(R.T @ R - np.eye(3)).max() < 1e-9 and abs(np.linalg.det(R) - 1) < 1e-9
+    assert abs(got["energy"]) < 1e-12
+    # noise-free data + (almost) true gyro: the robot pose comes back (the yaw pivot moves it by < its weight)
+    d = (gyro - truth["yaw"])
+    assert np.abs(got["pos"] - truth["twr"]).max() < 1e-3 + 10 * abs(d) ** 3
+    assert abs((got["yaw"] - truth["yaw"] + np.pi) % (2 * np.pi) - np.pi) < abs(d) + 1e-6
+
+
+def test_exact_gyro_exact_pose(oracle):
+    rng = np.random.default_rng(99)
+    tags, b, rtc, truth = N.make_scene(rng, 3)
+    got = oracle.sqpnp_solve(tags, b, rtc, truth["yaw"])
+    assert np.abs(got["pos"] - truth["twr"]).max() < 1e-6
+    assert np.abs(got["rot"] - truth["Rwr"]).max() < 1e-6
+
+
+def test_noisy_scene_agrees_with_numpy(oracle):
+    rng = np.random.default_rng(5)
+    for _ in range(6):
+        tags, b, rtc, truth = N.make_scene(rng, int(rng.integers(2, 6)), noise_px=0.3)
+        gyro = truth["yaw"] + rng.uniform(-0.2, 0.2)
+        ref = N.solve_robot_pose(tags, b, rtc, gyro)
+        got = oracle.sqpnp_solve(tags, b, rtc, gyro)
+        assert (ref is None) == (got is None)
+        if ref is not None:
+            assert np.abs(got["rot"] - ref["rot"]).max() < 1e-8 and np.abs(got["pos"] - ref["pos"]).max() < 1e-8
+            assert np.allclose(got["std"], ref["std"], rtol=1e-6)
+
+
+def test_guards(oracle):
+    rng = np.random.default_rng(1)
+    tags, b, rtc, truth = N.make_scene(rng, 2)
+    assert oracle.sqpnp_solve(tags, b[:-1], rtc, 0.0) is None       # len mismatch (lib.rs:255)
+    assert oracle.sqpnp_solve([], np.zeros((0, 3)), rtc, 0.0) is None  # < 3 points
+
+
+def test_create_solver_camera_transform(oracle):
+    t, q = oracle.create_solver_camera_transform(0, 0, 0, 0, 0, 0)
+    R = N.quat_to_mat(q)
+    # zero offsets: camera +z is robot +x (forward), camera +x is robot -y   
+    assert np.allclose(R.T @ [0, 0, 1], [1, 0, 0]) and np.allclose(R.T @ [1, 0, 0], [0, -1, 0]) and np.allclose(t, 0)
+    for args in [(0.3, -0.2, 0.5, 3.0, -10.0, 25.0), (0, 0, 0, 0, 0, 180.0)]:
+        t, q = oracle.create_solver_camera_transform(*args)
+        Rn, tn = N.create_solver_camera_transform(*args)
+        assert np.abs(N.quat_to_mat(q) - Rn).max() < 1e-12 and np.abs(t - tn).max() < 1e-12
+
+
+def test_unproject_roundtrip(oracle):
+    cam = (1368.3343056383071, 1368.513346806007, 784.1021700594862, 655.1967162171935, -0.03428799012079279,
+           -0.0021223103005884106, -0.001, -0.00014085919680638913, 0.015316405591806586)  # chalkydri.ron:29
+    rng = np.random.default_rng(0)
+    xy = rng.uniform(-0.5, 0.5, (200, 2))
+    r2 = (xy ** 2).sum(1)
+    fx, fy, cx, cy, k1, k2, p1, p2, k3 = cam
+    rad = 1 + r2 * (k1 + r2 * (k2 + r2 * k3))
+    xd = xy[:, 0] * rad + 2 * p1 * xy[:, 0] * xy[:, 1] + p2 * (r2 + 2 * xy[:, 0] ** 2)
+    yd = xy[:, 1] * rad + p1 * (r2 + 2 * xy[:, 1] ** 2) + 2 * p2 * xy[:, 0] * xy[:, 1]
+    px = np.stack([xd * fx + cx, yd * fy + cy], 1)
+    b, ok = oracle.unproject_opencv5(cam, px)
+    assert ok.all()
+    assert np.abs(b[:, :2] / b[:, 2:3] - xy).max() < 1e-10
+    assert np.abs(np.linalg.norm(b, axis=1) - 1).max() < 1e-14
