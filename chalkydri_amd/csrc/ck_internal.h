@@ -110,7 +110,7 @@ extern thread_local char ck_err_text[512];
 
 // ---- stage launchers (k_*.hip) ------------------------------------------------------------------------
 // threshold + tile-local CCL + cross-tile merge + border-root flatten, on frames [0,n) of `frames`
-int ck_launch_threshold_segment(ck_handle *h, const uint8_t *frames, int stride, size_t frame_pitch, int n);
+int ck_launch_threshold_segment(ck_handle *h, const uint8_t *frames, int stride, size_t frame_pitch, int n, bool precomputed = false);
 // canonical labels (min pixel index, flags stripped) and exact sizes — parity/test path, not the hot path
 int ck_launch_canonical_labels(ck_handle *h, int n, uint32_t *d_labels_out, uint32_t *d_sizes_out);
 int ck_launch_decimate(ck_handle *h, const uint8_t *frames, int stride, size_t frame_pitch, int n);

@@ -85,6 +85,10 @@ __device__ __forceinline__ uint32_t msb_nibble(uint32_t v) {
     return (((v >> 7) & 0x01010101u) * 0x01020408u) >> 24 & 0xFu;
 }
 
+// PRE = false: `frames` are gray images and the tri-state threshold is computed here;
+// PRE = true : `frames` already hold a tri-state map (0 / 127 / 255), e.g. CAT's class map, and only the
+//              segmentation runs (the map is copied through to `thresh` for the merge kernel).
+template <bool PRE>
 __global__ __launch_bounds__(NT) void k_tile(const uint8_t *__restrict__ frames, size_t frame_pitch, int stride,
                                              int w, int h, int tiles_x, int tiles_y, int min_diff, int min_comp,
                                              uint8_t *__restrict__ thresh, uint32_t *__restrict__ labels,
@@ -131,6 +135,7 @@ __global__ __launch_bounds__(NT) void k_tile(const uint8_t *__restrict__ frames,
     // ---- P1: min/max of every 4x4 tile of the staged region -------------------------------------------
     uint16_t *minmax = reinterpret_cast<uint16_t *>(lds + OFF_MINMAX);
     const int w4 = w >> 2, h4 = h >> 2;
+    if (!PRE)
     for (int item = tid; item < T4Y * T4X; item += NT) {
         int i = item / T4X, j = item - i * T4X;
         int g4x = (tx0 >> 2) - 1 + j, g4y = (ty0 >> 2) - 1 + i;
@@ -152,6 +157,7 @@ __global__ __launch_bounds__(NT) void k_tile(const uint8_t *__restrict__ frames,
 
     // ---- P2: 3x3 dilation -> per-4x4-tile threshold word (bit 8 = low contrast) ---------------------------
     uint16_t *thr = reinterpret_cast<uint16_t *>(lds + OFF_THR);
+    if (!PRE)
     for (int item = tid; item < (TH / 4) * (TW / 4); item += NT) {
         int i = item / (TW / 4), j = item - i * (TW / 4);
         uint32_t mn = 255, mx = 0;
@@ -177,9 +183,10 @@ __global__ __launch_bounds__(NT) void k_tile(const uint8_t *__restrict__ frames,
         uint32_t wbits = 0, bbits = 0;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            uint32_t tw_ = thr[(r >> 2) * (TW / 4) + 4 * c + k];
+            uint32_t tw_ = PRE ? 0u : thr[(r >> 2) * (TW / 4) + 4 * c + k];
             uint32_t o;
             if (gy >= h || gx + 4 * k >= w) o = 0x7F7F7F7Fu;      // outside the frame: no colour
+            else if (PRE) o = in[k];
             else if (tw_ & 0x100u) o = 0x7F7F7F7Fu;
             else {
                 o = 0;
@@ -505,12 +512,17 @@ __global__ __launch_bounds__(NT) void k_decimate(const uint8_t *__restrict__ src
 
 } // namespace
 
-int ck_launch_threshold_segment(ck_handle *h, const uint8_t *frames, int stride, size_t frame_pitch, int n) {
+int ck_launch_threshold_segment(ck_handle *h, const uint8_t *frames, int stride, size_t frame_pitch, int n, bool precomputed) {
     const int tiles = h->tiles_x * h->tiles_y;
     CK_HIP(hipMemsetAsync(h->d_broot_count, 0, sizeof(uint32_t) * (size_t)n, h->stream));
-    hipLaunchKernelGGL(k_tile, dim3((unsigned)(tiles * n)), dim3(NT), 0, h->stream, frames, frame_pitch, stride, h->qw, h->qh,
-                       h->tiles_x, h->tiles_y, h->cfg.min_white_black_diff, h->cfg.min_component_px, h->d_thresh, h->d_labels,
-                       h->d_broots, h->d_broot_count, h->broot_cap);
+    if (precomputed)
+        hipLaunchKernelGGL(k_tile<true>, dim3((unsigned)(tiles * n)), dim3(NT), 0, h->stream, frames, frame_pitch, stride, h->qw, h->qh,
+                           h->tiles_x, h->tiles_y, h->cfg.min_white_black_diff, h->cfg.min_component_px, h->d_thresh, h->d_labels,
+                           h->d_broots, h->d_broot_count, h->broot_cap);
+    else
+        hipLaunchKernelGGL(k_tile<false>, dim3((unsigned)(tiles * n)), dim3(NT), 0, h->stream, frames, frame_pitch, stride, h->qw, h->qh,
+                           h->tiles_x, h->tiles_y, h->cfg.min_white_black_diff, h->cfg.min_component_px, h->d_thresh, h->d_labels,
+                           h->d_broots, h->d_broot_count, h->broot_cap);
     hipLaunchKernelGGL(k_merge, dim3((unsigned)(tiles * n)), dim3(NT), 0, h->stream, h->d_thresh, h->d_labels, h->qw, h->qh,
                        h->tiles_x, h->tiles_y);
     int bx = (h->broot_cap + NT * 8 - 1) / (NT * 8);

@@ -158,3 +158,58 @@ def unproject_opencv5(cam, px):
     c = A.OpenCV5(*[float(v) for v in cam])
     L.ora_unproject_opencv5(C.byref(c), C.c_void_p(px.ctypes.data), len(px), C.c_void_p(out.ctypes.data), C.c_void_p(ok.ctypes.data))
     return out, ok.astype(bool)
+
+
+# ---- CAT -------------------------------------------------------------------------------------------------
+def cat_calc_otsu(rgb):
+    rgb = np.ascontiguousarray(rgb, np.uint8)
+    h, w = rgb.shape[:2]
+    out = np.empty((h, w), np.uint8)
+    lib().ora_cat_calc_otsu(C.c_void_p(rgb.ctypes.data), w, h, C.c_void_p(out.ctypes.data))
+    return out
+
+
+def cat_thresh(rgb):
+    rgb = np.ascontiguousarray(rgb, np.uint8)
+    h, w = rgb.shape[:2]
+    out = np.empty((h, w), np.uint8)
+    lib().ora_cat_thresh(C.c_void_p(rgb.ctypes.data), w, h, C.c_void_p(out.ctypes.data))
+    return out
+
+
+def cat_detect_corners(classes, cap=None):
+    c = np.ascontiguousarray(classes, np.uint8)
+    h, w = c.shape
+    cap = cap or w * h
+    pts = np.zeros((cap, 2), np.uint32)
+    n = lib().ora_cat_detect_corners(C.c_void_p(c.ctypes.data), w, h, C.c_void_p(pts.ctypes.data), cap)
+    return pts[:min(n, cap)].copy(), n
+
+
+def cat_check_edges(classes, pts, cap=None):
+    c = np.ascontiguousarray(classes, np.uint8)
+    h, w = c.shape
+    pts = np.ascontiguousarray(pts, np.uint32)
+    cap = cap or max(16, 2 * len(pts) ** 2)
+    lines = np.zeros((cap, 4), np.uint32)
+    n = lib().ora_cat_check_edges(C.c_void_p(c.ctypes.data), w, h, C.c_void_p(pts.ctypes.data), len(pts), C.c_void_p(lines.ctypes.data), cap)
+    return lines[:min(n, cap)].copy(), n
+
+
+def cat_connected_components(classes):
+    c = np.ascontiguousarray(classes, np.uint8)
+    h, w = c.shape
+    roots = np.empty((h, w), np.uint32)
+    sizes = np.empty((h, w), np.uint32)
+    lib().ora_cat_connected_components_canonical(C.c_void_p(c.ctypes.data), w, h, C.c_void_p(roots.ctypes.data), C.c_void_p(sizes.ctypes.data))
+    return roots, sizes
+
+
+def cat_connected_components_reference(classes):
+    """The reference-faithful sequential UnionFind (union by size): returns (parent, sizes) as u64 arrays."""
+    c = np.ascontiguousarray(classes, np.uint8)
+    h, w = c.shape
+    parent = np.empty(h * w, np.uint64)
+    sizes = np.empty(h * w, np.uint64)
+    lib().ora_cat_connected_components(C.c_void_p(c.ctypes.data), w, h, C.c_void_p(parent.ctypes.data), C.c_void_p(sizes.ctypes.data))
+    return parent, sizes
