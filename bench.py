@@ -1,0 +1,164 @@
+#!/usr/bin/env python3
+"""bench.py — frames/sec of the AprilTag detect + pose hot path on MI355X, with the HBM roofline of the
+threshold+segment stage and the CPU oracle timed beside it.
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+A step = one pass of the whole path (threshold -> segment -> clusters -> quad fit -> decode -> glue -> SQPnP -> 64-byte pose
+records) over one batch of synthetic frames that is already resident in HBM.  Workload at every N: BASELINE.json
+configs[1] — 1280x800 mono8, batch 256 per GPU, tag36h11, 6 field tags per frame rendered from 3-D scenes on the SURVEY
+§8d background (ramp +-24, uniform noise +-3).  N > 1 shards one camera stream per GPU (weak scaling) and ends every step
+with ONE RCCL all_gather of the 64-byte records; there is no other collective.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md)
+ALG_BYTES_PER_PX = 7.0  # threshold 1R+1W, segment 1R+4W
+
+
+def cpu_baseline(frames, gyro, task, cfg, seconds_hint=1.5):
+    """Oracle (oracle/libck_oracle.so, kind 'port') on the host cores, on a bounded sample of the same frames."""
+    from concurrent.futures import ThreadPoolExecutor
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import pyoracle
+    from chalkydri_amd import _abi as A
+    L = pyoracle.lib()
+    h, w = frames.shape[1:]
+    cores = max(1, min(16, os.cpu_count() or 1))
+
+    def one(i):
+        out = A.VisionMeasurement()
+        v = C.c_int(0)
+        f = np.ascontiguousarray(frames[i])
+        L.ora_process_frame(C.c_void_p(f.ctypes.data), w, h, w, C.byref(cfg), C.byref(task._pp), C.c_double(float(gyro[i])), 1,
+                            C.byref(out), C.byref(v))
+        return v.value
+
+    t0 = time.perf_counter()
+    one(0)
+    per = time.perf_counter() - t0
+    n = int(max(cores, seconds_hint * cores / max(per, 1e-3)))  # ~seconds_hint of wall time = cores * seconds_hint of CPU work
+    n = max(cores, (n // cores) * cores)
+    idx = [i % len(frames) for i in range(n)]
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(cores) as ex:
+        valid = list(ex.map(one, idx))
+    dt = time.perf_counter() - t0
+    return {"value": round(n / dt, 2), "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"{n} frames of the same 1280x800 workload through oracle/ (C restatement, detect+pose), {cores} threads, "
+                      f"{sum(valid)} valid poses, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--width", type=int, default=1280)
+    ap.add_argument("--height", type=int, default=800)
+    ap.add_argument("--tags", type=int, default=6)
+    ap.add_argument("--noise", type=int, default=3)
+    ap.add_argument("--decimate", type=int, default=1)
+    ap.add_argument("--unique", type=int, default=32, help="distinct frames rendered per stream, repeated to fill the batch")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as tdist
+    from chalkydri_amd import default_config, dist, scenes
+    from chalkydri_amd.apriltags import AprilTags
+
+    rank, local_rank, world = dist.env_rank()
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist.init("nccl")
+
+    w, h, n = args.width, args.height, args.batch
+    frames, gyro, layout, calib, r2c = scenes.bench_stream(2, n, w, h, args.tags, stream=rank, unique=args.unique, noise_amp=args.noise)
+    task = AprilTags(w, h, layout, calib, r2c, cam_id=rank, max_batch=n, device=local_rank, quad_decimate=args.decimate)
+    task.detector.upload(frames)                      # inputs resident in HBM before the timed region
+    d_gyro = torch.from_numpy(np.ascontiguousarray(gyro)).to(dev)
+    d_has = torch.ones(n, dtype=torch.uint8, device=dev)
+    d_rec = torch.zeros((n, 64), dtype=torch.uint8, device=dev)
+    d_valid = torch.zeros(n, dtype=torch.int32, device=dev)
+    gathered = None
+    thr_ms = []
+
+    def step(record=False):
+        nonlocal gathered
+        task.process_uploaded_into(n, d_gyro.data_ptr(), d_has.data_ptr(), d_rec.data_ptr(), d_valid.data_ptr())
+        if record:
+            thr_ms.append(task.detector.stage_ms()["threshold"])
+        gathered = dist.gather_records(d_rec, world)   # the one collective of the path (RCCL over xGMI)
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        tdist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(record=True)
+    torch.cuda.synchronize()
+    if world > 1:
+        tdist.barrier()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        tdist.all_reduce(tmax, op=tdist.ReduceOp.MAX)
+    dt = float(tmax.item())
+
+    if rank == 0:
+        stage = task.detector.stage_ms()
+        recs = dist.records_to_numpy(gathered)
+        valid_frac = float(np.count_nonzero(recs["tag_count"] > 0)) / len(recs)
+        ms_thr = float(np.mean(thr_ms))
+        achieved = ALG_BYTES_PER_PX * w * h * n / (ms_thr * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "frames/sec (detect+pose) on 1280x800 batch; HBM GB/s vs roofline",
+            "value": round(world * n * args.steps / dt, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt * 1e3 / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8 (threshold/segment/clusters: integer; quad fit/decode/SQPnP: f64)", "data": "synthetic",
+            "config": {"workload": f"{w}x{h} mono8 batch={n}/GPU, tag36h11, {args.tags} field tags/frame (3-D scenes), background ramp+-24 "
+                                   f"noise+-{args.noise}, quad_decimate={args.decimate}, detect+pose, one stream per GPU",
+                       "frames_with_pose": round(valid_frac, 4), "gather": "RCCL all_gather of 64-byte records" if world > 1 else "none (1 GPU)"},
+            "roofline": {"bound": "hbm", "kernel": "threshold+segment (k_tile + k_merge + k_roots_a/b)", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+                         "algorithmic_bytes_per_launch": ALG_BYTES_PER_PX * w * h * n, "avg_launch_ms": round(ms_thr, 4)},
+            "stage_ms_last_step": {k: round(v, 3) for k, v in stage.items()},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            cfg = default_config(w, h, quad_decimate=args.decimate)
+            out["cpu_baseline"] = cpu_baseline(frames[:args.unique], gyro[:args.unique], task, cfg)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    if world > 1:
+        tdist.barrier()
+        tdist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -70,6 +70,14 @@ class AprilTags:
         check(det._L.ck_process_uploaded(det._h, n, C.byref(self._pp), g.ctypes.data, has.ctypes.data, out, valid), "ck_process_uploaded")
         return out, np.array(valid[:], bool)
 
+    def process_uploaded_into(self, n, gyro_ptr, has_gyro_ptr, out_ptr, valid_ptr):
+        """Runs the whole path on the uploaded frames; every pointer may be host or device memory (no host round trip when
+        the caller hands over device buffers, e.g. torch tensors that feed the RCCL pose gather)."""
+        det = self.detector
+        check(det._L.ck_process_uploaded(det._h, n, C.byref(self._pp), C.c_void_p(gyro_ptr), C.c_void_p(has_gyro_ptr),
+                                         C.cast(C.c_void_p(out_ptr), C.POINTER(A.VisionMeasurement)),
+                                         C.cast(C.c_void_p(valid_ptr), C.POINTER(C.c_int32))), "ck_process_uploaded")
+
     def process_device(self, ptr, n, stride, frame_pitch, gyro):
         det = self.detector
         g = np.ascontiguousarray(gyro, np.float64)

@@ -59,8 +59,18 @@ struct ck_stage_ws {
     uint32_t *d_counters;      // [n][8]: 0 tmp points, 1 clusters, 2 kept points, 3 quads, 4 detections, 5 status
     ck_quad_t *d_quads;        // [n][quad_cap]
     ck_detection_t *d_dets;    // [n][det_cap]
-    void *d_fit_scratch;       // global scratch for clusters too large for LDS
+    void *d_fit_scratch;       // work lists of the quad-fit classes + decode candidates
     size_t fit_scratch_bytes;
+    // pose stage (glue + SQPnP), sized for max_batch frames and det_cap tags per frame
+    ck_field_tag_t *d_field; int field_cap;
+    double *d_gyro; uint8_t *d_has_gyro;
+    ck_sqpnp_problem_t *d_problems;
+    ck_iso3_t *d_pose_tags;    // [n][det_cap]
+    double *d_bearings;        // [n][det_cap][4][3]
+    double *d_world;           // [n][det_cap][4][3]
+    ck_sqpnp_result_t *d_results;
+    ck_vision_measurement_t *d_meas;
+    int32_t *d_valid;
 };
 #define CK_CNT_TMP 0
 #define CK_CNT_CLUSTERS 1

@@ -585,25 +585,24 @@ extern "C" int ck_unproject_opencv5(const ck_opencv5_t *cam, const double *px, i
 int ck_run_pose(ck_handle *h, int n, const ck_process_params_t *pp, const double *gyro, const uint8_t *has_gyro,
                 ck_vision_measurement_t *out, int32_t *valid) {
     ck_stage_ws &ws = h->ws;
-    DevBuf<ck_field_tag_t> dfield; DevBuf<double> dgyro, dbear, dworld; DevBuf<uint8_t> dhas; DevBuf<ck_sqpnp_problem_t> dprob;
-    DevBuf<ck_iso3_t> dtags; DevBuf<ck_sqpnp_result_t> dres; DevBuf<ck_vision_measurement_t> dout; DevBuf<int32_t> dvalid;
-    const size_t cap = (size_t)ws.det_cap;
-    if (dfield.alloc((size_t)pp->n_field) || dgyro.alloc((size_t)n) || dhas.alloc((size_t)n) || dprob.alloc((size_t)n) || dtags.alloc((size_t)n * cap) ||
-        dbear.alloc((size_t)n * cap * 12) || dworld.alloc((size_t)n * cap * 12) || dres.alloc((size_t)n) || dout.alloc((size_t)n) || dvalid.alloc((size_t)n)) return CK_ENOMEM;
-    if (pp->n_field) CK_HIP(hipMemcpyAsync(dfield.p, pp->field, sizeof(ck_field_tag_t) * (size_t)pp->n_field, hipMemcpyHostToDevice, h->stream));
-    CK_HIP(hipMemcpyAsync(dgyro.p, gyro, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, h->stream));
-    CK_HIP(hipMemcpyAsync(dhas.p, has_gyro, (size_t)n, hipMemcpyHostToDevice, h->stream));
+    if (pp->n_field > ws.field_cap) return CK_ECAPACITY;
+    // gyro / has_gyro / out / valid may be host or device pointers (hipMemcpyDefault resolves them)
+    if (pp->n_field) CK_HIP(hipMemcpyAsync(ws.d_field, pp->field, sizeof(ck_field_tag_t) * (size_t)pp->n_field, hipMemcpyDefault, h->stream));
+    CK_HIP(hipMemcpyAsync(ws.d_gyro, gyro, sizeof(double) * (size_t)n, hipMemcpyDefault, h->stream));
+    CK_HIP(hipMemcpyAsync(ws.d_has_gyro, has_gyro, (size_t)n, hipMemcpyDefault, h->stream));
     GlueArgs g;
-    g.ws = ws; g.cam = pp->cam; g.robot_to_cam = pp->robot_to_cam; g.field = dfield.p; g.n_field = pp->n_field; g.gyro = dgyro.p; g.has_gyro = dhas.p;
-    g.sign_change_error = pp->sign_change_error; g.problems = dprob.p; g.tags = dtags.p; g.bearings = dbear.p; g.n = n;
+    g.ws = ws; g.cam = pp->cam; g.robot_to_cam = pp->robot_to_cam; g.field = ws.d_field; g.n_field = pp->n_field; g.gyro = ws.d_gyro;
+    g.has_gyro = ws.d_has_gyro; g.sign_change_error = pp->sign_change_error; g.problems = ws.d_problems; g.tags = ws.d_pose_tags;
+    g.bearings = ws.d_bearings; g.n = n;
     hipLaunchKernelGGL(k_glue, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, h->stream, g);
     SolveArgs a;
-    a.prm = pp->sqpnp; a.problems = dprob.p; a.tags = dtags.p; a.bearings = dbear.p; a.out = dres.p; a.n = n; a.max_points = (int)cap * 4; a.world = dworld.p;
+    a.prm = pp->sqpnp; a.problems = ws.d_problems; a.tags = ws.d_pose_tags; a.bearings = ws.d_bearings; a.out = ws.d_results; a.n = n;
+    a.max_points = ws.det_cap * 4; a.world = ws.d_world;
     hipLaunchKernelGGL(k_sqpnp, dim3((unsigned)n), dim3(64), 0, h->stream, a);
-    hipLaunchKernelGGL(k_measure, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, h->stream, ws, dres.p, pp->camera_id, dout.p, dvalid.p, n);
+    hipLaunchKernelGGL(k_measure, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, h->stream, ws, ws.d_results, pp->camera_id, ws.d_meas, ws.d_valid, n);
     CK_HIP(hipGetLastError());
-    CK_HIP(hipMemcpyAsync(out, dout.p, sizeof(ck_vision_measurement_t) * (size_t)n, hipMemcpyDeviceToHost, h->stream));
-    CK_HIP(hipMemcpyAsync(valid, dvalid.p, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, h->stream));
+    CK_HIP(hipMemcpyAsync(out, ws.d_meas, sizeof(ck_vision_measurement_t) * (size_t)n, hipMemcpyDefault, h->stream));
+    CK_HIP(hipMemcpyAsync(valid, ws.d_valid, sizeof(int32_t) * (size_t)n, hipMemcpyDefault, h->stream));
     CK_HIP(hipStreamSynchronize(h->stream));
     return CK_OK;
 }
