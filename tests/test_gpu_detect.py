@@ -114,9 +114,8 @@ def test_detect_matches_oracle_and_truth(oracle, w, h, n_tags, fams, bits, kw):
         _same_dets(got[i], want)
         # and both agree with the renderer's ground truth: every rendered tag found, corners within 1.5 px
         for t in truths[i]:
-            side = np.linalg.norm(t["corners"][0] - t["corners"][1])
-            if side < 20:
-                continue
+            if min(np.linalg.norm(t["corners"][k] - t["corners"][(k + 1) % 4]) for k in range(4)) < 28:
+                continue   # strongly foreshortened / tiny tags may be missed or loose
             cand = [d for d in got[i] if (d.family(), d.id()) == (t["family"], t["id"])]
             assert cand, f"tag {t['id']} missed"
             d = min(cand, key=lambda d: np.abs(d.center() - t["center"]).max())

@@ -1,0 +1,74 @@
+"""CPU: host-side mirrors (field layout loader, wire record, sharding helpers) and a 2-rank gloo rehearsal of the pose gather."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+def test_field_layout_loader_on_reference_field_json(built):
+    from chalkydri_amd.apriltags import load_field_layout
+    tags = load_field_layout(os.path.join(HERE, "golden", "field.json"))   # copy of the reference's field.json (data fixture)
+    assert len(tags) == 32 and set(tags) == set(range(1, 33))
+    t1 = tags[1]
+    assert abs(t1.t[0] - 11.863959) < 1e-12 and abs(t1.t[2] - 0.889) < 1e-12
+    q = np.array(t1.q[:])
+    assert abs(np.linalg.norm(q) - 1) < 1e-15 and abs(q[3] - 1.0) < 1e-12   # W,X,Y,Z -> (w,x,y,z), normalised (field_layout.rs:36-38)
+
+
+def test_shard_helpers():
+    from chalkydri_amd import dist
+    for n, world in [(256, 8), (257, 8), (5, 8), (1024, 3)]:
+        blocks = [dist.shard_frames(n, r, world) for r in range(world)]
+        assert blocks[0][0] == 0 and blocks[-1][1] == n
+        assert all(a[1] == b[0] for a, b in zip(blocks, blocks[1:]))
+        assert max(b[1] - b[0] for b in blocks) - min(b[1] - b[0] for b in blocks) <= 1
+    assert dist.stream_of_rank(3, 8, 8) == [3] and dist.stream_of_rank(1, 8, 2) == [1, 3, 5, 7]
+
+
+def test_record_view_roundtrip():
+    from chalkydri_amd import _abi as A
+    from chalkydri_amd import dist
+    r = A.VisionMeasurement()
+    r.pose_x, r.pose_y, r.pose_rot, r.std_x, r.ts, r.camera_id, r.tag_count = 1.5, -2.25, 0.75, 0.01, 123456, 7, 5
+    raw = np.frombuffer(bytes(r), np.uint8).reshape(1, 64)
+    v = dist.records_to_numpy(raw)[0]
+    assert (v["pose_x"], v["pose_y"], v["pose_rot"], v["std_x"], v["ts"], v["camera_id"], v["tag_count"]) == (1.5, -2.25, 0.75, 0.01, 123456, 7, 5)
+    # little-endian f64 at offset 0, ts at 48, ids at 56/57 — crates/whacknet/src/lib.rs:43-66
+    assert raw[0, 56] == 7 and raw[0, 57] == 5 and np.frombuffer(raw[0, 48:56].tobytes(), "<u8")[0] == 123456
+
+
+WORKER = r'''
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import numpy as np, torch
+from chalkydri_amd import dist
+rank, local, world = dist.init("gloo")
+lo, hi = dist.shard_frames(10, rank, world)
+rec = torch.zeros((hi - lo, 64), dtype=torch.uint8)
+for i in range(lo, hi):
+    rec[i - lo, 0] = i          # frame index in byte 0
+    rec[i - lo, 56] = rank      # camera_id
+out = dist.gather_records(rec, world)
+assert out.shape == (10, 64)
+assert out[:, 0].tolist() == list(range(10)), out[:, 0].tolist()
+assert out[:, 56].tolist() == [0] * 5 + [1] * 5
+import torch.distributed as td
+td.barrier(); td.destroy_process_group()
+print("ok", rank)
+'''
+
+
+def test_two_rank_gloo_gather(tmp_path):
+    script = tmp_path / "w.py"
+    script.write_text(WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
+    outs = [p.communicate(timeout=180)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert "ok 0" in outs[0] and "ok 1" in outs[1]
