@@ -20,7 +20,8 @@
 
 namespace {
 
-constexpr int TW = CK_TW, TH = CK_TH, NT = 256;
+constexpr int TW = CK_TW, TH = CK_TH, NT = 256; // NT: merge / utility kernels
+constexpr int KNT = 256;                             // k_tile: one lane per (row segment, colour)
 constexpr int IMG_PITCH = 160;          // 12 pad | 4 halo | 128 tile | 4 halo | 12 pad
 constexpr int IMG_ROWS = TH + 8;
 constexpr int T4X = TW / 4 + 2, T4Y = TH / 4 + 2;
@@ -37,6 +38,7 @@ constexpr int OFF_MASK = OFF_UNION + UNION_BYTES;          // u64[TH][NSEG][2]
 constexpr int LDS_BYTES = OFF_MASK + TH * NSEG * 2 * 8;
 static_assert(OFF_THR + 1024 <= OFF_UNION + UNION_BYTES, "phase A scratch must fit in the size array");
 static_assert(LDS_BYTES <= 53248, "keep three workgroups per CU");
+static_assert(TH * NSEG * 2 == KNT, "k_tile thread mapping: colour x row x segment");
 
 // find with path halving.  Plain stores race with the atomicMin hooks of lds_union, but every value ever
 // written to p[a] is an ancestor of a, so the forest stays valid (a lost hook is re-issued by its own union).
@@ -85,11 +87,21 @@ __device__ __forceinline__ uint32_t msb_nibble(uint32_t v) {
     return (((v >> 7) & 0x01010101u) * 0x01020408u) >> 24 & 0xFu;
 }
 
+// Diagnostic build only (-DCK_TILE_PROFILE): per-phase cycle totals of k_tile in a buffer of their own.
+#ifdef CK_TILE_PROFILE
+__device__ unsigned long long g_tile_prof[16];
+#define TPROF_DECL unsigned long long tp0 = __builtin_readcyclecounter()
+#define TPROF(k) do { unsigned long long t_ = __builtin_readcyclecounter(); if (threadIdx.x == 0) atomicAdd(&g_tile_prof[k], t_ - tp0); tp0 = t_; } while (0)
+#else
+#define TPROF_DECL
+#define TPROF(k)
+#endif
+
 // PRE = false: `frames` are gray images and the tri-state threshold is computed here;
 // PRE = true : `frames` already hold a tri-state map (0 / 127 / 255), e.g. CAT's class map, and only the
 //              segmentation runs (the map is copied through to `thresh` for the merge kernel).
 template <bool PRE>
-__global__ __launch_bounds__(NT) void k_tile(const uint8_t *__restrict__ frames, size_t frame_pitch, int stride,
+__global__ __launch_bounds__(KNT) void k_tile(const uint8_t *__restrict__ frames, size_t frame_pitch, int stride,
                                              int w, int h, int tiles_x, int tiles_y, int min_diff, int min_comp,
                                              uint8_t *__restrict__ thresh, uint32_t *__restrict__ labels,
                                              ck_border_root *__restrict__ broots,
@@ -104,10 +116,11 @@ __global__ __launch_bounds__(NT) void k_tile(const uint8_t *__restrict__ frames,
     const size_t fbase = (size_t)frame * (size_t)w * (size_t)h;
     uint32_t *parent = reinterpret_cast<uint32_t *>(lds + OFF_PARENT);
 
+    TPROF_DECL;
     // ---- P0: parent[i] = i; stage the tile and its 4-pixel halo -------------------------------------
-    for (int i = tid * 4; i < TH * TW; i += NT * 4)
+    for (int i = tid * 4; i < TH * TW; i += KNT * 4)
         *reinterpret_cast<uint4 *>(&parent[i]) = make_uint4(i, i + 1, i + 2, i + 3);
-    for (int item = tid; item < IMG_ROWS * 8; item += NT) {
+    for (int item = tid; item < IMG_ROWS * 8; item += KNT) {
         int r = item >> 3, c = item & 7;
         int gy = ty0 - 4 + r, gx = tx0 + 16 * c;
         uint4 v = make_uint4(0, 0, 0, 0);
@@ -122,7 +135,7 @@ __global__ __launch_bounds__(NT) void k_tile(const uint8_t *__restrict__ frames,
         }
         *reinterpret_cast<uint4 *>(lds + OFF_IMG + r * IMG_PITCH + 16 + 16 * c) = v;
     }
-    for (int item = tid; item < IMG_ROWS * 2; item += NT) {
+    for (int item = tid; item < IMG_ROWS * 2; item += KNT) {
         int r = item >> 1, side = item & 1;
         int gy = ty0 - 4 + r, gx = side ? tx0 + TW : tx0 - 4;
         uint32_t v = 0;
@@ -131,12 +144,13 @@ __global__ __launch_bounds__(NT) void k_tile(const uint8_t *__restrict__ frames,
         *reinterpret_cast<uint32_t *>(lds + OFF_IMG + r * IMG_PITCH + (side ? 16 + TW : 12)) = v;
     }
     __syncthreads();
+    TPROF(0);
 
     // ---- P1: min/max of every 4x4 tile of the staged region -------------------------------------------
     uint16_t *minmax = reinterpret_cast<uint16_t *>(lds + OFF_MINMAX);
     const int w4 = w >> 2, h4 = h >> 2;
     if (!PRE)
-    for (int item = tid; item < T4Y * T4X; item += NT) {
+    for (int item = tid; item < T4Y * T4X; item += KNT) {
         int i = item / T4X, j = item - i * T4X;
         int g4x = (tx0 >> 2) - 1 + j, g4y = (ty0 >> 2) - 1 + i;
         uint32_t mn = 255, mx = 0;
@@ -158,7 +172,7 @@ __global__ __launch_bounds__(NT) void k_tile(const uint8_t *__restrict__ frames,
     // ---- P2: 3x3 dilation -> per-4x4-tile threshold word (bit 8 = low contrast) ---------------------------
     uint16_t *thr = reinterpret_cast<uint16_t *>(lds + OFF_THR);
     if (!PRE)
-    for (int item = tid; item < (TH / 4) * (TW / 4); item += NT) {
+    for (int item = tid; item < (TH / 4) * (TW / 4); item += KNT) {
         int i = item / (TW / 4), j = item - i * (TW / 4);
         uint32_t mn = 255, mx = 0;
 #pragma unroll
@@ -172,10 +186,11 @@ __global__ __launch_bounds__(NT) void k_tile(const uint8_t *__restrict__ frames,
         thr[item] = (uint16_t)((diff < min_diff) ? 0x100u : (mn + (uint32_t)(diff >> 1)));
     }
     __syncthreads();
+    TPROF(1);
 
     // ---- P3: threshold 16 pixels per item, write them, build the per-row colour masks ----------------------
     uint16_t *mask16 = reinterpret_cast<uint16_t *>(lds + OFF_MASK); // [r][seg][colour][piece]
-    for (int item = tid; item < TH * 8; item += NT) {
+    for (int item = tid; item < TH * 8; item += KNT) {
         int r = item >> 3, c = item & 7;
         int gy = ty0 + r, gx = tx0 + 16 * c;
         uint4 px = *reinterpret_cast<const uint4 *>(lds + OFF_IMG + (r + 4) * IMG_PITCH + 16 + 16 * c);
@@ -211,9 +226,10 @@ __global__ __launch_bounds__(NT) void k_tile(const uint8_t *__restrict__ frames,
         mask16[((r * NSEG + seg) * 2 + 1) * 4 + piece] = (uint16_t)bbits;
     }
     __syncthreads();
+    TPROF(2);
 
     // ---- P4: the image scratch is dead; it becomes the size array ---------------------------------------------
-    for (int i = tid * 16; i < UNION_BYTES; i += NT * 16) *reinterpret_cast<uint4 *>(lds + OFF_SIZE + i) = make_uint4(0, 0, 0, 0);
+    for (int i = tid * 16; i < UNION_BYTES; i += KNT * 16) *reinterpret_cast<uint4 *>(lds + OFF_SIZE + i) = make_uint4(0, 0, 0, 0);
 
     // ---- P5: unions.  thread = (colour, row, segment) --------------------------------------------------------------
     const uint64_t *masks = reinterpret_cast<const uint64_t *>(lds + OFF_MASK);
@@ -224,57 +240,98 @@ __global__ __launch_bounds__(NT) void k_tile(const uint8_t *__restrict__ frames,
     const uint64_t O = origin_mask(x0, w);
     const uint64_t S = M & ~((M << 1) & O); // segment-local run starts
     const uint32_t base = (uint32_t)(r * TW + 64 * s);
+    // Events of this segment: every link from one of its runs to a run that comes earlier in scan order
+    //   hleft : bit 0 continues the run that ends the segment on the left
+    //   Ev    : vertical links (first column of every stretch where this row and the row above overlap)
+    //   DL/DR : white only, diagonal links not already implied by a vertical one
+    uint64_t Ev = 0, DL = 0, DR = 0, U = 0, Su = 0, Ul = 0;
+    uint32_t left_node = 0;
+    bool hleft = false;
     if (M) {
-        if (s > 0 && (M & O & 1ull)) { // run continues from the segment on the left
+        if (s > 0 && (M & O & 1ull)) {
             uint64_t Ml = masks[(r * NSEG + s - 1) * 2 + color];
             if (Ml >> 63) {
                 uint64_t Ol = origin_mask(x0 - 64, w);
                 uint64_t Sl = Ml & ~((Ml << 1) & Ol);
-                lds_union(parent, base, base - 64 + (uint32_t)(63 - __builtin_clzll(Sl)));
+                left_node = base - 64 + (uint32_t)(63 - __builtin_clzll(Sl));
+                hleft = true;
             }
         }
         if (r > 0) {
-            const uint64_t U = masks[((r - 1) * NSEG + s) * 2 + color];
-            const uint64_t Su = U & ~((U << 1) & O);
+            U = masks[((r - 1) * NSEG + s) * 2 + color];
+            Su = U & ~((U << 1) & O);
             uint64_t V = M & U & O;
-            uint64_t Ev = V & ~(V << 1);
-            while (Ev) {
-                int i = __builtin_ctzll(Ev);
-                Ev &= Ev - 1;
-                lds_union(parent, base + run_start(S, i), base - TW + run_start(Su, i));
-            }
-            if (color == 0) { // white: diagonal links
-                uint64_t Ul = 0, Ur = 0;
+            Ev = V & ~(V << 1);
+            if (color == 0) {
+                uint64_t Ur = 0;
                 if (s > 0) Ul = masks[((r - 1) * NSEG + s - 1) * 2];
                 if (s < NSEG - 1) Ur = masks[((r - 1) * NSEG + s + 1) * 2];
                 int xn = x0 + 64; // origin flag of the column right of this segment
                 uint64_t On = (xn >= 1 && xn <= w - 2) ? 1ull : 0ull;
                 uint64_t MO = M & O;
-                uint64_t DL = MO & ((U << 1) | (Ul >> 63)) & ~U & ~(MO << 1);
-                uint64_t DR = MO & ((U >> 1) | (Ur << 63)) & ~(U & ((O >> 1) | (On << 63))) & ~(MO >> 1);
-                while (DL) {
-                    int i = __builtin_ctzll(DL);
-                    DL &= DL - 1;
-                    uint32_t b;
-                    if (i > 0) b = base - TW + run_start(Su, i - 1);
-                    else {
-                        uint64_t Ol = origin_mask(x0 - 64, w);
-                        uint64_t Sl = Ul & ~((Ul << 1) & Ol);
-                        b = base - TW - 64 + (uint32_t)(63 - __builtin_clzll(Sl));
-                    }
-                    lds_union(parent, base + run_start(S, i), b);
-                }
-                while (DR) {
-                    int i = __builtin_ctzll(DR);
-                    DR &= DR - 1;
-                    uint32_t b = (i < 63) ? base - TW + run_start(Su, i + 1) : base - TW + 64; // bit 0 of the right segment starts a run
-                    lds_union(parent, base + run_start(S, i), b);
-                }
+                DL = MO & ((U << 1) | (Ul >> 63)) & ~U & ~(MO << 1);
+                DR = MO & ((U >> 1) | (Ur << 63)) & ~(U & ((O >> 1) | (On << 63))) & ~(MO >> 1);
             }
         }
     }
+    auto up_left_node = [&](int i) -> uint32_t { // run of the pixel up-left of bit i
+        if (i > 0) return base - TW + (uint32_t)run_start(Su, i - 1);
+        uint64_t Ol = origin_mask(x0 - 64, w);
+        uint64_t Sl = Ul & ~((Ul << 1) & Ol);
+        return base - TW - 64 + (uint32_t)(63 - __builtin_clzll(Sl));
+    };
+    auto up_right_node = [&](int i) -> uint32_t { // bit 0 of the segment on the right always starts a run
+        return (i < 63) ? base - TW + (uint32_t)run_start(Su, i + 1) : base - TW + 64;
+    };
+    // ---- P5a: every run adopts ONE earlier run as its parent with a plain store.  Only the owner writes the entry
+    // and nothing reads parent[] in this phase, so no find and no atomic is needed for these links; the target always
+    // has a smaller index, which keeps the forest invariant (parent <= self) the atomic phase relies on.
+    {
+        uint64_t St = S;
+        while (St) {
+            int i = __builtin_ctzll(St);
+            St &= St - 1;
+            uint64_t rest = S & ~((2ull << i) - 1);
+            uint64_t above = rest ? (rest & (0ull - rest)) : 0ull;
+            uint64_t span = above ? (above - (1ull << i)) : (~0ull << i);
+            uint64_t e;
+            if ((e = Ev & span)) { int j = __builtin_ctzll(e); Ev &= ~(1ull << j); parent[base + i] = base - TW + (uint32_t)run_start(Su, j); }
+            else if ((e = DL & span)) { int j = __builtin_ctzll(e); DL &= ~(1ull << j); parent[base + i] = up_left_node(j); }
+            else if ((e = DR & span)) { int j = __builtin_ctzll(e); DR &= ~(1ull << j); parent[base + i] = up_right_node(j); }
+            else if (i == 0 && hleft) { hleft = false; parent[base] = left_node; }
+        }
+    }
     __syncthreads();
+    // ---- P5b: the remaining links (a run touching a second, third ... earlier run) go through the atomic union
+    if (hleft) lds_union(parent, base, left_node);
+    while (Ev) {
+        int i = __builtin_ctzll(Ev);
+        Ev &= Ev - 1;
+        lds_union(parent, base + run_start(S, i), base - TW + run_start(Su, i));
+    }
+    while (DL) {
+        int i = __builtin_ctzll(DL);
+        DL &= DL - 1;
+        lds_union(parent, base + run_start(S, i), up_left_node(i));
+    }
+    while (DR) {
+        int i = __builtin_ctzll(DR);
+        DR &= DR - 1;
+        lds_union(parent, base + run_start(S, i), up_right_node(i));
+    }
+    __syncthreads();
+    TPROF(3);
 
+    // ---- P6a: one halving find per run start shortens the chains the adopted parents left behind --------------------
+    {
+        uint64_t St = S;
+        while (St) {
+            int i = __builtin_ctzll(St);
+            St &= St - 1;
+            (void)lds_find(parent, base + i);
+        }
+    }
+    __syncthreads(); // halving stores must land before the owners publish final roots
     // ---- P6: flatten run starts, accumulate sizes and ring flags at the roots ---------------------------------------
     uint32_t *size32 = reinterpret_cast<uint32_t *>(lds + OFF_SIZE);
     {
@@ -283,7 +340,8 @@ __global__ __launch_bounds__(NT) void k_tile(const uint8_t *__restrict__ frames,
         while (St) {
             int i = __builtin_ctzll(St);
             St &= St - 1;
-            uint64_t above = St ? (St & (0ull - St)) : 0ull; // lowest remaining start
+            uint64_t rest = S & ~((2ull << i) - 1);          // starts above i in the whole segment
+            uint64_t above = rest ? (rest & (0ull - rest)) : 0ull; // lowest of them
             uint64_t span = above ? (above - (1ull << i)) : (~0ull << i);
             uint64_t run = M & span;
             uint32_t node = base + i;
@@ -297,10 +355,11 @@ __global__ __launch_bounds__(NT) void k_tile(const uint8_t *__restrict__ frames,
         }
     }
     __syncthreads();
+    TPROF(4);
 
     // ---- P7: write label words (16 pixels per item) -------------------------------------------------------------------
     const uint16_t *size16 = reinterpret_cast<const uint16_t *>(lds + OFF_SIZE);
-    for (int item = tid; item < TH * 8; item += NT) {
+    for (int item = tid; item < TH * 8; item += KNT) {
         int rr = item >> 3, c = item & 7;
         int gy = ty0 + rr, gx = tx0 + 16 * c;
         if (gy >= h || gx >= w) continue;
@@ -331,6 +390,7 @@ __global__ __launch_bounds__(NT) void k_tile(const uint8_t *__restrict__ frames,
                 *reinterpret_cast<uint4 *>(dst + 4 * q) = make_uint4(outw[4 * q], outw[4 * q + 1], outw[4 * q + 2], outw[4 * q + 3]);
     }
 
+    TPROF(5);
     // ---- P8: append ring-touching roots (wave ballot / prefix-sum compaction) ----------------------------------------
     {
         int cnt = 0;
@@ -370,7 +430,19 @@ __global__ __launch_bounds__(NT) void k_tile(const uint8_t *__restrict__ frames,
             }
         }
     }
+    TPROF(6);
 }
+
+#ifdef CK_TILE_PROFILE
+} // namespace
+extern "C" int ck_tile_profile_read(unsigned long long *out, int reset) {
+    unsigned long long z[16] = {};
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tile_prof), sizeof z) != hipSuccess) return -1;
+    if (reset && hipMemcpyToSymbol(HIP_SYMBOL(g_tile_prof), z, sizeof z) != hipSuccess) return -1;
+    return 0;
+}
+namespace {
+#endif
 
 // ---- cross-tile merge ----------------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t g_load(const uint32_t *L, uint32_t i) {
@@ -394,8 +466,8 @@ __device__ __forceinline__ uint32_t g_find_ro(const uint32_t *L, uint32_t r) {
         r = n;
     }
 }
-__device__ __forceinline__ void g_union(uint32_t *L, uint32_t p, uint32_t q) {
-    uint32_t a = g_load(L, p), b = g_load(L, q);
+// union of the components whose tile-local roots are a and b (both ring-touching, so their entries carry CK_LBL_BORDER)
+__device__ __forceinline__ void g_union_roots(uint32_t *L, uint32_t a, uint32_t b) {
     for (;;) {
         a = g_find(L, a);
         b = g_find(L, b);
@@ -407,8 +479,28 @@ __device__ __forceinline__ void g_union(uint32_t *L, uint32_t p, uint32_t q) {
     }
 }
 
+// One workgroup per tile, one thread per pixel of the tile's top row / left column / right column.  Every link that
+// crosses a tile boundary is reduced to the pair of tile-local roots it joins; a small LDS hash set keeps one thread
+// per distinct pair (a large component crosses an edge at dozens of places), and only those run the global union.
+constexpr int MSET = 1024;
+__device__ __forceinline__ void merge_link(uint32_t *L, unsigned long long *set, uint32_t p, uint32_t q) {
+    uint32_t a = L[p] & CK_LBL_IDX_MASK, b = L[q] & CK_LBL_IDX_MASK; // written by k_tile, read-only until a root entry is hooked
+    if (a == b) return;
+    unsigned long long key = a < b ? ((unsigned long long)a << 32) | b : ((unsigned long long)b << 32) | a;
+    uint32_t hsh = (uint32_t)((key >> 32) ^ key) * 2654435761u;
+    uint32_t slot = (hsh >> 12) & (MSET - 1);
+    for (int probe = 0; probe < 16; probe++) {
+        unsigned long long prev = atomicCAS(&set[slot], 0ull, key);
+        if (prev == key) return;          // another thread of this tile already owns the pair
+        if (prev == 0ull) break;          // inserted: this thread does the union
+        slot = (slot + 1) & (MSET - 1);
+    }                                     // table crowded: fall through and union without de-duplication
+    g_union_roots(L, a, b);
+}
+
 __global__ __launch_bounds__(NT) void k_merge(const uint8_t *__restrict__ thresh, uint32_t *__restrict__ labels, int w, int h,
                                               int tiles_x, int tiles_y) {
+    __shared__ unsigned long long sSet[MSET];
     const int tid = threadIdx.x;
     const int tiles = tiles_x * tiles_y;
     const int frame = blockIdx.x / tiles, tile = blockIdx.x - frame * tiles;
@@ -417,6 +509,8 @@ __global__ __launch_bounds__(NT) void k_merge(const uint8_t *__restrict__ thresh
     const size_t fbase = (size_t)frame * (size_t)w * (size_t)h;
     const uint8_t *T = thresh + fbase;
     uint32_t *L = labels + fbase;
+    for (int i = tid; i < MSET; i += NT) sSet[i] = 0ull;
+    __syncthreads();
     int x, y, kind;
     if (tid < TW) { x = tx0 + tid; y = ty0; kind = 0; }
     else if (tid < TW + TH) { x = tx0; y = ty0 + 1 + (tid - TW); kind = 1; }
@@ -427,21 +521,21 @@ __global__ __launch_bounds__(NT) void k_merge(const uint8_t *__restrict__ thresh
     const uint8_t v = T[p];
     if (v == 127) return;
     if (kind == 0) {
-        if (x == tx0 && tx0 > 0 && T[p - 1] == v) g_union(L, p, p - 1);
+        if (x == tx0 && tx0 > 0 && T[p - 1] == v) merge_link(L, sSet, p, p - 1);
         if (y >= 1) {
-            if (T[p - w] == v) g_union(L, p, p - w);
+            if (T[p - w] == v) merge_link(L, sSet, p, p - w);
             if (v == 255) {
-                if (T[p - w - 1] == 255) g_union(L, p, p - w - 1);
-                if (T[p - w + 1] == 255) g_union(L, p, p - w + 1);
+                if (T[p - w - 1] == 255) merge_link(L, sSet, p, p - w - 1);
+                if (T[p - w + 1] == 255) merge_link(L, sSet, p, p - w + 1);
             }
         }
     } else if (kind == 1) {
         if (tx0 > 0) {
-            if (T[p - 1] == v) g_union(L, p, p - 1);
-            if (v == 255 && T[p - w - 1] == 255) g_union(L, p, p - w - 1);
+            if (T[p - 1] == v) merge_link(L, sSet, p, p - 1);
+            if (v == 255 && T[p - w - 1] == 255) merge_link(L, sSet, p, p - w - 1);
         }
     } else {
-        if (v == 255 && T[p - w + 1] == 255) g_union(L, p, p - w + 1);
+        if (v == 255 && T[p - w + 1] == 255) merge_link(L, sSet, p, p - w + 1);
     }
 }
 
@@ -516,11 +610,11 @@ int ck_launch_threshold_segment(ck_handle *h, const uint8_t *frames, int stride,
     const int tiles = h->tiles_x * h->tiles_y;
     CK_HIP(hipMemsetAsync(h->d_broot_count, 0, sizeof(uint32_t) * (size_t)n, h->stream));
     if (precomputed)
-        hipLaunchKernelGGL(k_tile<true>, dim3((unsigned)(tiles * n)), dim3(NT), 0, h->stream, frames, frame_pitch, stride, h->qw, h->qh,
+        hipLaunchKernelGGL(k_tile<true>, dim3((unsigned)(tiles * n)), dim3(KNT), 0, h->stream, frames, frame_pitch, stride, h->qw, h->qh,
                            h->tiles_x, h->tiles_y, h->cfg.min_white_black_diff, h->cfg.min_component_px, h->d_thresh, h->d_labels,
                            h->d_broots, h->d_broot_count, h->broot_cap);
     else
-        hipLaunchKernelGGL(k_tile<false>, dim3((unsigned)(tiles * n)), dim3(NT), 0, h->stream, frames, frame_pitch, stride, h->qw, h->qh,
+        hipLaunchKernelGGL(k_tile<false>, dim3((unsigned)(tiles * n)), dim3(KNT), 0, h->stream, frames, frame_pitch, stride, h->qw, h->qh,
                            h->tiles_x, h->tiles_y, h->cfg.min_white_black_diff, h->cfg.min_component_px, h->d_thresh, h->d_labels,
                            h->d_broots, h->d_broot_count, h->broot_cap);
     hipLaunchKernelGGL(k_merge, dim3((unsigned)(tiles * n)), dim3(NT), 0, h->stream, h->d_thresh, h->d_labels, h->qw, h->qh,

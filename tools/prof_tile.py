@@ -1,0 +1,41 @@
+"""Diagnostic: builds a -DCK_TILE_PROFILE copy of the library into /tmp and prints per-phase cycle shares of k_tile."""
+import ctypes as C, os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+src = os.path.join(ROOT, "chalkydri_amd", "csrc")
+out = "/tmp/cktprof"; os.makedirs(out, exist_ok=True)
+objs = []
+for f in sorted(os.listdir(src)):
+    if f.endswith(".hip"):
+        o = os.path.join(out, f + ".o")
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=off",
+                               "-DCK_TILE_PROFILE", "-I" + os.path.join(ROOT, "include"), "-I" + src, "-c", os.path.join(src, f), "-o", o])
+        objs.append(o)
+    elif f.endswith(".c"):
+        o = os.path.join(out, f + ".o")
+        subprocess.check_call(["gcc", "-O2", "-fPIC", "-ffp-contract=off", "-I" + os.path.join(ROOT, "include"), "-I" + src, "-c", os.path.join(src, f), "-o", o])
+        objs.append(o)
+lib = os.path.join(out, "libchalkydri_hip.so")
+subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs)
+from chalkydri_amd import _lib
+_lib.LIB_PATH = lib
+import numpy as np
+from chalkydri_amd import synth
+from chalkydri_amd.detector import AprilTagDetector
+w, h, n = 1280, 800, 64
+L = _lib.lib()
+for noise in (3, 1):
+    base = np.stack([synth.render(synth.frame_seed(2, i), w, h, 6, noise_amp=noise)[0] for i in range(16)])
+    frames = np.concatenate([base] * 4)
+    det = AprilTagDetector(w, h, max_batch=n)
+    det.upload(frames)
+    buf = (C.c_ulonglong * 16)()
+    det.time_threshold_segment(n, 2)
+    L.ck_tile_profile_read(buf, 1)
+    ms = det.time_threshold_segment(n, 4)
+    L.ck_tile_profile_read(buf, 1)
+    names = ["P0 load", "P1-2 minmax", "P3 thresh+masks", "P4-5 unions", "P6 flatten+sizes", "P7 labels out", "P8 roots append"]
+    tot = sum(buf[k] for k in range(7)) or 1
+    tiles = 130 * n * 5
+    print("noise", noise, "ms/pass", round(ms, 3), "cycles/tile", round(tot / tiles), {names[k]: round(100 * buf[k] / tot, 1) for k in range(7)})
+    det.close()
