@@ -779,7 +779,7 @@ int ck_launch_fit_quads(ck_handle *h, const uint8_t *qframes, int qstride, size_
     a.list = lists + list_cap; a.list_count = list_counts + 1; a.head = heads + 1;
     hipLaunchKernelGGL((k_fit<256, 4096, 256, true, 2>), dim3((unsigned)(cus * 2)), dim3(256), 0, h->stream, a);
     a.list = lists + 2 * (size_t)list_cap; a.list_count = list_counts + 2; a.head = heads + 2;
-    hipLaunchKernelGGL((k_fit<1024, 16384, 256, false, 4>), dim3((unsigned)cus), dim3(1024), 0, h->stream, a);
+    hipLaunchKernelGGL((k_fit<512, 16384, 256, false, 2>), dim3((unsigned)cus), dim3(512), 0, h->stream, a);
     hipLaunchKernelGGL(k_clamp_counts, dim3(1), dim3(64), 0, h->stream, list_counts, list_cap, ws, n);
     CK_HIP(hipGetLastError());
     return CK_OK;
