@@ -146,7 +146,54 @@ struct Block {
         }
         return v;
     }
-    __device__ static void sync() { __syncthreads(); }
+    // inclusive scan of six values per thread with ONE barrier pair; v[] is replaced by the inclusive sums
+    __device__ static void scan_incl6(long long v[6], long long *scratch /* [6*NW] */) {
+        const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+#pragma unroll
+        for (int q = 0; q < 6; q++) {
+            long long x = v[q];
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                long long o = __shfl_up(x, d, 64);
+                if (lane >= d) x += o;
+            }
+            v[q] = x;
+        }
+        if (NW > 1) {
+            if (lane == 63)
+#pragma unroll
+                for (int q = 0; q < 6; q++) scratch[q * NW + wv] = v[q];
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < 6; q++) {
+                long long base = 0;
+                for (int k = 0; k < wv; k++) base += scratch[q * NW + k];
+                v[q] += base;
+            }
+            __syncthreads();
+        }
+    }
+    // sums of six values per thread over the workgroup (every thread gets them), one barrier pair
+    __device__ static void reduce_add6(long long v[6], long long *scratch /* [6*NW] */) {
+        const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+#pragma unroll
+        for (int q = 0; q < 6; q++)
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) v[q] += __shfl_xor(v[q], d, 64);
+        if (NW > 1) {
+            if (lane == 0)
+#pragma unroll
+                for (int q = 0; q < 6; q++) scratch[q * NW + wv] = v[q];
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < 6; q++) {
+                long long r = 0;
+                for (int k = 0; k < NW; k++) r += scratch[q * NW + k];
+                v[q] = r;
+            }
+            __syncthreads();
+        }
+    }
 };
 
 __device__ __forceinline__ void key_xy(unsigned long long k, int *x, int *y) { *x = (int)((k >> 13) & 0x1FFF); *y = (int)(k & 0x1FFF); }
@@ -279,7 +326,7 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(WPS, 8))) v
     __shared__ long long sP[6][SL];          // inclusive moment prefix sums over the current span; later the pair-fit table
     __shared__ double sErr[SL], sSm[SL];
     __shared__ long long sTot[NCH + 1][6];   // cumulative moments at chunk ends
-    __shared__ long long sScratch[2 * (NTH / 64) + 2];
+    __shared__ long long sScratch[6 * (NTH / 64) + 2];
     __shared__ double sMaxVal[MAXM];
     __shared__ uint16_t sMaxIdx[MAXM];
     __shared__ int sSelIdx[MAXSEL];
@@ -290,11 +337,14 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(WPS, 8))) v
     __shared__ int sNmax, sFlag;
     __shared__ double sLines[4][4];
     __shared__ double sQuad[4][2];
+    __shared__ uint16_t sCombos[496];
+    __shared__ double sRefine[4][16][2]; // per edge, per sample of the current round: refined point (x,y); x = NaN: no point
     static_assert(sizeof(PairFit) * MAXSEL * MAXSEL <= sizeof(long long) * 6 * SL, "pair-fit table must fit in sP");
     const int tid = threadIdx.x;
     const ck_stage_ws &ws = a.ws;
     uint32_t *sXY = reinterpret_cast<uint32_t *>(sKeys);
     uint16_t *sW = reinterpret_cast<uint16_t *>(sKeys) + 2 * CAP; // bytes [4*CAP, 6*CAP)
+    for (int i = tid; i < 495; i += NTH) sCombos[i] = g_combos[i]; // once per workgroup; the loop below starts with a barrier
 
     for (;;) {
         __syncthreads();
@@ -315,12 +365,32 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(WPS, 8))) v
 
         // ---- 1. bounding box + border direction ----------------------------------------------------------
         int xmin = 1 << 30, xmax = -(1 << 30), ymin = 1 << 30, ymax = -(1 << 30);
-        for (int i = tid; i < sz0; i += NTH) { // one coalesced pass; the raw 8-byte points wait in the key buffer
-            unsigned long long raw = reinterpret_cast<const unsigned long long *>(pts)[i];
-            sKeys[i] = raw;
-            int px = (int)(raw & 0xFFFF), py = (int)((raw >> 16) & 0xFFFF);
-            xmin = min(xmin, px); xmax = max(xmax, px);
-            ymin = min(ymin, py); ymax = max(ymax, py);
+        {   // one coalesced pass; all of a lane's loads are issued before the first use (one memory round trip, not EPL)
+            constexpr int EPL = CAP / NTH;
+            const unsigned long long *praw = reinterpret_cast<const unsigned long long *>(pts);
+            if constexpr (EPL <= 16) {
+                unsigned long long raw[EPL];
+#pragma unroll
+                for (int e = 0; e < EPL; e++) { int i = tid + e * NTH; raw[e] = (i < sz0) ? praw[i] : 0ull; }
+#pragma unroll
+                for (int e = 0; e < EPL; e++) {
+                    int i = tid + e * NTH;
+                    if (i < sz0) {
+                        sKeys[i] = raw[e];
+                        int px = (int)(raw[e] & 0xFFFF), py = (int)((raw[e] >> 16) & 0xFFFF);
+                        xmin = min(xmin, px); xmax = max(xmax, px);
+                        ymin = min(ymin, py); ymax = max(ymax, py);
+                    }
+                }
+            } else {
+                for (int i = tid; i < sz0; i += NTH) {
+                    unsigned long long raw = praw[i];
+                    sKeys[i] = raw;
+                    int px = (int)(raw & 0xFFFF), py = (int)((raw >> 16) & 0xFFFF);
+                    xmin = min(xmin, px); xmax = max(xmax, px);
+                    ymin = min(ymin, py); ymax = max(ymax, py);
+                }
+            }
         }
         int *iscr = reinterpret_cast<int *>(sScratch);
         xmin = B::reduce_min(xmin, iscr); xmax = -B::reduce_min(-xmax, iscr);
@@ -383,7 +453,43 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(WPS, 8))) v
         if (ksz < 2) continue;
 
         // ---- 3. gradient weights: one image gather per point, all in flight together ---------------------------------
-        for (int i = tid; i < sz; i += NTH) sW[i] = (uint16_t)point_weight(a, qim, sXY[i]);
+        {
+            constexpr int EPL = CAP / NTH;
+            if constexpr (EPL <= 16) { // issue every gather of the lane, then compute: one round trip
+                uint8_t g[EPL][4];
+                bool inb[EPL];
+#pragma unroll
+                for (int e = 0; e < EPL; e++) {
+                    int i = tid + e * NTH;
+                    inb[e] = false;
+                    g[e][0] = g[e][1] = g[e][2] = g[e][3] = 0;
+                    if (i < sz) {
+                        uint32_t xy = sXY[i];
+                        int x = (int)(xy >> 13), y = (int)(xy & 0x1FFF);
+                        int ix = (x + 1) >> 1, iy = (y + 1) >> 1;
+                        if (ix > 0 && ix + 1 < a.qw && iy > 0 && iy + 1 < a.qh) {
+                            const uint8_t *row = qim + (size_t)iy * a.qstride + ix;
+                            inb[e] = true;
+                            g[e][0] = row[1]; g[e][1] = row[-1]; g[e][2] = row[a.qstride]; g[e][3] = row[-a.qstride];
+                        }
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < EPL; e++) {
+                    int i = tid + e * NTH;
+                    if (i < sz) {
+                        uint32_t W = 1;
+                        if (inb[e]) {
+                            int gx = (int)g[e][0] - (int)g[e][1], gy = (int)g[e][2] - (int)g[e][3];
+                            W = isqrt_u32((uint32_t)(gx * gx + gy * gy)) + 1;
+                        }
+                        sW[i] = (uint16_t)W;
+                    }
+                }
+            } else {
+                for (int i = tid; i < sz; i += NTH) sW[i] = (uint16_t)point_weight(a, qim, sXY[i]);
+            }
+        }
         // the cluster's slice of the point array is dead from here on; the large class keeps its maxima there
         double *gval = reinterpret_cast<double *>(pts);
         uint32_t *gidx = reinterpret_cast<uint32_t *>(gval + (sz0 + 1) / 2);
@@ -412,7 +518,10 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(WPS, 8))) v
             }
             long long v[6] = {run.Mx, run.My, run.Mxx, run.Mxy, run.Myy, run.W}, ex[6];
 #pragma unroll
-            for (int q = 0; q < 6; q++) ex[q] = B::scan_incl(v[q], sScratch, nullptr) - v[q];
+            for (int q = 0; q < 6; q++) ex[q] = v[q];
+            B::scan_incl6(ex, sScratch);
+#pragma unroll
+            for (int q = 0; q < 6; q++) ex[q] -= v[q];
 #pragma unroll
             for (int e = 0; e < EPT; e++) {
                 int j = tid * EPT + e;
@@ -511,11 +620,10 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(WPS, 8))) v
             M6 part = m6_zero();
             for (int i = cb + tid; i <= gi; i += NTH) part = m6_add(part, moments_of(sXY[i], sW[i]));
             long long pv[6] = {part.Mx, part.My, part.Mxx, part.Mxy, part.Myy, part.W};
+            B::reduce_add6(pv, sScratch);
+            if (tid == 0)
 #pragma unroll
-            for (int q = 0; q < 6; q++) {
-                long long t = B::reduce_add(pv[q], sScratch);
-                if (tid == 0) sSelI[s][q] = sTot[c][q] + t;
-            }
+                for (int q = 0; q < 6; q++) sSelI[s][q] = sTot[c][q] + pv[q];
             if (tid == 0) {
                 M6 self = moments_of(sXY[gi], sW[gi]);
                 long long sv[6] = {self.Mx, self.My, self.Mxx, self.Mxy, self.Myy, self.W};
@@ -551,7 +659,7 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(WPS, 8))) v
         int bestc = 1 << 30;
         {
             for (int cb = tid; cb < 495; cb += NTH) { // every lane walks its own subsets; ties resolved by the packed index
-                const int pk = g_combos[cb];
+                const int pk = sCombos[cb];
                 const int m0 = pk >> 12, m1 = (pk >> 8) & 15, m2 = (pk >> 4) & 15, m3 = pk & 15;
                 if (m3 >= nsel) continue;
                 {
@@ -652,11 +760,92 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(WPS, 8))) v
         PROF(9);
         if (!sFlag) continue;
         if (a.refine) {
-            if (tid < 4) {
-                double P[4][2], line[4];
-                for (int i = 0; i < 4; i++) { P[i][0] = sQuad[i][0]; P[i][1] = sQuad[i][1]; }
-                refine_edge(a, im, P, reversed, tid, line);
-                for (int q = 0; q < 4; q++) sLines[tid][q] = line[q];
+            // Edge refinement (oracle refine_edges).  The samples of an edge are independent: lane (edge, k) evaluates sample
+            // 16*round + k (its 2*range+1 gradient probes are independent loads), then ONE lane per edge accumulates the
+            // refined points in sample order, so every sum is formed exactly as in the sequential code.
+            const int edge = (tid >> 4) & 3, k = tid & 15;
+            const bool worker = tid < 64;
+            const int ea = edge, eb = (edge + 1) & 3;
+            double nx = 0, ny = 0, mag = 1;
+            int nsamples = 0;
+            if (worker) {
+                nx = sQuad[eb][1] - sQuad[ea][1];
+                ny = -sQuad[eb][0] + sQuad[ea][0];
+                mag = sqrt(nx * nx + ny * ny);
+                nx = nx / mag; ny = ny / mag;
+                if (reversed) { nx = -nx; ny = -ny; }
+                nsamples = (int)(mag / 8.0);
+                if (nsamples < 16) nsamples = 16;
+            }
+            int max_samples = nsamples; // the same for the 16 lanes of an edge; rounds are driven by the largest edge
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) max_samples = max(max_samples, __shfl_xor(max_samples, d, 64));
+            if (NTH > 64) {
+                if (tid == 0) sRedI[0] = max_samples;
+                __syncthreads();
+                max_samples = sRedI[0];
+                __syncthreads();
+            }
+            double Mx = 0, My = 0, Mxx = 0, Mxy = 0, Myy = 0, N = 0; // meaningful on lane k == 0 of every edge
+            for (int base = 0; base < max_samples; base += 16) {
+                if (worker) {
+                    const int sidx = base + k;
+                    double bx = __builtin_nan(""), by = 0;
+                    if (sidx < nsamples) {
+                        double alpha = (1.0 + (double)sidx) / ((double)nsamples + 1.0);
+                        double x0 = alpha * sQuad[ea][0] + (1.0 - alpha) * sQuad[eb][0];
+                        double y0 = alpha * sQuad[ea][1] + (1.0 - alpha) * sQuad[eb][1];
+                        double Mn = 0, Mcount = 0;
+                        const int range = a.decimate + 1;
+                        for (int n = -range; n <= range; n++) {
+                            double grange = 1.0;
+                            int x1 = (int)(x0 + ((double)n + grange) * nx), y1 = (int)(y0 + ((double)n + grange) * ny);
+                            if (x1 < 0 || x1 >= a.w || y1 < 0 || y1 >= a.h) continue;
+                            int x2 = (int)(x0 + ((double)n - grange) * nx), y2 = (int)(y0 + ((double)n - grange) * ny);
+                            if (x2 < 0 || x2 >= a.w || y2 < 0 || y2 >= a.h) continue;
+                            int g1 = im[(size_t)y1 * a.stride + x1], g2 = im[(size_t)y2 * a.stride + x2];
+                            if (g1 < g2) continue;
+                            double weight = (double)((g2 - g1) * (g2 - g1));
+                            Mn += weight * (double)n;
+                            Mcount += weight;
+                        }
+                        if (Mcount != 0) {
+                            double n0 = Mn / Mcount;
+                            bx = x0 + n0 * nx; by = y0 + n0 * ny;
+                        }
+                    }
+                    sRefine[edge][k][0] = bx; sRefine[edge][k][1] = by;
+                }
+                __syncthreads();
+                if (worker && k == 0)
+                    for (int q = 0; q < 16 && base + q < nsamples; q++) {
+                        double bx = sRefine[edge][q][0], by = sRefine[edge][q][1];
+                        if (bx != bx) continue; // no usable gradient at this sample
+                        Mx += bx; My += by; Mxx += bx * bx; Mxy += bx * by; Myy += by * by; N += 1.0;
+                    }
+                __syncthreads();
+            }
+            if (worker && k == 0) {
+                double line[4];
+                if (N < 2.0) {
+                    line[0] = 0.5 * (sQuad[ea][0] + sQuad[eb][0]); line[1] = 0.5 * (sQuad[ea][1] + sQuad[eb][1]);
+                    line[2] = nx; line[3] = ny;
+                } else {
+                    double Ex = Mx / N, Ey = My / N;
+                    double Cxx = Mxx / N - Ex * Ex, Cxy = Mxy / N - Ex * Ey, Cyy = Myy / N - Ey * Ey;
+                    double d = Cxx - Cyy, q4 = 4.0 * Cxy;
+                    double disc = sqrt(d * d + q4 * Cxy);
+                    double eig = 0.5 * (Cxx + Cyy + disc);
+                    double nx1 = Cxx - eig, ny1 = Cxy, M1 = nx1 * nx1 + ny1 * ny1;
+                    double nx2 = Cxy, ny2 = Cyy - eig, M2 = nx2 * nx2 + ny2 * ny2;
+                    double fx, fy, M;
+                    if (M1 > M2) { fx = nx1; fy = ny1; M = M1; } else { fx = nx2; fy = ny2; M = M2; }
+                    double len = sqrt(M);
+                    line[0] = Ex; line[1] = Ey;
+                    if (len < 1e-12) { line[2] = nx; line[3] = ny; }
+                    else { line[2] = fx / len; line[3] = fy / len; }
+                }
+                for (int q = 0; q < 4; q++) sLines[edge][q] = line[q];
             }
             __syncthreads();
             if (tid == 0)
