@@ -59,6 +59,7 @@ struct ck_stage_ws {
     uint32_t *d_counters;      // [n][8]: 0 tmp points, 1 clusters, 2 kept points, 3 quads, 4 detections, 5 status
     ck_quad_t *d_quads;        // [n][quad_cap]
     ck_detection_t *d_dets;    // [n][det_cap]
+    uint16_t *d_wimg;          // [n][qh][qw] gradient-magnitude weight of every pixel (isqrt(gx^2+gy^2)+1; 1 on the frame ring)
     void *d_fit_scratch;       // work lists of the quad-fit classes + decode candidates
     size_t fit_scratch_bytes;
     // pose stage (glue + SQPnP), sized for max_batch frames and det_cap tags per frame

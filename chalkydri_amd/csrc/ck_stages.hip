@@ -37,6 +37,7 @@ int ck_stage_alloc(ck_handle *h) {
     size_t cand_bytes = 256 + ((nb * 4 + 255) / 256) * 256 + sizeof(ck_detection_t) * (size_t)ws.quad_cap * cfg.n_families * nb;
     ws.fit_scratch_bytes = ((list_bytes + 255) / 256) * 256 + cand_bytes;
     CK_HIP(hipMalloc(&ws.d_fit_scratch, ws.fit_scratch_bytes));
+    CK_HIP(hipMalloc(&ws.d_wimg, sizeof(uint16_t) * h->npix * nb));
     ws.field_cap = 1024;
     CK_HIP(hipMalloc(&ws.d_field, sizeof(ck_field_tag_t) * (size_t)ws.field_cap));
     CK_HIP(hipMalloc(&ws.d_gyro, sizeof(double) * nb));
@@ -77,7 +78,7 @@ void ck_stage_free(ck_handle *h) {
     }
     (void)hipFree(ws.d_ht_keys); (void)hipFree(ws.d_ht_count); (void)hipFree(ws.d_ht_off); (void)hipFree(ws.d_tmp);
     (void)hipFree(ws.d_points); (void)hipFree(ws.d_clusters); (void)hipFree(ws.d_counters); (void)hipFree(ws.d_quads);
-    (void)hipFree(ws.d_dets); (void)hipFree(ws.d_fit_scratch);
+    (void)hipFree(ws.d_dets); (void)hipFree(ws.d_fit_scratch); (void)hipFree(ws.d_wimg);
     (void)hipFree(ws.d_field); (void)hipFree(ws.d_gyro); (void)hipFree(ws.d_has_gyro); (void)hipFree(ws.d_problems);
     (void)hipFree(ws.d_pose_tags); (void)hipFree(ws.d_bearings); (void)hipFree(ws.d_world); (void)hipFree(ws.d_results);
     (void)hipFree(ws.d_meas); (void)hipFree(ws.d_valid);

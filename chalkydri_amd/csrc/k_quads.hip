@@ -14,16 +14,20 @@
 //      lexicographic tie-break), intersect the four lines, area/angle/winding checks, optional edge refinement.
 // Clusters are dispatched through per-size-class work lists built by k_classify (S <= 512, M <= 4096,
 // L <= 16384 points); each variant is a persistent grid that pulls cluster indices until the list is drained.
+#include <stdlib.h>
+
 #include "ck_internal.h"
 
 namespace {
 
 struct FitArgs {
     const uint8_t *qim; int qw, qh, qstride; size_t qpitch;     // image the clusters came from
+    const uint16_t *wimg;                                       // its gradient-magnitude weights, [n][qh][qw]
     const uint8_t *im; int w, h, stride; size_t pitch;          // full resolution image
     int decimate, refine, max_nmaxima, min_tag_width, normal_ok, reversed_ok;
     double cos_critical, max_mse;
     ck_stage_ws ws;
+    int stop_after;         // diagnostics (CK_FIT_STOP_AFTER): end every cluster after phase k; 99 = run everything
     const uint32_t *list;   // work list of this size class: frame << 20 | cluster index
     const uint32_t *list_count;
     uint32_t *head;         // dequeue counter
@@ -313,6 +317,107 @@ __device__ __forceinline__ M6 moments_of(uint32_t xy, uint32_t Wt) {
     return m;
 }
 
+
+// Bitonic sort of CAP = NTH*EPL keys, thread t holding elements t*EPL .. t*EPL+EPL-1 in registers.  Strides below EPL are
+// compare-exchanges inside a thread, strides below 64*EPL are lane exchanges (ds_bpermute, no memory, no barrier); only
+// strides that cross a wave go through the LDS buffer.  Always sorts all CAP slots (unused ones hold ~0).
+template <int NTH, int EPL, int K, int J>
+__device__ __forceinline__ void sort_stage(unsigned long long (&k)[EPL], unsigned long long *buf) {
+    const int t = threadIdx.x;
+    if constexpr (J < EPL) {
+#pragma unroll
+        for (int e = 0; e < EPL; e++) {
+            if ((e & J) == 0) {
+                const int i = t * EPL + e;
+                const bool up = (i & K) == 0;
+                unsigned long long a = k[e], b = k[e | J];
+                const bool sw = (a > b) == up;
+                k[e] = sw ? b : a; k[e | J] = sw ? a : b;
+            }
+        }
+    } else {
+        constexpr int TJ = J / EPL;       // partner thread = t ^ TJ
+        const bool lower = (t & TJ) == 0; // this thread holds the smaller index of every pair
+        if constexpr (TJ < 64) {
+#pragma unroll
+            for (int e = 0; e < EPL; e++) {
+                const int i = t * EPL + e;
+                const bool up = (i & K) == 0;
+                unsigned long long mine = k[e];
+                unsigned long long other = __shfl_xor(mine, TJ, 64);
+                const bool take_min = (lower == up);
+                k[e] = take_min ? (mine < other ? mine : other) : (mine > other ? mine : other);
+            }
+        } else {
+            __syncthreads();
+#pragma unroll
+            for (int e = 0; e < EPL; e++) buf[t * EPL + e] = k[e];
+            __syncthreads();
+#pragma unroll
+            for (int e = 0; e < EPL; e++) {
+                const int i = t * EPL + e;
+                const bool up = (i & K) == 0;
+                unsigned long long mine = k[e];
+                unsigned long long other = buf[(t ^ TJ) * EPL + e];
+                const bool take_min = (lower == up);
+                k[e] = take_min ? (mine < other ? mine : other) : (mine > other ? mine : other);
+            }
+        }
+    }
+}
+template <int NTH, int EPL, int K, int J>
+struct SortJ {
+    __device__ __forceinline__ static void run(unsigned long long (&k)[EPL], unsigned long long *buf) {
+        sort_stage<NTH, EPL, K, J>(k, buf);
+        if constexpr (J > 1) SortJ<NTH, EPL, K, J / 2>::run(k, buf);
+    }
+};
+template <int NTH, int EPL, int K>
+struct SortK {
+    __device__ __forceinline__ static void run(unsigned long long (&k)[EPL], unsigned long long *buf) {
+        SortJ<NTH, EPL, K, K / 2>::run(k, buf);
+        if constexpr (K < NTH * EPL) SortK<NTH, EPL, K * 2>::run(k, buf);
+    }
+};
+template <int NTH, int EPL>
+__device__ __forceinline__ void sort_registers(unsigned long long (&k)[EPL], unsigned long long *buf) {
+    SortK<NTH, EPL, 2>::run(k, buf);
+}
+
+// keys of one cluster -> registers (thread t owns slots t*EPL .. t*EPL+EPL-1 of an NTH*EPL array), border-direction sum,
+// sort, write back.  Returns dot (valid on every thread).  `raw` = staged 8-byte points in sKeys[0..sz0).
+template <int NTH, int EPL>
+__device__ __forceinline__ long long keys_sort(unsigned long long *sKeys, long long *sScratch, int sz0, int xmin, int xmax, int ymin, int ymax,
+                                               int normal_ok, int reversed_ok) {
+    using B = Block<NTH>;
+    const int tid = threadIdx.x;
+    unsigned long long kreg[EPL];
+    long long dot = 0;
+#pragma unroll
+    for (int e = 0; e < EPL; e++) {
+        int i = tid * EPL + e;
+        unsigned long long key = ~0ull;
+        if (i < sz0) {
+            unsigned long long raw = sKeys[i];
+            int px = (int)(raw & 0xFFFF), py = (int)((raw >> 16) & 0xFFFF);
+            int pgx = (int)(signed char)((raw >> 32) & 0xFF), pgy = (int)(signed char)((raw >> 40) & 0xFF);
+            long long dx = 4ll * px - 2ll * (xmin + xmax) - 1;
+            long long dy = 4ll * py - 2ll * (ymin + ymax) + 1;
+            dot += dx * pgx + dy * pgy;
+            key = angle_key(px, py, xmin, xmax, ymin, ymax);
+        }
+        kreg[e] = key;
+    }
+    dot = B::reduce_add(dot, sScratch);
+    if ((dot < 0) ? reversed_ok : normal_ok) { // uniform: skip the sort when the border direction is rejected anyway
+        sort_registers<NTH, EPL>(kreg, sKeys);
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < EPL; e++) sKeys[tid * EPL + e] = kreg[e];
+    }
+    return dot;
+}
+
 // NTH threads per cluster, up to CAP points, chunks of CH points; MLDS: the maxima list fits in LDS
 template <int NTH, int CAP, int CH, bool MLDS, int WPS>
 __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(WPS, 8))) void k_fit(FitArgs a) {
@@ -346,23 +451,23 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(WPS, 8))) v
     uint16_t *sW = reinterpret_cast<uint16_t *>(sKeys) + 2 * CAP; // bytes [4*CAP, 6*CAP)
     for (int i = tid; i < 495; i += NTH) sCombos[i] = g_combos[i]; // once per workgroup; the loop below starts with a barrier
 
-    for (;;) {
+    // static striding over the class work list: no dequeue atomics (520 k clusters per batch through one counter cost more
+    // than any phase of the fit); clusters of one class are similar enough for the load to even out over ~100 per workgroup
+    const uint32_t n_work = *a.list_count;
+    for (uint32_t work = blockIdx.x; work < n_work; work += gridDim.x) {
         __syncthreads();
-        if (tid == 0) sWork = atomicAdd(a.head, 1u);
-        __syncthreads();
-        const uint32_t work = sWork;
-        if (work >= *a.list_count) break; // every wave of every workgroup reaches this exit
         const uint32_t item = a.list[work];
         const int frame = (int)(item >> 20), ci = (int)(item & 0xFFFFFu);
         const ck_cluster_t cl = ws.d_clusters[(size_t)frame * ws.cluster_cap + ci];
         ck_cluster_point_t *pts = ws.d_points + (size_t)frame * ws.point_cap + cl.start;
         const int sz0 = (int)cl.count;
-        const uint8_t *qim = a.qim + (size_t)frame * a.qpitch;
+        const uint16_t *wq = a.wimg + (size_t)frame * a.qw * a.qh;
         const uint8_t *im = a.im + (size_t)frame * a.pitch;
         if (sz0 > CAP) continue; // cannot happen: the class lists are built from the counts
         PROF_DECL;
         PROF(15);
 
+        if (a.stop_after == 0) continue;
         // ---- 1. bounding box + border direction ----------------------------------------------------------
         int xmin = 1 << 30, xmax = -(1 << 30), ymin = 1 << 30, ymax = -(1 << 30);
         {   // one coalesced pass; all of a lane's loads are issued before the first use (one memory round trip, not EPL)
@@ -396,41 +501,28 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(WPS, 8))) v
         xmin = B::reduce_min(xmin, iscr); xmax = -B::reduce_min(-xmax, iscr);
         ymin = B::reduce_min(ymin, iscr); ymax = -B::reduce_min(-ymax, iscr);
         if ((xmax - xmin) * (ymax - ymin) < a.min_tag_width) continue;
-        long long dot = 0;
-        int n2 = 1;
-        while (n2 < sz0) n2 <<= 1;
-        for (int i = tid; i < n2; i += NTH) { // each thread rewrites only the entries it staged itself
-            unsigned long long key = ~0ull;
-            if (i < sz0) {
-                unsigned long long raw = sKeys[i];
-                int px = (int)(raw & 0xFFFF), py = (int)((raw >> 16) & 0xFFFF);
-                int pgx = (int)(signed char)((raw >> 32) & 0xFF), pgy = (int)(signed char)((raw >> 40) & 0xFF);
-                long long dx = 4ll * px - 2ll * (xmin + xmax) - 1;
-                long long dy = 4ll * py - 2ll * (ymin + ymax) + 1;
-                dot += dx * pgx + dy * pgy;
-                key = angle_key(px, py, xmin, xmax, ymin, ymax);
-            }
-            sKeys[i] = key;
+        long long dot;
+        {   // pick the keys-per-thread count that matches the cluster (padded to a power of two, at least one per thread)
+            constexpr int EPLS = CAP / NTH;
+            int n2 = NTH;
+            while (n2 < sz0) n2 <<= 1;
+            const int epl = n2 / NTH;
+            __syncthreads(); // raw points staged by other threads
+            if (EPLS >= 32 && epl == 32) dot = keys_sort<NTH, (EPLS >= 32 ? 32 : 1)>(sKeys, sScratch, sz0, xmin, xmax, ymin, ymax, a.normal_ok, a.reversed_ok);
+            else if (EPLS >= 16 && epl == 16) dot = keys_sort<NTH, (EPLS >= 16 ? 16 : 1)>(sKeys, sScratch, sz0, xmin, xmax, ymin, ymax, a.normal_ok, a.reversed_ok);
+            else if (EPLS >= 8 && epl == 8) dot = keys_sort<NTH, (EPLS >= 8 ? 8 : 1)>(sKeys, sScratch, sz0, xmin, xmax, ymin, ymax, a.normal_ok, a.reversed_ok);
+            else if (EPLS >= 4 && epl == 4) dot = keys_sort<NTH, (EPLS >= 4 ? 4 : 1)>(sKeys, sScratch, sz0, xmin, xmax, ymin, ymax, a.normal_ok, a.reversed_ok);
+            else if (EPLS >= 2 && epl == 2) dot = keys_sort<NTH, (EPLS >= 2 ? 2 : 1)>(sKeys, sScratch, sz0, xmin, xmax, ymin, ymax, a.normal_ok, a.reversed_ok);
+            else dot = keys_sort<NTH, 1>(sKeys, sScratch, sz0, xmin, xmax, ymin, ymax, a.normal_ok, a.reversed_ok);
         }
-        dot = B::reduce_add(dot, sScratch);
         const int reversed = dot < 0;
         PROF(0);
         if (reversed && !a.reversed_ok) continue;
         if (!reversed && !a.normal_ok) continue;
+        if (a.stop_after == 1) continue;
 
-        // ---- 2. bitonic sort, duplicate removal, packing to (x,y) ---------------------------------------------
+        // ---- 2. duplicate removal, packing to (x,y) ----------------------------------------------------------------
         __syncthreads();
-        for (int k = 2; k <= n2; k <<= 1)
-            for (int j = k >> 1; j > 0; j >>= 1) {
-                for (int t = tid; t < (n2 >> 1); t += NTH) {
-                    int i = 2 * t - (t & (j - 1));
-                    int l = i + j;
-                    unsigned long long ka = sKeys[i], kb = sKeys[l];
-                    bool up = (i & k) == 0;
-                    if ((ka > kb) == up) { sKeys[i] = kb; sKeys[l] = ka; }
-                }
-                __syncthreads();
-            }
         PROF(1);
         // compaction writes u32 (x<<13|y) at index <= i into the first half of the same buffer: a round only
         // overwrites bytes below 4*(base+NTH) while unread keys start at byte 8*(base+NTH)
@@ -452,42 +544,35 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(WPS, 8))) v
         const int ksz = sz / 12 < 20 ? sz / 12 : 20;
         if (ksz < 2) continue;
 
+        if (a.stop_after == 2) continue;
         // ---- 3. gradient weights: one image gather per point, all in flight together ---------------------------------
         {
             constexpr int EPL = CAP / NTH;
             if constexpr (EPL <= 16) { // issue every gather of the lane, then compute: one round trip
-                uint8_t g[EPL][4];
-                bool inb[EPL];
+                uint16_t g[EPL];
 #pragma unroll
                 for (int e = 0; e < EPL; e++) {
                     int i = tid + e * NTH;
-                    inb[e] = false;
-                    g[e][0] = g[e][1] = g[e][2] = g[e][3] = 0;
+                    g[e] = 1;
                     if (i < sz) {
                         uint32_t xy = sXY[i];
                         int x = (int)(xy >> 13), y = (int)(xy & 0x1FFF);
                         int ix = (x + 1) >> 1, iy = (y + 1) >> 1;
-                        if (ix > 0 && ix + 1 < a.qw && iy > 0 && iy + 1 < a.qh) {
-                            const uint8_t *row = qim + (size_t)iy * a.qstride + ix;
-                            inb[e] = true;
-                            g[e][0] = row[1]; g[e][1] = row[-1]; g[e][2] = row[a.qstride]; g[e][3] = row[-a.qstride];
-                        }
+                        if (ix >= 0 && ix < a.qw && iy >= 0 && iy < a.qh) g[e] = wq[(size_t)iy * a.qw + ix];
                     }
                 }
 #pragma unroll
                 for (int e = 0; e < EPL; e++) {
                     int i = tid + e * NTH;
-                    if (i < sz) {
-                        uint32_t W = 1;
-                        if (inb[e]) {
-                            int gx = (int)g[e][0] - (int)g[e][1], gy = (int)g[e][2] - (int)g[e][3];
-                            W = isqrt_u32((uint32_t)(gx * gx + gy * gy)) + 1;
-                        }
-                        sW[i] = (uint16_t)W;
-                    }
+                    if (i < sz) sW[i] = g[e];
                 }
             } else {
-                for (int i = tid; i < sz; i += NTH) sW[i] = (uint16_t)point_weight(a, qim, sXY[i]);
+                for (int i = tid; i < sz; i += NTH) {
+                    uint32_t xy = sXY[i];
+                    int x = (int)(xy >> 13), y = (int)(xy & 0x1FFF);
+                    int ix = (x + 1) >> 1, iy = (y + 1) >> 1;
+                    sW[i] = (ix >= 0 && ix < a.qw && iy >= 0 && iy < a.qh) ? wq[(size_t)iy * a.qw + ix] : (uint16_t)1;
+                }
             }
         }
         // the cluster's slice of the point array is dead from here on; the large class keeps its maxima there
@@ -498,6 +583,7 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(WPS, 8))) v
         __syncthreads();
 
         PROF(3);
+        if (a.stop_after == 3) continue;
         // ---- 4. chunk loop: moment prefix sums, windowed error, smoothing, maxima ----------------------------------------
         const int nch = (sz + CH - 1) / CH;
         for (int c = 0; c < nch; c++) {
@@ -564,6 +650,7 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(WPS, 8))) v
         auto mval = [&](int i) -> double { return MLDS ? sMaxVal[i] : gval[i]; };
         auto midx = [&](int i) -> int { return MLDS ? (int)sMaxIdx[i] : (int)gidx[i]; };
 
+        if (a.stop_after == 4) continue;
         // ---- 5a. threshold = (max_nmaxima+1)-th largest smoothed error ---------------------------------------------------
         double thr = 0.0;
         bool use_thr = false;
@@ -613,6 +700,7 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(WPS, 8))) v
         __syncthreads();
 
         PROF(6);
+        if (a.stop_after == 5) continue;
         // ---- 5b. moment prefix sums at the selected maxima (chunk totals + partial sums inside the chunk) ------------------
         for (int s = 0; s < nsel; s++) {
             const int gi = sSelIdx[s];
@@ -642,6 +730,7 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(WPS, 8))) v
         };
 
         PROF(7);
+        if (a.stop_after == 6) continue;
         // ---- 5c. one line fit per ordered pair of maxima; the 4-subset search is then table lookups ------------------------
         PairFit *sF = reinterpret_cast<PairFit *>(&sP[0][0]);
         for (int pr = tid; pr < nsel * nsel; pr += NTH) {
@@ -700,6 +789,7 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(WPS, 8))) v
         if (best == HUGE_VAL) continue;
         if (best / (double)sz >= a.max_mse) continue;
 
+        if (a.stop_after == 7) continue;
         // ---- 5d. lines, corners, geometric checks (one lane; sequential like the oracle) ---------------------------------------
         if (tid == 0) {
             int sel[4] = {(bestc >> 12) & 15, (bestc >> 8) & 15, (bestc >> 4) & 15, bestc & 15};
@@ -876,6 +966,25 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(WPS, 8))) v
     }
 }
 
+// Gradient-magnitude weights of a whole batch in one streaming pass (1 B read, 2 B written per pixel): the fitter then needs
+// ONE 2-byte gather per contour point instead of four byte gathers.
+__global__ __launch_bounds__(256) void k_weight_image(const uint8_t *__restrict__ qim, size_t qpitch, int qstride, int qw, int qh,
+                                                      uint16_t *__restrict__ wimg, size_t total) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    size_t npix = (size_t)qw * qh;
+    size_t fr = i / npix, rem = i - fr * npix;
+    int iy = (int)(rem / qw), ix = (int)(rem - (size_t)iy * qw);
+    uint32_t W = 1;
+    if (ix > 0 && ix + 1 < qw && iy > 0 && iy + 1 < qh) {
+        const uint8_t *row = qim + fr * qpitch + (size_t)iy * qstride + ix;
+        int gx = (int)row[1] - (int)row[-1];
+        int gy = (int)row[qstride] - (int)row[-qstride];
+        W = isqrt_u32((uint32_t)(gx * gx + gy * gy)) + 1;
+    }
+    wimg[i] = (uint16_t)W;
+}
+
 // builds the three per-size-class work lists from the cluster tables
 __global__ __launch_bounds__(256) void k_classify(ck_stage_ws ws, int n, uint32_t *lists, uint32_t *list_counts, int list_cap) {
     const int frame = blockIdx.y;
@@ -937,6 +1046,12 @@ int ck_launch_fit_quads(ck_handle *h, const uint8_t *qframes, int qstride, size_
     hipLaunchKernelGGL(k_clamp_counts, dim3(1), dim3(64), 0, h->stream, list_counts, list_cap, ws, 0);
     FitArgs a;
     a.qim = qframes; a.qw = h->qw; a.qh = h->qh; a.qstride = qstride; a.qpitch = qpitch;
+    a.wimg = ws.d_wimg;
+    {
+        size_t total = h->npix * (size_t)n;
+        hipLaunchKernelGGL(k_weight_image, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->stream, qframes, qpitch, qstride, h->qw, h->qh,
+                           ws.d_wimg, total);
+    }
     a.im = frames; a.w = h->w; a.h = h->h; a.stride = stride; a.pitch = pitch;
     a.decimate = h->cfg.quad_decimate; a.refine = h->cfg.refine_edges; a.max_nmaxima = h->cfg.max_nmaxima;
     a.cos_critical = h->cfg.cos_critical_rad; a.max_mse = h->cfg.max_line_fit_mse;
@@ -949,6 +1064,7 @@ int ck_launch_fit_quads(ck_handle *h, const uint8_t *qframes, int qstride, size_
     a.min_tag_width /= h->cfg.quad_decimate;
     if (a.min_tag_width < 3) a.min_tag_width = 3;
     a.ws = ws;
+    { const char *e = getenv("CK_FIT_STOP_AFTER"); a.stop_after = e ? atoi(e) : 99; }
     {
         static bool combos_ready = false; // process-wide table, written once
         if (!combos_ready) {
@@ -964,7 +1080,7 @@ int ck_launch_fit_quads(ck_handle *h, const uint8_t *qframes, int qstride, size_
     }
     int cus = 256;
     a.list = lists; a.list_count = list_counts; a.head = heads;
-    hipLaunchKernelGGL((k_fit<64, 512, 64, true, 4>), dim3((unsigned)(cus * 12)), dim3(64), 0, h->stream, a);
+    hipLaunchKernelGGL((k_fit<64, 512, 64, true, 4>), dim3((unsigned)(cus * 8)), dim3(64), 0, h->stream, a);
     a.list = lists + list_cap; a.list_count = list_counts + 1; a.head = heads + 1;
     hipLaunchKernelGGL((k_fit<256, 4096, 256, true, 2>), dim3((unsigned)(cus * 2)), dim3(256), 0, h->stream, a);
     a.list = lists + 2 * (size_t)list_cap; a.list_count = list_counts + 2; a.head = heads + 2;

@@ -1,0 +1,5 @@
+#!/bin/bash
+# cumulative cost of the k_fit phases: run the pipeline with every cluster stopped after phase k
+for k in 0 1 2 3 4 5 6 7 99; do
+  CK_FIT_STOP_AFTER=$k python tools/bench_detect.py 1280 800 256 3 1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('stop_after', $k, 'quads_ms', d['quads'])"
+done
