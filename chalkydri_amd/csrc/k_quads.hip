@@ -68,12 +68,12 @@ __device__ __forceinline__ uint32_t isqrt_u32(uint32_t v) {
 
 // line fit from a moment sum over N points (half-pixel units) — mirrors fit_line() of the oracle exactly
 __device__ __forceinline__ void fit_line_m(const M6 &m, int N, double *lineparm, double *err, double *mse) {
-    double dW = (double)m.W;
-    double Ex = (0.5 * (double)m.Mx) / dW;
-    double Ey = (0.5 * (double)m.My) / dW;
-    double Cxx = (0.25 * (double)m.Mxx) / dW - Ex * Ex;
-    double Cxy = (0.25 * (double)m.Mxy) / dW - Ex * Ey;
-    double Cyy = (0.25 * (double)m.Myy) / dW - Ey * Ey;
+    double inv = 1.0 / (double)m.W; // one reciprocal, five products — same operations as the oracle
+    double Ex = (0.5 * (double)m.Mx) * inv;
+    double Ey = (0.5 * (double)m.My) * inv;
+    double Cxx = (0.25 * (double)m.Mxx) * inv - Ex * Ex;
+    double Cxy = (0.25 * (double)m.Mxy) * inv - Ex * Ey;
+    double Cyy = (0.25 * (double)m.Myy) * inv - Ey * Ey;
     double d = Cxx - Cyy;
     double q = 4.0 * Cxy;
     double disc = sqrt(d * d + q * Cxy);
@@ -423,14 +423,15 @@ template <int NTH, int CAP, int CH, bool MLDS, int WPS>
 __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(WPS, 8))) void k_fit(FitArgs a) {
     using B = Block<NTH>;
     constexpr int SL = CH + 2 * HALO;
-    constexpr int NCH = CAP / CH;
+    constexpr int G = (CAP <= 4096) ? 64 : CH;   // granularity of the cumulative-moment table
+    constexpr int NG = CAP / G;
     constexpr int MAXM = MLDS ? CAP / 2 : 1;
     // sKeys holds the 64-bit sort keys; after duplicate removal its first half is reused for the packed
     // coordinates (x<<13|y, u32) and the third quarter for the u16 weights.
     __shared__ unsigned long long sKeys[CAP];
     __shared__ long long sP[6][SL];          // inclusive moment prefix sums over the current span; later the pair-fit table
     __shared__ double sErr[SL], sSm[SL];
-    __shared__ long long sTot[NCH + 1][6];   // cumulative moments at chunk ends
+    __shared__ long long sTot[NG + 1][6];    // cumulative moments of the first k*G sorted points
     __shared__ long long sScratch[6 * (NTH / 64) + 2];
     __shared__ double sMaxVal[MAXM];
     __shared__ uint16_t sMaxIdx[MAXM];
@@ -617,7 +618,14 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(WPS, 8))) v
                 }
             }
             __syncthreads();
-            if (tid < 6) sTot[c + 1][tid] = sTot[c][tid] + sP[tid][HALO + chn - 1] - sP[tid][HALO - 1];
+            {   // cumulative moments at every G-th point of this chunk (and at its end, which closes the cluster's last block)
+                constexpr int BPC = CH / G;
+                if (tid < 6 * BPC) {
+                    int q = tid % 6, bb = tid / 6;
+                    int last = min((bb + 1) * G, chn);      // points of this chunk covered through block bb
+                    if (bb * G < chn) sTot[c * BPC + bb + 1][q] = sTot[c * BPC][q] + sP[q][HALO + last - 1] - sP[q][HALO - 1];
+                }
+            }
             for (int j = HALO - 4 + tid; j < HALO + chn + 4; j += NTH) {
                 int hi = j + ksz, lo = j - ksz - 1;
                 M6 m = {sP[0][hi], sP[1][hi], sP[2][hi], sP[3][hi], sP[4][hi], sP[5][hi]};
@@ -659,26 +667,33 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(WPS, 8))) v
             double cur = HUGE_VAL;
             int remaining = a.max_nmaxima + 1;
             for (int round = 0; round <= a.max_nmaxima; round++) {
+                // largest value below `cur` and how many times it occurs, in one pass and one reduction
                 double m = -HUGE_VAL;
-                for (int i = tid; i < nmax_all; i += NTH) { double v = mval(i); if (v < cur && v > m) m = v; }
+                int cnt = 0;
+                for (int i = tid; i < nmax_all; i += NTH) {
+                    double v = mval(i);
+                    if (v < cur) { if (v > m) { m = v; cnt = 1; } else if (v == m) cnt++; }
+                }
 #pragma unroll
-                for (int d = 32; d >= 1; d >>= 1) { double o = __shfl_xor(m, d, 64); if (o > m) m = o; }
+                for (int d = 32; d >= 1; d >>= 1) {
+                    double om = __shfl_xor(m, d, 64);
+                    int oc = __shfl_xor(cnt, d, 64);
+                    if (om > m) { m = om; cnt = oc; } else if (om == m) cnt += oc;
+                }
                 if (NTH > 64) {
-                    if ((tid & 63) == 0) sRed[tid >> 6] = m;
+                    if ((tid & 63) == 0) { sRed[tid >> 6] = m; sRedI[tid >> 6] = cnt; }
                     __syncthreads();
-                    m = sRed[0];
-                    for (int k = 1; k < NTH / 64; k++) if (sRed[k] > m) m = sRed[k];
+                    m = sRed[0]; cnt = sRedI[0];
+                    for (int k = 1; k < NTH / 64; k++) {
+                        if (sRed[k] > m) { m = sRed[k]; cnt = sRedI[k]; } else if (sRed[k] == m) cnt += sRedI[k];
+                    }
                     __syncthreads();
                 }
-                long long cnt = 0;
-                for (int i = tid; i < nmax_all; i += NTH) cnt += (mval(i) == m);
-                cnt = B::reduce_add(cnt, sScratch);
                 if (cnt >= remaining) { thr = m; break; }
-                remaining -= (int)cnt;
+                remaining -= cnt;
                 cur = m;
             }
         }
-        PROF(5);
         // survivors (at most max_nmaxima of them), then put them in increasing index order
         __syncthreads();
         if (tid == 0) sNmax = 0;
@@ -702,24 +717,43 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(WPS, 8))) v
         PROF(6);
         if (a.stop_after == 5) continue;
         // ---- 5b. moment prefix sums at the selected maxima (chunk totals + partial sums inside the chunk) ------------------
-        for (int s = 0; s < nsel; s++) {
-            const int gi = sSelIdx[s];
-            const int c = gi / CH, cb = c * CH;
-            M6 part = m6_zero();
-            for (int i = cb + tid; i <= gi; i += NTH) part = m6_add(part, moments_of(sXY[i], sW[i]));
-            long long pv[6] = {part.Mx, part.My, part.Mxx, part.Mxy, part.Myy, part.W};
-            B::reduce_add6(pv, sScratch);
-            if (tid == 0)
+        if constexpr (G == 64) {
+            // one wave per selected maximum: at most 64 points beyond the table entry, summed with shuffles only
+            const int lane = tid & 63, wv = tid >> 6;
+            for (int s = wv; s < nsel; s += NTH / 64) {
+                const int gi = sSelIdx[s];
+                const int blk = gi >> 6, i = (blk << 6) + lane;
+                M6 m = m6_zero();
+                if (i <= gi) m = moments_of(sXY[i], sW[i]);
+                long long pv[6] = {m.Mx, m.My, m.Mxx, m.Mxy, m.Myy, m.W};
 #pragma unroll
-                for (int q = 0; q < 6; q++) sSelI[s][q] = sTot[c][q] + pv[q];
-            if (tid == 0) {
-                M6 self = moments_of(sXY[gi], sW[gi]);
-                long long sv[6] = {self.Mx, self.My, self.Mxx, self.Mxy, self.Myy, self.W};
-                for (int q = 0; q < 6; q++) sSelE[s][q] = sSelI[s][q] - sv[q];
+                for (int q = 0; q < 6; q++)
+#pragma unroll
+                    for (int d = 32; d >= 1; d >>= 1) pv[q] += __shfl_xor(pv[q], d, 64);
+                if (lane == 0) {
+                    M6 self = moments_of(sXY[gi], sW[gi]);
+                    long long sv[6] = {self.Mx, self.My, self.Mxx, self.Mxy, self.Myy, self.W};
+                    for (int q = 0; q < 6; q++) { sSelI[s][q] = sTot[blk][q] + pv[q]; sSelE[s][q] = sSelI[s][q] - sv[q]; }
+                }
+            }
+        } else {
+            for (int s = 0; s < nsel; s++) {
+                const int gi = sSelIdx[s];
+                const int c = gi / G, cb = c * G;
+                M6 part = m6_zero();
+                for (int i = cb + tid; i <= gi; i += NTH) part = m6_add(part, moments_of(sXY[i], sW[i]));
+                long long pv[6] = {part.Mx, part.My, part.Mxx, part.Mxy, part.Myy, part.W};
+                B::reduce_add6(pv, sScratch);
+                if (tid == 0) {
+                    M6 self = moments_of(sXY[gi], sW[gi]);
+                    long long sv[6] = {self.Mx, self.My, self.Mxx, self.Mxy, self.Myy, self.W};
+                    for (int q = 0; q < 6; q++) { sSelI[s][q] = sTot[c][q] + pv[q]; sSelE[s][q] = sSelI[s][q] - sv[q]; }
+                }
             }
         }
         __syncthreads();
-        const M6 total = {sTot[nch][0], sTot[nch][1], sTot[nch][2], sTot[nch][3], sTot[nch][4], sTot[nch][5]};
+        const int ntot = (sz + G - 1) / G;
+        const M6 total = {sTot[ntot][0], sTot[ntot][1], sTot[ntot][2], sTot[ntot][3], sTot[ntot][4], sTot[ntot][5]};
         auto rangeM = [&](int sa, int sb, int *N) { // points from maximum sa to maximum sb inclusive, going forward
             M6 I = {sSelI[sb][0], sSelI[sb][1], sSelI[sb][2], sSelI[sb][3], sSelI[sb][4], sSelI[sb][5]};
             M6 E = {sSelE[sa][0], sSelE[sa][1], sSelE[sa][2], sSelE[sa][3], sSelE[sa][4], sSelE[sa][5]};

@@ -14,7 +14,7 @@
  *   - points of a cluster are ordered by an exact 60-bit angular key (octant + 30-bit ratio + x + y), not by
  *     a float slope;
  *   - line-fit moments are int64 prefix sums over half-pixel coordinates with integer weights
- *     W = isqrt(gx^2+gy^2)+1 (AprilTag-3 uses double sums with W = sqrt(..)+1);
+ *     W = isqrt(gx^2+gy^2)+1 (AprilTag-3 uses double sums with W = sqrt(..)+1); the line fit divides once (reciprocal) and multiplies;
  *   - the edge-refinement line normal uses the closed-form eigenvector (AprilTag-3: atan2f/cosf/sinf);
  *   - codebook lookup is a brute-force minimum-Hamming search over ids x 4 rotations (AprilTag-3: hash table);
  *   - duplicates are detections of one (family,id) whose centre lies inside the other's quad.
@@ -237,12 +237,13 @@ static void fit_line(const lfps_t *lf, int sz, int i0, int i1, double *lineparm,
         N = sz - i0 + i1 + 1;
     }
     /* moments are in half-pixel units: x_px = X/2 */
-    double dW = (double)W;
-    double Ex = (0.5 * (double)Mx) / dW;
-    double Ey = (0.5 * (double)My) / dW;
-    double Cxx = (0.25 * (double)Mxx) / dW - Ex * Ex;
-    double Cxy = (0.25 * (double)Mxy) / dW - Ex * Ey;
-    double Cyy = (0.25 * (double)Myy) / dW - Ey * Ey;
+    /* one reciprocal, five products (a design choice shared by the HIP kernel; AprilTag-3 divides five times) */
+    double inv = 1.0 / (double)W;
+    double Ex = (0.5 * (double)Mx) * inv;
+    double Ey = (0.5 * (double)My) * inv;
+    double Cxx = (0.25 * (double)Mxx) * inv - Ex * Ex;
+    double Cxy = (0.25 * (double)Mxy) * inv - Ex * Ey;
+    double Cyy = (0.25 * (double)Myy) * inv - Ey * Ey;
     double d = Cxx - Cyy;
     double q = 4.0 * Cxy;
     double disc = sqrt(d * d + q * Cxy);
