@@ -16,6 +16,8 @@
 //   k_roots_a/b  flatten the entries of ring-touching roots and accumulate their sizes into csize[].
 // No full-frame relabel pass exists: interior components are final when k_tile writes them; ring-touching
 // ones are resolved by consumers with one extra hop (label word format in ck_internal.h).
+#include <stdlib.h>
+
 #include "ck_internal.h"
 
 namespace {
@@ -37,7 +39,7 @@ constexpr int UNION_BYTES = TH * TW * 2;
 constexpr int OFF_MASK = OFF_UNION + UNION_BYTES;          // u64[TH][NSEG][2]
 constexpr int LDS_BYTES = OFF_MASK + TH * NSEG * 2 * 8;
 static_assert(OFF_THR + 1024 <= OFF_UNION + UNION_BYTES, "phase A scratch must fit in the size array");
-static_assert(LDS_BYTES <= 53248, "keep three workgroups per CU");
+static_assert(LDS_BYTES + 2 * (TW + TH) * 2 + 64 <= 53248, "keep three workgroups per CU");
 static_assert(TH * NSEG * 2 == KNT, "k_tile thread mapping: colour x row x segment");
 
 // find with path halving.  Plain stores race with the atomicMin hooks of lds_union, but every value ever
@@ -60,10 +62,21 @@ __device__ __forceinline__ uint32_t lds_find_ro(const volatile uint32_t *p, uint
     return a;
 }
 // root = smaller index
+// two halving finds walked in lockstep: both chains have a read in flight at every step (the kernel is bound by LDS
+// round-trip latency, not LDS bandwidth)
+__device__ __forceinline__ void lds_find2(volatile uint32_t *p, uint32_t &a, uint32_t &b) {
+    for (;;) {
+        uint32_t na = p[a], nb = p[b];
+        bool da = (na == a), db = (nb == b);
+        if (da && db) return;
+        uint32_t ga = p[na], gb = p[nb];
+        if (!da) { if (ga != na) p[a] = ga; a = ga; }
+        if (!db) { if (gb != nb) p[b] = gb; b = gb; }
+    }
+}
 __device__ __forceinline__ void lds_union(uint32_t *p, uint32_t a, uint32_t b) {
     for (;;) {
-        a = lds_find(p, a);
-        b = lds_find(p, b);
+        lds_find2(p, a, b);
         if (a == b) return;
         if (a < b) { uint32_t t = a; a = b; b = t; }
         uint32_t old = atomicMin(&p[a], b);
@@ -105,9 +118,13 @@ __global__ __launch_bounds__(KNT) void k_tile(const uint8_t *__restrict__ frames
                                              int w, int h, int tiles_x, int tiles_y, int min_diff, int min_comp,
                                              uint8_t *__restrict__ thresh, uint32_t *__restrict__ labels,
                                              ck_border_root *__restrict__ broots,
-                                             uint32_t *__restrict__ broot_count, int broot_cap) {
+                                             uint32_t *__restrict__ broot_count, int broot_cap, int stop_after) {
     __shared__ __attribute__((aligned(16))) uint8_t lds[LDS_BYTES];
+    constexpr int RLIST = 2 * (TW + TH);          // a tile has at most this many ring-touching components
+    __shared__ uint16_t sRootList[RLIST];         // tile-local node index of every ring-touching root
+    __shared__ uint32_t sRootCnt;
     const int tid = threadIdx.x;
+    if (tid == 0) sRootCnt = 0;                    // ordered before its first use by the barriers below
     const int tiles = tiles_x * tiles_y;
     const int frame = blockIdx.x / tiles, tile = blockIdx.x - frame * tiles;
     const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
@@ -146,6 +163,7 @@ __global__ __launch_bounds__(KNT) void k_tile(const uint8_t *__restrict__ frames
     __syncthreads();
     TPROF(0);
 
+    if (stop_after == 0) return; // diagnostics (CK_TILE_STOP_AFTER)
     // ---- P1: min/max of every 4x4 tile of the staged region -------------------------------------------
     uint16_t *minmax = reinterpret_cast<uint16_t *>(lds + OFF_MINMAX);
     const int w4 = w >> 2, h4 = h >> 2;
@@ -188,6 +206,7 @@ __global__ __launch_bounds__(KNT) void k_tile(const uint8_t *__restrict__ frames
     __syncthreads();
     TPROF(1);
 
+    if (stop_after == 1) return; // diagnostics (CK_TILE_STOP_AFTER)
     // ---- P3: threshold 16 pixels per item, write them, build the per-row colour masks ----------------------
     uint16_t *mask16 = reinterpret_cast<uint16_t *>(lds + OFF_MASK); // [r][seg][colour][piece]
     for (int item = tid; item < TH * 8; item += KNT) {
@@ -228,6 +247,7 @@ __global__ __launch_bounds__(KNT) void k_tile(const uint8_t *__restrict__ frames
     __syncthreads();
     TPROF(2);
 
+    if (stop_after == 2) return; // diagnostics (CK_TILE_STOP_AFTER)
     // ---- P4: the image scratch is dead; it becomes the size array ---------------------------------------------
     for (int i = tid * 16; i < UNION_BYTES; i += KNT * 16) *reinterpret_cast<uint4 *>(lds + OFF_SIZE + i) = make_uint4(0, 0, 0, 0);
 
@@ -283,6 +303,7 @@ __global__ __launch_bounds__(KNT) void k_tile(const uint8_t *__restrict__ frames
     auto up_right_node = [&](int i) -> uint32_t { // bit 0 of the segment on the right always starts a run
         return (i < 63) ? base - TW + (uint32_t)run_start(Su, i + 1) : base - TW + 64;
     };
+    if (stop_after == 3) return; // diagnostics (CK_TILE_STOP_AFTER)
     // ---- P5a: every run adopts ONE earlier run as its parent with a plain store.  Only the owner writes the entry
     // and nothing reads parent[] in this phase, so no find and no atomic is needed for these links; the target always
     // has a smaller index, which keeps the forest invariant (parent <= self) the atomic phase relies on.
@@ -302,6 +323,7 @@ __global__ __launch_bounds__(KNT) void k_tile(const uint8_t *__restrict__ frames
         }
     }
     __syncthreads();
+    if (stop_after == 4 || stop_after == 5) return; // diagnostics (CK_TILE_STOP_AFTER)
     // ---- P5b: the remaining links (a run touching a second, third ... earlier run) go through the atomic union
     if (hleft) lds_union(parent, base, left_node);
     while (Ev) {
@@ -322,41 +344,53 @@ __global__ __launch_bounds__(KNT) void k_tile(const uint8_t *__restrict__ frames
     __syncthreads();
     TPROF(3);
 
-    // ---- P6a: one halving find per run start shortens the chains the adopted parents left behind --------------------
-    {
-        uint64_t St = S;
-        while (St) {
-            int i = __builtin_ctzll(St);
-            St &= St - 1;
-            (void)lds_find(parent, base + i);
-        }
-    }
     __syncthreads(); // halving stores must land before the owners publish final roots
+    if (stop_after == 6) return; // diagnostics (CK_TILE_STOP_AFTER)
     // ---- P6: flatten run starts, accumulate sizes and ring flags at the roots ---------------------------------------
     uint32_t *size32 = reinterpret_cast<uint32_t *>(lds + OFF_SIZE);
     {
         const bool ring_row = (r == 0 && ty0 > 0) || (r == TH - 1 && ty0 + TH < h);
         uint64_t St = S;
-        while (St) {
-            int i = __builtin_ctzll(St);
-            St &= St - 1;
-            uint64_t rest = S & ~((2ull << i) - 1);          // starts above i in the whole segment
-            uint64_t above = rest ? (rest & (0ull - rest)) : 0ull; // lowest of them
-            uint64_t span = above ? (above - (1ull << i)) : (~0ull << i);
-            uint64_t run = M & span;
-            uint32_t node = base + i;
-            uint32_t root = lds_find_ro(parent, node);
-            parent[node] = root;
-            bool ring = ring_row || (s == 0 && tx0 > 0 && (run & 1ull)) ||
-                        (s == NSEG - 1 && tx0 + TW < w && (run >> 63));
-            uint32_t add = (uint32_t)__popcll(run) << (16 * (root & 1));
-            atomicAdd(&size32[root >> 1], add);
-            if (ring) atomicOr(&size32[root >> 1], 0x8000u << (16 * (root & 1)));
+        while (St) { // four runs per round: their root walks proceed in lockstep
+            uint32_t node[4], root[4], add[4];
+            bool ring[4], live[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                live[q] = St != 0;
+                node[q] = base; add[q] = 0; ring[q] = false;
+                if (live[q]) {
+                    int i = __builtin_ctzll(St);
+                    St &= St - 1;
+                    uint64_t rest = S & ~((2ull << i) - 1);          // starts above i in the whole segment
+                    uint64_t above = rest ? (rest & (0ull - rest)) : 0ull; // lowest of them
+                    uint64_t span = above ? (above - (1ull << i)) : (~0ull << i);
+                    uint64_t run = M & span;
+                    node[q] = base + i;
+                    add[q] = (uint32_t)__popcll(run);
+                    ring[q] = ring_row || (s == 0 && tx0 > 0 && (run & 1ull)) || (s == NSEG - 1 && tx0 + TW < w && (run >> 63));
+                }
+                root[q] = node[q];
+            }
+            const volatile uint32_t *vp = parent;
+            for (int it = 0; it < 8192; it++) {
+                uint32_t n0 = vp[root[0]], n1 = vp[root[1]], n2 = vp[root[2]], n3 = vp[root[3]];
+                if (n0 == root[0] && n1 == root[1] && n2 == root[2] && n3 == root[3]) break;
+                root[0] = n0; root[1] = n1; root[2] = n2; root[3] = n3;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                if (live[q]) {
+                    parent[node[q]] = root[q];
+                    uint32_t sh = 16 * (root[q] & 1);
+                    atomicAdd(&size32[root[q] >> 1], add[q] << sh);
+                    if (ring[q]) atomicOr(&size32[root[q] >> 1], 0x8000u << sh);
+                }
         }
     }
     __syncthreads();
     TPROF(4);
 
+    if (stop_after == 7) return; // diagnostics (CK_TILE_STOP_AFTER)
     // ---- P7: write label words (16 pixels per item) -------------------------------------------------------------------
     const uint16_t *size16 = reinterpret_cast<const uint16_t *>(lds + OFF_SIZE);
     for (int item = tid; item < TH * 8; item += KNT) {
@@ -388,48 +422,42 @@ __global__ __launch_bounds__(KNT) void k_tile(const uint8_t *__restrict__ frames
         for (int q = 0; q < 4; q++)
             if (gx + 4 * q < w)
                 *reinterpret_cast<uint4 *>(dst + 4 * q) = make_uint4(outw[4 * q], outw[4 * q + 1], outw[4 * q + 2], outw[4 * q + 3]);
-    }
-
-    TPROF(5);
-    // ---- P8: append ring-touching roots (wave ballot / prefix-sum compaction) ----------------------------------------
-    {
-        int cnt = 0;
-        uint64_t St = S;
-        while (St) {
-            int i = __builtin_ctzll(St);
-            St &= St - 1;
-            uint32_t node = base + i;
-            if (parent[node] == node && (size16[node] & 0x8000u)) cnt++;
-        }
-        // inclusive wave scan of cnt
-        int lane = tid & 63, incl = cnt;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            int o = __shfl_up(incl, d, 64);
-            if (lane >= d) incl += o;
-        }
-        int total = __shfl(incl, 63, 64);
-        uint32_t wbase = 0;
-        if (lane == 63 && total > 0) wbase = atomicAdd(&broot_count[frame], (uint32_t)total);
-        wbase = __shfl(wbase, 63, 64);
-        uint32_t pos = wbase + (uint32_t)(incl - cnt);
-        St = S;
-        while (St) {
-            int i = __builtin_ctzll(St);
-            St &= St - 1;
-            uint32_t node = base + i;
-            uint32_t sw = size16[node];
-            if (parent[node] == node && (sw & 0x8000u)) {
-                if (pos < (uint32_t)broot_cap) {
-                    ck_border_root br;
-                    br.root = (uint32_t)(ty0 + (int)(node / TW)) * (uint32_t)w + (uint32_t)(tx0 + (int)(node % TW));
-                    br.size = sw & 0x7FFFu;
-                    broots[(size_t)frame * broot_cap + pos] = br;
-                }
-                pos++;
+        // ring-touching roots that start in this 16-pixel chunk: a root is a run start whose label word points at itself
+        uint32_t chunk_bits = 0xFFFFu << (16 * piece);
+        uint64_t starts = (SW | SB) & (uint64_t)0xFFFF << (16 * piece);
+        (void)chunk_bits;
+        while (starts) {
+            int bit = __builtin_ctzll(starts);
+            starts &= starts - 1;
+            uint32_t word = outw[bit - 16 * piece];
+            uint32_t self = (uint32_t)gy * (uint32_t)w + (uint32_t)(tx0 + 64 * seg + bit);
+            if ((word & CK_LBL_BORDER) && (word & CK_LBL_IDX_MASK) == self) {
+                uint32_t node = sbase + (uint32_t)bit;
+                uint32_t pos = atomicAdd(&sRootCnt, 1u);
+                if (pos < RLIST) sRootList[pos] = (uint16_t)node;
             }
         }
     }
+    __syncthreads();
+    // ---- P8: one global reservation per tile for its ring-touching roots, then a coalesced copy of the list -----------
+    {
+        __shared__ uint32_t sRootBase;
+        uint32_t cnt = min(sRootCnt, (uint32_t)RLIST);
+        if (tid == 0 && cnt) sRootBase = atomicAdd(&broot_count[frame], cnt);
+        __syncthreads();
+        for (uint32_t i = tid; i < cnt; i += KNT) {
+            uint32_t pos = sRootBase + i;
+            if (pos < (uint32_t)broot_cap) {
+                uint32_t node = sRootList[i];
+                ck_border_root br;
+                br.root = (uint32_t)(ty0 + (int)(node / TW)) * (uint32_t)w + (uint32_t)(tx0 + (int)(node % TW));
+                br.size = size16[node] & 0x7FFFu;
+                broots[(size_t)frame * broot_cap + pos] = br;
+            }
+        }
+    }
+
+    TPROF(5);
     TPROF(6);
 }
 
@@ -608,15 +636,16 @@ __global__ __launch_bounds__(NT) void k_decimate(const uint8_t *__restrict__ src
 
 int ck_launch_threshold_segment(ck_handle *h, const uint8_t *frames, int stride, size_t frame_pitch, int n, bool precomputed) {
     const int tiles = h->tiles_x * h->tiles_y;
+    static const int stop_after = getenv("CK_TILE_STOP_AFTER") ? atoi(getenv("CK_TILE_STOP_AFTER")) : 99;
     CK_HIP(hipMemsetAsync(h->d_broot_count, 0, sizeof(uint32_t) * (size_t)n, h->stream));
     if (precomputed)
         hipLaunchKernelGGL(k_tile<true>, dim3((unsigned)(tiles * n)), dim3(KNT), 0, h->stream, frames, frame_pitch, stride, h->qw, h->qh,
                            h->tiles_x, h->tiles_y, h->cfg.min_white_black_diff, h->cfg.min_component_px, h->d_thresh, h->d_labels,
-                           h->d_broots, h->d_broot_count, h->broot_cap);
+                           h->d_broots, h->d_broot_count, h->broot_cap, stop_after);
     else
         hipLaunchKernelGGL(k_tile<false>, dim3((unsigned)(tiles * n)), dim3(KNT), 0, h->stream, frames, frame_pitch, stride, h->qw, h->qh,
                            h->tiles_x, h->tiles_y, h->cfg.min_white_black_diff, h->cfg.min_component_px, h->d_thresh, h->d_labels,
-                           h->d_broots, h->d_broot_count, h->broot_cap);
+                           h->d_broots, h->d_broot_count, h->broot_cap, stop_after);
     hipLaunchKernelGGL(k_merge, dim3((unsigned)(tiles * n)), dim3(NT), 0, h->stream, h->d_thresh, h->d_labels, h->qw, h->qh,
                        h->tiles_x, h->tiles_y);
     int bx = (h->broot_cap + NT * 8 - 1) / (NT * 8);
