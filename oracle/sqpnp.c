@@ -122,18 +122,30 @@ static void svd3(const double M[9], double U[9], double s[3], double V[9]) {
         s[c] = sqrt(w[idx[c]] > 0 ? w[idx[c]] : 0);
         for (int r = 0; r < 3; r++) V[r * 3 + c] = Vt[r * 3 + idx[c]];
     }
-    /* U columns = M v / s; the last column is completed by a cross product when s is tiny */
+    /* U columns = M v / s.  Columns whose singular value vanishes are completed deterministically (a rank-deficient
+     * guess is normal here: tags on one axis-aligned wall give exact null eigenvectors e0..e2 of Omega). */
     for (int c = 0; c < 3; c++) {
         double v[3] = {V[c], V[3 + c], V[6 + c]}, u[3];
         mat3_vec(M, v, u);
         double n = sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
         if (n > 1e-12 * (s[0] > 0 ? s[0] : 1.0)) { for (int r = 0; r < 3; r++) U[r * 3 + c] = u[r] / n; }
-        else {
-            int a = (c + 1) % 3, b = (c + 2) % 3;
-            double ua[3] = {U[a], U[3 + a], U[6 + a]}, ub[3] = {U[b], U[3 + b], U[6 + b]};
+        else if (c == 2) { /* complete a right-handed frame */
+            double ua[3] = {U[0], U[3], U[6]}, ub[3] = {U[1], U[4], U[7]};
             double cr[3] = {ua[1] * ub[2] - ua[2] * ub[1], ua[2] * ub[0] - ua[0] * ub[2], ua[0] * ub[1] - ua[1] * ub[0]};
             double cn = sqrt(cr[0] * cr[0] + cr[1] * cr[1] + cr[2] * cr[2]);
-            for (int r = 0; r < 3; r++) U[r * 3 + c] = cn > 0 ? cr[r] / cn : (r == c);
+            for (int r = 0; r < 3; r++) U[r * 3 + 2] = cn > 0 ? cr[r] / cn : (r == 2);
+        } else if (c == 1) { /* rank 1: the coordinate axis least aligned with u0 (first on ties), made orthogonal to u0 */
+            double u0[3] = {U[0], U[3], U[6]};
+            int k = 0;
+            for (int r = 1; r < 3; r++)
+                if (fabs(u0[r]) < fabs(u0[k])) k = r;
+            double e[3] = {0, 0, 0};
+            e[k] = 1.0;
+            double d = u0[k], g[3] = {e[0] - d * u0[0], e[1] - d * u0[1], e[2] - d * u0[2]};
+            double gn = sqrt(g[0] * g[0] + g[1] * g[1] + g[2] * g[2]);
+            for (int r = 0; r < 3; r++) U[r * 3 + 1] = g[r] / gn;
+        } else { /* zero matrix: U = I */
+            for (int r = 0; r < 3; r++) U[r * 3 + 0] = (r == 0);
         }
     }
 }

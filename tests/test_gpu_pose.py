@@ -111,3 +111,24 @@ def test_process_end_to_end(oracle, calib_kind):
             assert abs((r.pose_rot - truths[i]["yaw"] + np.pi) % (2 * np.pi) - np.pi) < 0.03
     assert valid[:3].all() and not valid[3]
     task.detector.close()
+
+
+def test_bench_stream_validity_matches_oracle(oracle):
+    """The bench workload itself (one axis-aligned wall, 6 tags, noise +-3): every frame's record agrees with the
+    oracle's AprilTags::process, and every frame yields a pose.  Regression for the rank-1 nearest_so3 guesses."""
+    from chalkydri_amd.apriltags import AprilTags
+    w, h, n = 1280, 800, 12
+    frames, gyro, layout, calib, r2c = scenes.bench_stream(2, n, w, h, 6, stream=0, unique=n, noise_amp=3)
+    task = AprilTags(w, h, layout, calib, r2c, cam_id=0, max_batch=n)
+    recs, valid = task.process_batch(frames, list(gyro))
+    cfg = default_config(w, h)
+    for i in range(n):
+        out = A.VisionMeasurement()
+        v = C.c_int(0)
+        oracle.lib().ora_process_frame(C.c_void_p(frames[i].ctypes.data), w, h, w, C.byref(cfg), C.byref(task._pp),
+                                       C.c_double(float(gyro[i])), 1, C.byref(out), C.byref(v))
+        r = recs[i]
+        assert bool(v.value) and bool(valid[i]), i
+        assert r.tag_count == out.tag_count == 6
+        assert abs(r.pose_x - out.pose_x) < 1e-6 and abs(r.pose_y - out.pose_y) < 1e-6 and abs(r.pose_rot - out.pose_rot) < 1e-7
+    task.detector.close()

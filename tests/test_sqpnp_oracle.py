@@ -84,3 +84,40 @@ def test_unproject_roundtrip(oracle):
     assert ok.all()
     assert np.abs(b[:, :2] / b[:, 2:3] - xy).max() < 1e-10
     assert np.abs(np.linalg.norm(b, axis=1) - 1).max() < 1e-14
+
+
+def _wall_scene(rng, n_tags, noise_px=0.0, f=1100.0):
+    """Tags on one axis-aligned wall (x = 5, facing -x): after centring, every world x is exactly 0, so Omega has the
+    exact null vectors e0..e2 and the first eigen-guesses are rank-1 matrices — nearest_so3 must complete them
+    deterministically (oracle/sqpnp.c svd3)."""
+    rtc = N.create_solver_camera_transform(0.2, 0.0, 0.6, 0.0, 0.0, 0.0)
+    yaw = rng.uniform(-0.1, 0.1)
+    Rwr = N.euler_to_mat(0, 0, yaw)
+    twr = np.array([rng.uniform(0.6, 1.6), rng.uniform(-0.4, 0.4), 0.0])
+    Rrc, trc = rtc
+    Rcw = Rrc @ Rwr.T
+    tcw = trc - Rcw @ twr
+    Rtag = N.euler_to_mat(0, 0, np.pi)
+    tags = [(Rtag, np.array([5.0, -1.2 + 0.8 * (k % 4), 0.9 + 0.65 * (k // 4)])) for k in range(n_tags)]
+    world = np.concatenate([(R @ N.CORNERS.T).T + t for R, t in tags])
+    cam = world @ Rcw.T + tcw
+    px = cam[:, :2] / cam[:, 2:3] * f
+    px += rng.normal(0, noise_px, px.shape) if noise_px > 0 else 0
+    b = np.concatenate([px / f, np.ones((len(px), 1))], 1)
+    b /= np.linalg.norm(b, axis=1, keepdims=True)
+    return tags, b, rtc, {"Rwr": Rwr, "twr": twr, "yaw": yaw}
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_axis_aligned_wall_is_solved(oracle, seed):
+    """Regression: the rank-1 eigen-guesses of a one-wall scene used to read unset columns of U, so validity depended
+    on what the previous call left on the stack.  The pose must come back every time, and twice the same."""
+    rng = np.random.default_rng(100 + seed)
+    tags, b, rtc, truth = _wall_scene(rng, 6, noise_px=0.15)
+    gyro = truth["yaw"] + rng.uniform(-0.02, 0.02)
+    got = oracle.sqpnp_solve(tags, b, rtc, gyro)
+    again = oracle.sqpnp_solve(tags, b, rtc, gyro)
+    assert got is not None and again is not None
+    assert np.array_equal(got["rot"], again["rot"]) and np.array_equal(got["pos"], again["pos"])
+    assert np.abs(got["pos"][:2] - truth["twr"][:2]).max() < 0.03
+    assert abs((got["yaw"] - truth["yaw"] + np.pi) % (2 * np.pi) - np.pi) < 0.03
