@@ -19,7 +19,7 @@ namespace {
 constexpr int NT = 256;
 constexpr int ETW = 64, ETH = 16;         // emit tile
 constexpr int LW = ETW + 2, LH = ETH + 1; // staged region: one column each side, one row below
-constexpr int LHT = 512;                  // LDS hash slots
+constexpr int LHT = 512;                  // LDS hash slots (= 2 * NT: the reservation pass gives every thread two)
 constexpr uint32_t SKIP = 0xFFFFFFFFu;
 
 __device__ __forceinline__ uint32_t key_hash(unsigned long long k) {
@@ -33,6 +33,7 @@ struct EmitArgs {
     const uint32_t *labels;
     const uint32_t *csize;
     int w, h, tiles_x, tiles_y, min_comp;
+    int stop_after; // diagnostics (CK_EMIT_STOP_AFTER): 0 staging only, 1 +count, 2 +reserve; 99 = everything
     ck_stage_ws ws;
 };
 
@@ -52,7 +53,8 @@ __global__ __launch_bounds__(NT) void k_emit(EmitArgs a) {
     __shared__ uint8_t sT[LH][LW + 2];
     __shared__ uint32_t sR[LH][LW];
     __shared__ unsigned long long sKey[LHT];
-    __shared__ uint32_t sCnt[LHT], sCnt2[LHT], sSlot[LHT], sBase[LHT], sTBase[LHT];
+    __shared__ uint32_t sCnt[LHT], sSlot[LHT], sBase[LHT], sTBase[LHT];
+    __shared__ uint32_t sWave[NT / 64 + 1];
     const int tid = threadIdx.x;
     const int tiles = a.tiles_x * a.tiles_y;
     const int frame = blockIdx.x / tiles, tile = blockIdx.x - frame * tiles;
@@ -69,7 +71,7 @@ __global__ __launch_bounds__(NT) void k_emit(EmitArgs a) {
     uint32_t *counters = ws.d_counters + (size_t)frame * CK_CNT_STRIDE;
     ck_tmp_point *tmp = ws.d_tmp + (size_t)frame * ws.point_cap;
 
-    for (int i = tid; i < LHT; i += NT) { sKey[i] = 0ull; sCnt[i] = 0; sCnt2[i] = 0; }
+    for (int i = tid; i < LHT; i += NT) { sKey[i] = 0ull; sCnt[i] = 0; }
     for (int i = tid; i < LH * LW; i += NT) {
         int ly = i / LW, lx = i - ly * LW;
         int gy = y0 + ly, gx = x0 - 1 + lx;
@@ -84,6 +86,7 @@ __global__ __launch_bounds__(NT) void k_emit(EmitArgs a) {
         sR[ly][lx] = r;
     }
     __syncthreads();
+    if (a.stop_after == 0) return;
 
     const int lx = (tid & 63) + 1; // staged column of this thread's pixels
     const int gx = x0 + (tid & 63);
@@ -91,7 +94,12 @@ __global__ __launch_bounds__(NT) void k_emit(EmitArgs a) {
     const int dxs[4] = {1, 0, -1, 1}, dys[4] = {0, 1, 1, 1};
     const bool colok = gx >= 1 && gx <= w - 2;
 
-    // pass 1: count points per key in the LDS table
+    // pass 1: count points per key in the LDS table; the add's return value is the point's rank inside (tile, key),
+    // kept in registers (slot << 16 | rank) so that the write pass neither probes nor counts again
+    constexpr uint32_t NONE = 0xFFFFFFFFu;
+    uint32_t cand[16];
+#pragma unroll
+    for (int q = 0; q < 16; q++) cand[q] = NONE;
     if (colok) {
 #pragma unroll
         for (int rr = 0; rr < 4; rr++) {
@@ -108,65 +116,73 @@ __global__ __launch_bounds__(NT) void k_emit(EmitArgs a) {
                 if (r1 == SKIP) continue;
                 unsigned long long key = r0 < r1 ? ((unsigned long long)r0 << 32) | r1 : ((unsigned long long)r1 << 32) | r0;
                 uint32_t s = key_hash(key) & (LHT - 1);
+                bool placed = false;
                 for (int probe = 0; probe < LHT; probe++) {
                     unsigned long long prev = atomicCAS(&sKey[s], 0ull, key);
-                    if (prev == 0ull || prev == key) { atomicAdd(&sCnt[s], 1u); break; }
+                    if (prev == 0ull || prev == key) { cand[rr * 4 + k] = (s << 16) | atomicAdd(&sCnt[s], 1u); placed = true; break; }
                     s = (s + 1) & (LHT - 1);
                 }
+                if (!placed) atomicOr(&counters[CK_CNT_STATUS], (uint32_t)CK_FRAME_CLUSTERS_OVERFLOW);
             }
         }
     }
     __syncthreads();
+    if (a.stop_after == 1) return;
 
-    // pass 2: one global reservation per (tile, key)
-    for (int s = tid; s < LHT; s += NT) {
-        unsigned long long key = sKey[s];
-        if (key == 0ull) continue;
-        uint32_t cnt = sCnt[s];
-        uint32_t g = key_hash(key) & (uint32_t)(ws.ht_size - 1);
-        uint32_t found = SKIP;
-        for (int probe = 0; probe < ws.ht_size; probe++) {
-            unsigned long long prev = atomicCAS(&gkeys[g], 0ull, key);
-            if (prev == 0ull || prev == key) { found = g; break; }
-            g = (g + 1) & (uint32_t)(ws.ht_size - 1);
+    // pass 2: one reservation of temp space per tile (exclusive scan of the per-key counts), and per (tile, key) one
+    // global insert + one add that hands out the points' ranks inside the cluster
+    {
+        const unsigned long long k0 = sKey[2 * tid], k1 = sKey[2 * tid + 1];
+        const uint32_t c0 = k0 ? sCnt[2 * tid] : 0u, c1 = k1 ? sCnt[2 * tid + 1] : 0u;
+        uint32_t incl = c0 + c1;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            uint32_t o = __shfl_up(incl, d, 64);
+            if ((tid & 63) >= d) incl += o;
         }
-        if (found == SKIP) { atomicOr(&counters[CK_CNT_STATUS], (uint32_t)CK_FRAME_CLUSTERS_OVERFLOW); sSlot[s] = SKIP; continue; }
-        sSlot[s] = found;
-        sBase[s] = atomicAdd(&gcount[found], cnt);
-        sTBase[s] = atomicAdd(&counters[CK_CNT_TMP], cnt);
+        if ((tid & 63) == 63) sWave[tid >> 6] = incl;
+        __syncthreads();
+        uint32_t before = 0, total = 0;
+#pragma unroll
+        for (int wv = 0; wv < NT / 64; wv++) { uint32_t t = sWave[wv]; if (wv < (tid >> 6)) before += t; total += t; }
+        if (tid == 0) sWave[NT / 64] = total ? atomicAdd(&counters[CK_CNT_TMP], total) : 0u;
+        const uint32_t excl = before + incl - (c0 + c1);
+        sTBase[2 * tid] = excl; sTBase[2 * tid + 1] = excl + c0;
+        for (int q = 0; q < 2; q++) {
+            const unsigned long long key = q ? k1 : k0;
+            const int s = 2 * tid + q;
+            if (key == 0ull) continue;
+            uint32_t g = key_hash(key) & (uint32_t)(ws.ht_size - 1);
+            uint32_t found = SKIP;
+            for (int probe = 0; probe < ws.ht_size; probe++) {
+                unsigned long long prev = atomicCAS(&gkeys[g], 0ull, key);
+                if (prev == 0ull || prev == key) { found = g; break; }
+                g = (g + 1) & (uint32_t)(ws.ht_size - 1);
+            }
+            if (found == SKIP) { atomicOr(&counters[CK_CNT_STATUS], (uint32_t)CK_FRAME_CLUSTERS_OVERFLOW); sSlot[s] = SKIP; continue; }
+            sSlot[s] = found;
+            sBase[s] = atomicAdd(&gcount[found], q ? c1 : c0);
+        }
     }
     __syncthreads();
+    if (a.stop_after == 2) return;
 
     // pass 3: write the points
+    const uint32_t tile_base = sWave[NT / 64];
     if (colok) {
 #pragma unroll
         for (int rr = 0; rr < 4; rr++) {
             int ly = row0 + rr, gy = y0 + ly;
-            if (gy < 1 || gy > h - 2) continue;
-            int v0 = sT[ly][lx];
-            uint32_t r0 = sR[ly][lx];
-            if (r0 == SKIP) continue;
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                int v1 = sT[ly + dys[k]][lx + dxs[k]];
-                if (v0 + v1 != 255) continue;
-                uint32_t r1 = sR[ly + dys[k]][lx + dxs[k]];
-                if (r1 == SKIP) continue;
-                unsigned long long key = r0 < r1 ? ((unsigned long long)r0 << 32) | r1 : ((unsigned long long)r1 << 32) | r0;
-                uint32_t s = key_hash(key) & (LHT - 1);
-                bool hit = false;
-                for (int probe = 0; probe < LHT; probe++) {
-                    unsigned long long kk = sKey[s];
-                    if (kk == key) { hit = true; break; }
-                    if (kk == 0ull) break;
-                    s = (s + 1) & (LHT - 1);
-                }
-                if (!hit) { atomicOr(&counters[CK_CNT_STATUS], (uint32_t)CK_FRAME_CLUSTERS_OVERFLOW); continue; }
+                const uint32_t cd = cand[rr * 4 + k];
+                if (cd == NONE) continue;
+                const uint32_t s = cd >> 16, lr = cd & 0xFFFFu;
                 uint32_t slot = sSlot[s];
                 if (slot == SKIP) continue;
-                uint32_t lr = atomicAdd(&sCnt2[s], 1u);
-                uint32_t ti = sTBase[s] + lr;
+                uint32_t ti = tile_base + sTBase[s] + lr;
                 if (ti >= (uint32_t)ws.point_cap) { atomicOr(&counters[CK_CNT_STATUS], (uint32_t)CK_FRAME_POINTS_OVERFLOW); continue; }
+                int v0 = sT[ly][lx], v1 = sT[ly + dys[k]][lx + dxs[k]];
                 ck_tmp_point tp;
                 tp.slot = slot; tp.rank = sBase[s] + lr;
                 tp.x = (uint16_t)(2 * gx + dxs[k]); tp.y = (uint16_t)(2 * gy + dys[k]);
@@ -254,6 +270,7 @@ int ck_launch_clusters(ck_handle *h, int n) {
     a.thresh = h->d_thresh; a.labels = h->d_labels; a.csize = h->d_csize;
     a.w = h->qw; a.h = h->qh; a.tiles_x = (h->qw + ETW - 1) / ETW; a.tiles_y = (h->qh + ETH - 1) / ETH;
     a.min_comp = h->cfg.min_component_px; a.ws = ws;
+    { static const int stop_after = getenv("CK_EMIT_STOP_AFTER") ? atoi(getenv("CK_EMIT_STOP_AFTER")) : 99; a.stop_after = stop_after; }
     hipLaunchKernelGGL(k_emit, dim3((unsigned)(a.tiles_x * a.tiles_y * n)), dim3(NT), 0, h->stream, a);
     int min_cluster = h->cfg.min_cluster_pixels < 24 ? 24 : h->cfg.min_cluster_pixels;
     hipLaunchKernelGGL(k_scan, dim3((unsigned)n), dim3(SNT), 0, h->stream, ws, min_cluster, ws.max_cluster_points);

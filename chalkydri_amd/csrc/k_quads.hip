@@ -423,7 +423,10 @@ template <int NTH, int CAP, int CH, bool MLDS, int WPS>
 __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(WPS, 8))) void k_fit(FitArgs a) {
     using B = Block<NTH>;
     constexpr int SL = CH + 2 * HALO;
-    constexpr int G = (CAP <= 4096) ? 64 : CH;   // granularity of the cumulative-moment table
+    // granularity of the cumulative-moment table: fine for the LDS-resident classes so that a selected maximum needs only
+    // a few points beyond its table entry (LPM lanes x 4 points), one entry per chunk for the large class
+    constexpr int G = (CAP <= 512) ? 16 : (CAP <= 4096) ? 32 : CH;
+    constexpr int LPM = G / 4;
     constexpr int NG = CAP / G;
     constexpr int MAXM = MLDS ? CAP / 2 : 1;
     // sKeys holds the 64-bit sort keys; after duplicate removal its first half is reused for the packed
@@ -434,7 +437,6 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(WPS, 8))) v
     __shared__ long long sTot[NG + 1][6];    // cumulative moments of the first k*G sorted points
     __shared__ long long sScratch[6 * (NTH / 64) + 2];
     __shared__ double sMaxVal[MAXM];
-    __shared__ uint16_t sMaxIdx[MAXM];
     __shared__ int sSelIdx[MAXSEL];
     __shared__ long long sSelI[MAXSEL][6], sSelE[MAXSEL][6];
     __shared__ double sRed[NTH / 64 + 1];
@@ -450,6 +452,7 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(WPS, 8))) v
     const ck_stage_ws &ws = a.ws;
     uint32_t *sXY = reinterpret_cast<uint32_t *>(sKeys);
     uint16_t *sW = reinterpret_cast<uint16_t *>(sKeys) + 2 * CAP; // bytes [4*CAP, 6*CAP)
+    uint16_t *sMaxIdx = reinterpret_cast<uint16_t *>(sKeys) + 3 * CAP; // bytes [6*CAP, 8*CAP): free once the keys are packed
     for (int i = tid; i < 495; i += NTH) sCombos[i] = g_combos[i]; // once per workgroup; the loop below starts with a barrier
 
     // static striding over the class work list: no dequeue atomics (520 k clusters per batch through one counter cost more
@@ -664,6 +667,20 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(WPS, 8))) v
         bool use_thr = false;
         if (nmax_all > a.max_nmaxima) {
             use_thr = true;
+            if (MLDS && nmax_all <= NTH) {
+                // one value per thread: count the values above / not below it; the (max_nmaxima+1)-th largest is the one
+                // with gt <= max_nmaxima < ge (every thread holding that value writes the same bits)
+                const double v = tid < nmax_all ? sMaxVal[tid] : 0.0;
+                int gt = 0, ge = 0;
+                for (int j = 0; j < nmax_all; j++) {
+                    const double u = sMaxVal[j];
+                    gt += (u > v) ? 1 : 0;
+                    ge += (u >= v) ? 1 : 0;
+                }
+                if (tid < nmax_all && gt <= a.max_nmaxima && a.max_nmaxima < ge) sRed[0] = v;
+                __syncthreads();
+                thr = sRed[0];
+            } else {
             double cur = HUGE_VAL;
             int remaining = a.max_nmaxima + 1;
             for (int round = 0; round <= a.max_nmaxima; round++) {
@@ -693,6 +710,7 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(WPS, 8))) v
                 remaining -= cnt;
                 cur = m;
             }
+            }
         }
         // survivors (at most max_nmaxima of them), then put them in increasing index order
         __syncthreads();
@@ -706,34 +724,46 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(WPS, 8))) v
         __syncthreads();
         const int nsel = sNmax;
         if (nsel < 4 || nsel > MAXSEL) continue;
-        if (tid == 0)
-            for (int i = 1; i < nsel; i++) {
-                int v = sSelIdx[i], j = i - 1;
-                while (j >= 0 && sSelIdx[j] > v) { sSelIdx[j + 1] = sSelIdx[j]; j--; }
-                sSelIdx[j + 1] = v;
+        {   // rank sort (the indices are distinct): no serial chain of dependent LDS round trips
+            int mine = 0, rank = 0;
+            if (tid < nsel) {
+                mine = sSelIdx[tid];
+                for (int j = 0; j < nsel; j++) rank += (sSelIdx[j] < mine) ? 1 : 0;
             }
+            __syncthreads();
+            if (tid < nsel) sSelIdx[rank] = mine;
+        }
         __syncthreads();
 
         PROF(6);
         if (a.stop_after == 5) continue;
         // ---- 5b. moment prefix sums at the selected maxima (chunk totals + partial sums inside the chunk) ------------------
-        if constexpr (G == 64) {
-            // one wave per selected maximum: at most 64 points beyond the table entry, summed with shuffles only
-            const int lane = tid & 63, wv = tid >> 6;
-            for (int s = wv; s < nsel; s += NTH / 64) {
-                const int gi = sSelIdx[s];
-                const int blk = gi >> 6, i = (blk << 6) + lane;
+        if constexpr (G <= 32) {
+            // LPM lanes per selected maximum, four points each: the at most G points beyond the table entry
+            if (tid < MAXSEL * LPM) {
+                const int s = tid / LPM, part = tid % LPM;
                 M6 m = m6_zero();
-                if (i <= gi) m = moments_of(sXY[i], sW[i]);
+                int gi = 0, blk = 0;
+                if (s < nsel) {
+                    gi = sSelIdx[s];
+                    blk = gi / G;
+                    const int i0 = blk * G + part * 4;
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        const int i = i0 + e;
+                        if (i <= gi) m = m6_add(m, moments_of(sXY[i], sW[i]));
+                    }
+                }
                 long long pv[6] = {m.Mx, m.My, m.Mxx, m.Mxy, m.Myy, m.W};
 #pragma unroll
                 for (int q = 0; q < 6; q++)
 #pragma unroll
-                    for (int d = 32; d >= 1; d >>= 1) pv[q] += __shfl_xor(pv[q], d, 64);
-                if (lane == 0) {
+                    for (int d = LPM / 2; d >= 1; d >>= 1) pv[q] += __shfl_xor(pv[q], d, 64);
+                if (s < nsel && part == 0) {
                     M6 self = moments_of(sXY[gi], sW[gi]);
                     long long sv[6] = {self.Mx, self.My, self.Mxx, self.Mxy, self.Myy, self.W};
-                    for (int q = 0; q < 6; q++) { sSelI[s][q] = sTot[blk][q] + pv[q]; sSelE[s][q] = sSelI[s][q] - sv[q]; }
+#pragma unroll
+                    for (int q = 0; q < 6; q++) { long long v = sTot[blk][q] + pv[q]; sSelI[s][q] = v; sSelE[s][q] = v - sv[q]; }
                 }
             }
         } else {
