@@ -388,7 +388,7 @@ __device__ __forceinline__ void sort_registers(unsigned long long (&k)[EPL], uns
 // sort, write back.  Returns dot (valid on every thread).  `raw` = staged 8-byte points in sKeys[0..sz0).
 template <int NTH, int EPL>
 __device__ __forceinline__ long long keys_sort(unsigned long long *sKeys, long long *sScratch, int sz0, int xmin, int xmax, int ymin, int ymax,
-                                               int normal_ok, int reversed_ok) {
+                                               int normal_ok, int reversed_ok, bool do_sort = true) {
     using B = Block<NTH>;
     const int tid = threadIdx.x;
     unsigned long long kreg[EPL];
@@ -409,11 +409,172 @@ __device__ __forceinline__ long long keys_sort(unsigned long long *sKeys, long l
         kreg[e] = key;
     }
     dot = B::reduce_add(dot, sScratch);
-    if ((dot < 0) ? reversed_ok : normal_ok) { // uniform: skip the sort when the border direction is rejected anyway
+    if (do_sort && ((dot < 0) ? reversed_ok : normal_ok)) { // uniform: skip the sort when the border direction is rejected anyway
         sort_registers<NTH, EPL>(kreg, sKeys);
         __syncthreads();
 #pragma unroll
         for (int e = 0; e < EPL; e++) sKeys[tid * EPL + e] = kreg[e];
+    }
+    return dot;
+}
+
+// Bucketed rank sort for the LDS-resident classes: a counting pass over nb angle buckets (octant + leading bits of the
+// in-octant fraction, so bucket order = key order), then every key ranks itself inside its bucket.  About one LDS atomic,
+// two scatters and a handful of compares per key, against log^2(n)/2 compare-exchanges for the bitonic network.  A
+// cluster whose angles pile up in one bucket (more than BUCKET_LIMIT keys) is left to the bitonic path (*done = false;
+// the staged points are still intact then).  Same result either way: equal keys are adjacent, their order is irrelevant.
+constexpr int BUCKET_LIMIT = 32;
+template <int NTH, int EPLS>
+__device__ __forceinline__ long long keys_bucket_sort(unsigned long long *sKeys, uint32_t *hist /* [nb + 1] */, long long *sScratch, int sz0,
+                                                      int xmin, int xmax, int ymin, int ymax, int normal_ok, int reversed_ok, bool do_sort,
+                                                      bool *done) {
+    using B = Block<NTH>;
+    const int tid = threadIdx.x;
+    int n2 = NTH;
+    while (n2 < sz0) n2 <<= 1;
+    int nb = n2 > 2048 ? 2048 : n2; // about one key per bucket; n2 >= NTH
+    const int lgq = (31 - __clz(nb)) - 3; // fraction bits per octant
+    for (int i = tid; i <= nb; i += NTH) hist[i] = 0;
+    unsigned long long kreg[EPLS];
+    uint32_t meta[EPLS]; // bucket << 16 | arrival index inside the bucket
+    long long dot = 0;
+#pragma unroll
+    for (int e = 0; e < EPLS; e++) {
+        const int i = tid + e * NTH;
+        kreg[e] = 0; meta[e] = 0;
+        if (i < sz0) {
+            unsigned long long raw = sKeys[i];
+            int px = (int)(raw & 0xFFFF), py = (int)((raw >> 16) & 0xFFFF);
+            int pgx = (int)(signed char)((raw >> 32) & 0xFF), pgy = (int)(signed char)((raw >> 40) & 0xFF);
+            long long dx = 4ll * px - 2ll * (xmin + xmax) - 1;
+            long long dy = 4ll * py - 2ll * (ymin + ymax) + 1;
+            dot += dx * pgx + dy * pgy;
+            kreg[e] = angle_key(px, py, xmin, xmax, ymin, ymax);
+        }
+    }
+    dot = B::reduce_add(dot, sScratch);
+    *done = true;
+    if (!do_sort || !((dot < 0) ? reversed_ok : normal_ok)) return dot; // uniform: rejected by border direction anyway
+    __syncthreads(); // histogram zeroed, every staged point read
+#pragma unroll
+    for (int e = 0; e < EPLS; e++) {
+        const int i = tid + e * NTH;
+        if (i < sz0) {
+            const uint32_t oct = (uint32_t)(kreg[e] >> 57), frac = (uint32_t)(kreg[e] >> 26) & 0x7FFFFFFFu;
+            uint32_t fb = frac >> (30 - lgq);
+            fb = fb > (1u << lgq) - 1 ? (1u << lgq) - 1 : fb; // frac == 2^30 (end of an inverted octant) stays in its octant
+            const uint32_t b = (oct << lgq) | fb;
+            meta[e] = (b << 16) | atomicAdd(&hist[b], 1u);
+        }
+    }
+    __syncthreads();
+    {   // exclusive scan of the counts in place (hist[nb] = sz0) and the largest count
+        const int per = nb / NTH;
+        uint32_t sum = 0, mx = 0;
+        for (int q = 0; q < per; q++) { uint32_t c = hist[tid * per + q]; sum += c; mx = mx > c ? mx : c; }
+        long long total;
+        const long long incl = B::scan_incl((long long)sum, sScratch, &total);
+        const int worst = -B::reduce_min(-(int)mx, reinterpret_cast<int *>(sScratch));
+        if (worst > BUCKET_LIMIT) { *done = false; __syncthreads(); return dot; }
+        uint32_t run = (uint32_t)(incl - sum);
+        for (int q = 0; q < per; q++) { uint32_t c = hist[tid * per + q]; hist[tid * per + q] = run; run += c; }
+        if (tid == NTH - 1) hist[nb] = run;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < EPLS; e++) {
+        const int i = tid + e * NTH;
+        if (i < sz0) sKeys[hist[meta[e] >> 16] + (meta[e] & 0xFFFFu)] = kreg[e];
+    }
+    __syncthreads();
+    uint32_t pos[EPLS];
+#pragma unroll
+    for (int e = 0; e < EPLS; e++) {
+        const int i = tid + e * NTH;
+        pos[e] = 0;
+        if (i < sz0) {
+            const uint32_t b = meta[e] >> 16, s0 = hist[b], s1 = hist[b + 1], mine = s0 + (meta[e] & 0xFFFFu);
+            const unsigned long long key = kreg[e];
+            uint32_t rank = 0;
+            for (uint32_t j = s0; j < s1; j++) {
+                const unsigned long long o = sKeys[j];
+                rank += (o < key || (o == key && j < mine)) ? 1u : 0u;
+            }
+            pos[e] = s0 + rank;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < EPLS; e++) {
+        const int i = tid + e * NTH;
+        if (i < sz0) sKeys[pos[e]] = kreg[e];
+    }
+    return dot;
+}
+
+// The same sort for the large class, whose keys do not fit in registers: the counting pass only counts, the scatter goes
+// to the cluster's own slice of the global point array (dead once staged; 8 bytes per point like the keys), and the rank
+// pass walks that slice and writes the sorted keys to LDS.  The staged points stay intact until the bucket sizes are known,
+// so the bitonic fallback can still start from them.
+constexpr int BUCKET_LIMIT_L = 96;
+template <int NTH>
+__device__ __forceinline__ long long keys_bucket_sort_global(unsigned long long *sKeys, uint32_t *hist /* [2 * (1024 + 1)] */, long long *sScratch,
+                                                             unsigned long long *gtmp, int sz0, int xmin, int xmax, int ymin, int ymax,
+                                                             int normal_ok, int reversed_ok, bool do_sort, bool *done) {
+    using B = Block<NTH>;
+    const int tid = threadIdx.x;
+    constexpr int nb = 1024, lgq = 7;
+    uint32_t *cursor = hist + nb + 1;
+    auto bucket_of = [&](unsigned long long key) -> uint32_t {
+        const uint32_t oct = (uint32_t)(key >> 57), frac = (uint32_t)(key >> 26) & 0x7FFFFFFFu;
+        uint32_t fb = frac >> (30 - lgq);
+        fb = fb > (1u << lgq) - 1 ? (1u << lgq) - 1 : fb;
+        return (oct << lgq) | fb;
+    };
+    for (int i = tid; i <= nb; i += NTH) hist[i] = 0;
+    __syncthreads();
+    long long dot = 0;
+    for (int i = tid; i < sz0; i += NTH) {
+        unsigned long long raw = sKeys[i];
+        int px = (int)(raw & 0xFFFF), py = (int)((raw >> 16) & 0xFFFF);
+        int pgx = (int)(signed char)((raw >> 32) & 0xFF), pgy = (int)(signed char)((raw >> 40) & 0xFF);
+        long long dx = 4ll * px - 2ll * (xmin + xmax) - 1;
+        long long dy = 4ll * py - 2ll * (ymin + ymax) + 1;
+        dot += dx * pgx + dy * pgy;
+        atomicAdd(&hist[bucket_of(angle_key(px, py, xmin, xmax, ymin, ymax))], 1u);
+    }
+    dot = B::reduce_add(dot, sScratch);
+    *done = true;
+    if (!do_sort || !((dot < 0) ? reversed_ok : normal_ok)) return dot;
+    __syncthreads();
+    {
+        constexpr int per = nb / NTH;
+        uint32_t sum = 0, mx = 0;
+        for (int q = 0; q < per; q++) { uint32_t c = hist[tid * per + q]; sum += c; mx = mx > c ? mx : c; }
+        long long total;
+        const long long incl = B::scan_incl((long long)sum, sScratch, &total);
+        const int worst = -B::reduce_min(-(int)mx, reinterpret_cast<int *>(sScratch));
+        if (worst > BUCKET_LIMIT_L) { *done = false; __syncthreads(); return dot; }
+        uint32_t run = (uint32_t)(incl - sum);
+        for (int q = 0; q < per; q++) { uint32_t c = hist[tid * per + q]; hist[tid * per + q] = run; cursor[tid * per + q] = run; run += c; }
+        if (tid == NTH - 1) hist[nb] = run;
+    }
+    __syncthreads();
+    for (int i = tid; i < sz0; i += NTH) {
+        unsigned long long raw = sKeys[i];
+        const unsigned long long key = angle_key((int)(raw & 0xFFFF), (int)((raw >> 16) & 0xFFFF), xmin, xmax, ymin, ymax);
+        gtmp[atomicAdd(&cursor[bucket_of(key)], 1u)] = key;
+    }
+    __syncthreads(); // workgroup-scope release/acquire: the slice written above is read by other waves below
+    for (int j = tid; j < sz0; j += NTH) {
+        const unsigned long long key = gtmp[j];
+        const uint32_t b = bucket_of(key), s0 = hist[b], s1 = hist[b + 1];
+        uint32_t rank = 0;
+        for (uint32_t k = s0; k < s1; k++) {
+            const unsigned long long o = gtmp[k];
+            rank += (o < key || (o == key && k < (uint32_t)j)) ? 1u : 0u;
+        }
+        sKeys[s0 + rank] = key;
     }
     return dot;
 }
@@ -505,6 +666,7 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(WPS, 8))) v
         xmin = B::reduce_min(xmin, iscr); xmax = -B::reduce_min(-xmax, iscr);
         ymin = B::reduce_min(ymin, iscr); ymax = -B::reduce_min(-ymax, iscr);
         if ((xmax - xmin) * (ymax - ymin) < a.min_tag_width) continue;
+        if (a.stop_after == 10) continue;
         long long dot;
         {   // pick the keys-per-thread count that matches the cluster (padded to a power of two, at least one per thread)
             constexpr int EPLS = CAP / NTH;
@@ -512,18 +674,27 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(WPS, 8))) v
             while (n2 < sz0) n2 <<= 1;
             const int epl = n2 / NTH;
             __syncthreads(); // raw points staged by other threads
-            if (EPLS >= 32 && epl == 32) dot = keys_sort<NTH, (EPLS >= 32 ? 32 : 1)>(sKeys, sScratch, sz0, xmin, xmax, ymin, ymax, a.normal_ok, a.reversed_ok);
-            else if (EPLS >= 16 && epl == 16) dot = keys_sort<NTH, (EPLS >= 16 ? 16 : 1)>(sKeys, sScratch, sz0, xmin, xmax, ymin, ymax, a.normal_ok, a.reversed_ok);
-            else if (EPLS >= 8 && epl == 8) dot = keys_sort<NTH, (EPLS >= 8 ? 8 : 1)>(sKeys, sScratch, sz0, xmin, xmax, ymin, ymax, a.normal_ok, a.reversed_ok);
-            else if (EPLS >= 4 && epl == 4) dot = keys_sort<NTH, (EPLS >= 4 ? 4 : 1)>(sKeys, sScratch, sz0, xmin, xmax, ymin, ymax, a.normal_ok, a.reversed_ok);
-            else if (EPLS >= 2 && epl == 2) dot = keys_sort<NTH, (EPLS >= 2 ? 2 : 1)>(sKeys, sScratch, sz0, xmin, xmax, ymin, ymax, a.normal_ok, a.reversed_ok);
-            else dot = keys_sort<NTH, 1>(sKeys, sScratch, sz0, xmin, xmax, ymin, ymax, a.normal_ok, a.reversed_ok);
+            bool sorted = false;
+            if constexpr (CAP <= 4096)
+                dot = keys_bucket_sort<NTH, EPLS>(sKeys, reinterpret_cast<uint32_t *>(&sP[0][0]), sScratch, sz0, xmin, xmax, ymin, ymax,
+                                                  a.normal_ok, a.reversed_ok, a.stop_after != 11, &sorted);
+            else
+                dot = keys_bucket_sort_global<NTH>(sKeys, reinterpret_cast<uint32_t *>(&sP[0][0]), sScratch,
+                                                   reinterpret_cast<unsigned long long *>(pts), sz0, xmin, xmax, ymin, ymax,
+                                                   a.normal_ok, a.reversed_ok, a.stop_after != 11, &sorted);
+            if (sorted) {}
+            else if (EPLS >= 32 && epl == 32) dot = keys_sort<NTH, (EPLS >= 32 ? 32 : 1)>(sKeys, sScratch, sz0, xmin, xmax, ymin, ymax, a.normal_ok, a.reversed_ok, a.stop_after != 11);
+            else if (EPLS >= 16 && epl == 16) dot = keys_sort<NTH, (EPLS >= 16 ? 16 : 1)>(sKeys, sScratch, sz0, xmin, xmax, ymin, ymax, a.normal_ok, a.reversed_ok, a.stop_after != 11);
+            else if (EPLS >= 8 && epl == 8) dot = keys_sort<NTH, (EPLS >= 8 ? 8 : 1)>(sKeys, sScratch, sz0, xmin, xmax, ymin, ymax, a.normal_ok, a.reversed_ok, a.stop_after != 11);
+            else if (EPLS >= 4 && epl == 4) dot = keys_sort<NTH, (EPLS >= 4 ? 4 : 1)>(sKeys, sScratch, sz0, xmin, xmax, ymin, ymax, a.normal_ok, a.reversed_ok, a.stop_after != 11);
+            else if (EPLS >= 2 && epl == 2) dot = keys_sort<NTH, (EPLS >= 2 ? 2 : 1)>(sKeys, sScratch, sz0, xmin, xmax, ymin, ymax, a.normal_ok, a.reversed_ok, a.stop_after != 11);
+            else dot = keys_sort<NTH, 1>(sKeys, sScratch, sz0, xmin, xmax, ymin, ymax, a.normal_ok, a.reversed_ok, a.stop_after != 11);
         }
         const int reversed = dot < 0;
         PROF(0);
         if (reversed && !a.reversed_ok) continue;
         if (!reversed && !a.normal_ok) continue;
-        if (a.stop_after == 1) continue;
+        if (a.stop_after == 1 || a.stop_after == 11) continue;
 
         // ---- 2. duplicate removal, packing to (x,y) ----------------------------------------------------------------
         __syncthreads();

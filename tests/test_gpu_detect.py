@@ -87,6 +87,59 @@ def test_quads_match_oracle(oracle, w, h, n_tags, kw):
     det.close()
 
 
+def _shapes(w, h, seed):
+    """Hand-drawn frame that drives the sort of every size class through both of its paths: thin bars and spokes put
+    hundreds of boundary points into one angle bucket (bitonic fallback), blobs and rings spread them out (bucket path);
+    the outline rectangles are large-class clusters."""
+    rng = np.random.default_rng(seed)
+    im = np.full((h, w), 40, np.uint8)
+    yy, xx = np.mgrid[0:h, 0:w]
+    im[20:23, 30:w - 40] = 220                                  # long thin bars
+    im[40:h - 30, 14:17] = 220
+    im[(np.abs((yy - 60) - (xx - 40) * 0.31) < 1.6) & (xx > 40) & (xx < w - 60)] = 220   # thin slanted line
+    im[60:h - 20, 60:w - 20] = 215                              # big plate ...
+    im[70:h - 30, 70:w - 30] = 35                               # ... hollowed: two long outlines
+    cx, cy = w // 2, h // 2 + 10
+    r = np.hypot(xx - cx, yy - cy)
+    im[(r < 0.28 * h) & (r > 0.2 * h)] = 225                    # ring
+    for k in range(12):                                         # spokes inside the ring
+        a = k * np.pi / 6 + 0.1
+        d = np.abs((xx - cx) * np.sin(a) - (yy - cy) * np.cos(a))
+        im[(d < 1.3) & (r < 0.18 * h) & (r > 6)] = 225
+    for _ in range(10):                                         # filled quadrilaterals of assorted sizes
+        x0, y0 = rng.integers(80, w - 160), rng.integers(80, h - 120)
+        sw, sh = rng.integers(14, 70), rng.integers(14, 70)
+        sk = rng.uniform(-0.4, 0.4)
+        m = (np.abs((xx - x0) - sk * (yy - y0)) < sw / 2) & (np.abs(yy - y0) < sh / 2)
+        im[m] = 228 if rng.random() < 0.5 else 20
+    noise = rng.integers(-1, 2, im.shape)
+    return np.clip(im.astype(np.int64) + noise, 0, 255).astype(np.uint8)
+
+
+@pytest.mark.parametrize("w,h,seed", [(640, 480, 1), (1280, 800, 2)])
+def test_quads_match_oracle_on_drawn_shapes(oracle, w, h, seed):
+    from chalkydri_amd.detector import AprilTagDetector
+    frames = np.stack([_shapes(w, h, seed), _shapes(w, h, seed + 10)[::-1].copy()])
+    det = AprilTagDetector(w, h, max_batch=2)
+    got = det.quads(frames)
+    cfg = default_config(w, h)
+    sizes, nq = [], 0
+    for i in range(2):
+        th = oracle.threshold(frames[i])
+        lab, sz = oracle.segment(th)
+        ocl, opts, _ = oracle.clusters(th, lab, sz)
+        sizes += [int(c[3]) for c in ocl]
+        oq, ov = oracle.fit_quads(frames[i], cfg, ocl, opts)
+        want, have = _quads_np(oq), _quads_np(got[i])
+        assert want.shape == have.shape, f"{len(want)} oracle quads vs {len(have)} device quads"
+        assert np.array_equal(want, have), f"max |diff| = {np.abs(want - have).max()}"
+        nq += len(want)
+    assert nq >= 3
+    # all three size classes of the fit kernel were exercised
+    assert any(s <= 512 for s in sizes) and any(512 < s <= 4096 for s in sizes) and any(4096 < s <= 16384 for s in sizes)
+    det.close()
+
+
 def _same_dets(have, want):
     assert len(have) == len(want), f"{len(have)} vs {len(want)} detections"
     for a, b in zip(have, want):
