@@ -99,6 +99,25 @@ __device__ __forceinline__ void fit_line_m(const M6 &m, int N, double *lineparm,
 __device__ const double k_smooth[7] = {0.011108996538242306, 0.1353352832366127, 0.6065306597126334, 1.0,
                                        0.6065306597126334, 0.1353352832366127, 0.011108996538242306};
 
+// Wave-wide inclusive sums on the DPP path (no LDS crossbar, no lane-index arithmetic): four row_shr steps inside each
+// row of 16 lanes, then row_bcast:15 into rows 1 and 3 and row_bcast:31 into rows 2 and 3.  Lanes without a source add 0.
+template <int CTRL, int ROWS>
+__device__ __forceinline__ uint32_t dpp0(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROWS, 0xF, true); }
+template <int CTRL, int ROWS>
+__device__ __forceinline__ unsigned long long dpp0_64(unsigned long long v) {
+    return ((unsigned long long)dpp0<CTRL, ROWS>((uint32_t)(v >> 32)) << 32) | dpp0<CTRL, ROWS>((uint32_t)v);
+}
+__device__ __forceinline__ uint32_t wave_scan_u32(uint32_t x) {
+    x += dpp0<0x111, 0xF>(x); x += dpp0<0x112, 0xF>(x); x += dpp0<0x114, 0xF>(x); x += dpp0<0x118, 0xF>(x);
+    x += dpp0<0x142, 0xA>(x); x += dpp0<0x143, 0xC>(x);
+    return x;
+}
+__device__ __forceinline__ unsigned long long wave_scan_u64(unsigned long long x) {
+    x += dpp0_64<0x111, 0xF>(x); x += dpp0_64<0x112, 0xF>(x); x += dpp0_64<0x114, 0xF>(x); x += dpp0_64<0x118, 0xF>(x);
+    x += dpp0_64<0x142, 0xA>(x); x += dpp0_64<0x143, 0xC>(x);
+    return x;
+}
+
 template <int NTH>
 struct Block {
     static constexpr int NW = NTH / 64;
@@ -173,6 +192,29 @@ struct Block {
                 long long base = 0;
                 for (int k = 0; k < wv; k++) base += scratch[q * NW + k];
                 v[q] += base;
+            }
+            __syncthreads();
+        }
+    }
+    // inclusive scan of three 64-bit and three 32-bit values per thread, one barrier pair; both arrays are replaced.
+    // scratch: 5 * NW long long (the 32-bit values travel as a second array inside it)
+    __device__ static void scan_incl_3x64_3x32(unsigned long long a[3], uint32_t b[3], long long *scratch) {
+        const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+#pragma unroll
+        for (int q = 0; q < 3; q++) { a[q] = wave_scan_u64(a[q]); b[q] = wave_scan_u32(b[q]); }
+        if (NW > 1) {
+            unsigned long long *s64 = reinterpret_cast<unsigned long long *>(scratch);
+            uint32_t *s32 = reinterpret_cast<uint32_t *>(scratch + 3 * NW);
+            if (lane == 63)
+#pragma unroll
+                for (int q = 0; q < 3; q++) { s64[q * NW + wv] = a[q]; s32[q * NW + wv] = b[q]; }
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < 3; q++) {
+                unsigned long long ba = 0;
+                uint32_t bb = 0;
+                for (int k = 0; k < wv; k++) { ba += s64[q * NW + k]; bb += s32[q * NW + k]; }
+                a[q] += ba; b[q] += bb;
             }
             __syncthreads();
         }
@@ -293,8 +335,8 @@ struct PairFit { double err, mse, nx, ny; };
 __device__ uint16_t g_combos[495];
 
 __device__ __forceinline__ int wrap_index(int i, int sz) { // i in [-HALO, sz + CH + HALO): bring into [0, sz)
-    while (i < 0) i += sz;
-    while (i >= sz) i -= sz;
+    if (i < 0) i += sz;   // one step each way is enough: i >= -HALO >= -sz, and a span ends before sz + HALO <= 2 * sz
+    if (i >= sz) i -= sz;
     return i;
 }
 // gradient-magnitude weight of a sorted point (x,y in half pixels)
@@ -593,7 +635,11 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(WPS, 8))) v
     // sKeys holds the 64-bit sort keys; after duplicate removal its first half is reused for the packed
     // coordinates (x<<13|y, u32) and the third quarter for the u16 weights.
     __shared__ unsigned long long sKeys[CAP];
-    __shared__ long long sP[6][SL];          // inclusive moment prefix sums over the current span; later the pair-fit table
+    // inclusive moment prefix sums over the current span of SL points: Mxx, Mxy, Myy as 64-bit and Mx, My, W as 32-bit
+    // (a span's sums stay below 304 * 362 * 8192 < 2^32); the same bytes are the sort's histogram before and the pair-fit
+    // table after the chunk loop
+    constexpr int SPB = 36 * SL > (int)sizeof(PairFit) * MAXSEL * MAXSEL ? 36 * SL : (int)sizeof(PairFit) * MAXSEL * MAXSEL;
+    __shared__ __attribute__((aligned(16))) unsigned char sPraw[SPB];
     __shared__ double sErr[SL], sSm[SL];
     __shared__ long long sTot[NG + 1][6];    // cumulative moments of the first k*G sorted points
     __shared__ long long sScratch[6 * (NTH / 64) + 2];
@@ -608,7 +654,9 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(WPS, 8))) v
     __shared__ double sQuad[4][2];
     __shared__ uint16_t sCombos[496];
     __shared__ double sRefine[4][16][2]; // per edge, per sample of the current round: refined point (x,y); x = NaN: no point
-    static_assert(sizeof(PairFit) * MAXSEL * MAXSEL <= sizeof(long long) * 6 * SL, "pair-fit table must fit in sP");
+    static_assert(SPB >= 2 * (1024 + 1) * 4 || CAP <= 512, "sort histogram must fit in sPraw");
+    long long (*sP64)[SL] = reinterpret_cast<long long (*)[SL]>(sPraw);            // [3][SL]: Mxx, Mxy, Myy
+    uint32_t (*sP32)[SL] = reinterpret_cast<uint32_t (*)[SL]>(sPraw + 24 * SL);     // [3][SL]: Mx, My, W
     const int tid = threadIdx.x;
     const ck_stage_ws &ws = a.ws;
     uint32_t *sXY = reinterpret_cast<uint32_t *>(sKeys);
@@ -676,10 +724,10 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(WPS, 8))) v
             __syncthreads(); // raw points staged by other threads
             bool sorted = false;
             if constexpr (CAP <= 4096)
-                dot = keys_bucket_sort<NTH, EPLS>(sKeys, reinterpret_cast<uint32_t *>(&sP[0][0]), sScratch, sz0, xmin, xmax, ymin, ymax,
+                dot = keys_bucket_sort<NTH, EPLS>(sKeys, reinterpret_cast<uint32_t *>(sPraw), sScratch, sz0, xmin, xmax, ymin, ymax,
                                                   a.normal_ok, a.reversed_ok, a.stop_after != 11, &sorted);
             else
-                dot = keys_bucket_sort_global<NTH>(sKeys, reinterpret_cast<uint32_t *>(&sP[0][0]), sScratch,
+                dot = keys_bucket_sort_global<NTH>(sKeys, reinterpret_cast<uint32_t *>(sPraw), sScratch,
                                                    reinterpret_cast<unsigned long long *>(pts), sz0, xmin, xmax, ymin, ymax,
                                                    a.normal_ok, a.reversed_ok, a.stop_after != 11, &sorted);
             if (sorted) {}
@@ -777,18 +825,17 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(WPS, 8))) v
                 }
                 loc[e] = run;
             }
-            long long v[6] = {run.Mx, run.My, run.Mxx, run.Mxy, run.Myy, run.W}, ex[6];
-#pragma unroll
-            for (int q = 0; q < 6; q++) ex[q] = v[q];
-            B::scan_incl6(ex, sScratch);
-#pragma unroll
-            for (int q = 0; q < 6; q++) ex[q] -= v[q];
+            unsigned long long xa[3] = {(unsigned long long)run.Mxx, (unsigned long long)run.Mxy, (unsigned long long)run.Myy};
+            uint32_t xb[3] = {(uint32_t)run.Mx, (uint32_t)run.My, (uint32_t)run.W};
+            B::scan_incl_3x64_3x32(xa, xb, sScratch);
+            xa[0] -= (unsigned long long)run.Mxx; xa[1] -= (unsigned long long)run.Mxy; xa[2] -= (unsigned long long)run.Myy;
+            xb[0] -= (uint32_t)run.Mx; xb[1] -= (uint32_t)run.My; xb[2] -= (uint32_t)run.W;
 #pragma unroll
             for (int e = 0; e < EPT; e++) {
                 int j = tid * EPT + e;
                 if (j < sl) {
-                    sP[0][j] = loc[e].Mx + ex[0]; sP[1][j] = loc[e].My + ex[1]; sP[2][j] = loc[e].Mxx + ex[2];
-                    sP[3][j] = loc[e].Mxy + ex[3]; sP[4][j] = loc[e].Myy + ex[4]; sP[5][j] = loc[e].W + ex[5];
+                    sP64[0][j] = loc[e].Mxx + (long long)xa[0]; sP64[1][j] = loc[e].Mxy + (long long)xa[1]; sP64[2][j] = loc[e].Myy + (long long)xa[2];
+                    sP32[0][j] = (uint32_t)loc[e].Mx + xb[0]; sP32[1][j] = (uint32_t)loc[e].My + xb[1]; sP32[2][j] = (uint32_t)loc[e].W + xb[2];
                 }
             }
             __syncthreads();
@@ -797,13 +844,27 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(WPS, 8))) v
                 if (tid < 6 * BPC) {
                     int q = tid % 6, bb = tid / 6;
                     int last = min((bb + 1) * G, chn);      // points of this chunk covered through block bb
-                    if (bb * G < chn) sTot[c * BPC + bb + 1][q] = sTot[c * BPC][q] + sP[q][HALO + last - 1] - sP[q][HALO - 1];
+                    if (bb * G < chn) {
+                        const int jh = HALO + last - 1, jl = HALO - 1;
+                        long long d;
+                        if (q == 0) d = (long long)(sP32[0][jh] - sP32[0][jl]);
+                        else if (q == 1) d = (long long)(sP32[1][jh] - sP32[1][jl]);
+                        else if (q == 5) d = (long long)(sP32[2][jh] - sP32[2][jl]);
+                        else d = sP64[q - 2][jh] - sP64[q - 2][jl];
+                        sTot[c * BPC + bb + 1][q] = sTot[c * BPC][q] + d;
+                    }
                 }
             }
             for (int j = HALO - 4 + tid; j < HALO + chn + 4; j += NTH) {
                 int hi = j + ksz, lo = j - ksz - 1;
-                M6 m = {sP[0][hi], sP[1][hi], sP[2][hi], sP[3][hi], sP[4][hi], sP[5][hi]};
-                if (lo >= 0) { M6 l = {sP[0][lo], sP[1][lo], sP[2][lo], sP[3][lo], sP[4][lo], sP[5][lo]}; m = m6_sub(m, l); }
+                uint32_t mx = sP32[0][hi], my = sP32[1][hi], mw = sP32[2][hi];
+                M6 m;
+                m.Mxx = sP64[0][hi]; m.Mxy = sP64[1][hi]; m.Myy = sP64[2][hi];
+                if (lo >= 0) {
+                    mx -= sP32[0][lo]; my -= sP32[1][lo]; mw -= sP32[2][lo];
+                    m.Mxx -= sP64[0][lo]; m.Mxy -= sP64[1][lo]; m.Myy -= sP64[2][lo];
+                }
+                m.Mx = (long long)mx; m.My = (long long)my; m.W = (long long)mw;
                 double e;
                 fit_line_m(m, 2 * ksz + 1, nullptr, &e, nullptr);
                 sErr[j] = e;
@@ -967,7 +1028,7 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(WPS, 8))) v
         PROF(7);
         if (a.stop_after == 6) continue;
         // ---- 5c. one line fit per ordered pair of maxima; the 4-subset search is then table lookups ------------------------
-        PairFit *sF = reinterpret_cast<PairFit *>(&sP[0][0]);
+        PairFit *sF = reinterpret_cast<PairFit *>(sPraw);
         for (int pr = tid; pr < nsel * nsel; pr += NTH) {
             int sa = pr / nsel, sb = pr - sa * nsel;
             if (sa == sb) continue;
