@@ -118,18 +118,23 @@ __device__ __forceinline__ unsigned long long wave_scan_u64(unsigned long long x
     return x;
 }
 
+__device__ __forceinline__ int wave_min_i32(int x) { // same DPP ladder with min; lanes without a source keep their own value
+    x = min(x, __builtin_amdgcn_update_dpp(x, x, 0x111, 0xF, 0xF, false));
+    x = min(x, __builtin_amdgcn_update_dpp(x, x, 0x112, 0xF, 0xF, false));
+    x = min(x, __builtin_amdgcn_update_dpp(x, x, 0x114, 0xF, 0xF, false));
+    x = min(x, __builtin_amdgcn_update_dpp(x, x, 0x118, 0xF, 0xF, false));
+    x = min(x, __builtin_amdgcn_update_dpp(x, x, 0x142, 0xA, 0xF, false));
+    x = min(x, __builtin_amdgcn_update_dpp(x, x, 0x143, 0xC, 0xF, false));
+    return __builtin_amdgcn_readlane(x, 63);
+}
+
 template <int NTH>
 struct Block {
     static constexpr int NW = NTH / 64;
     // inclusive sum over the workgroup of one 64-bit value per thread; scratch: NW+1 values of LDS
     __device__ static long long scan_incl(long long v, long long *scratch, long long *total) {
         const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-        long long x = v;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            long long o = __shfl_up(x, d, 64);
-            if (lane >= d) x += o;
-        }
+        long long x = (long long)wave_scan_u64((unsigned long long)v);
         if (NW > 1) {
             if (lane == 63) scratch[wv] = x;
             __syncthreads();
@@ -157,8 +162,11 @@ struct Block {
     }
     __device__ static long long reduce_add(long long v, long long *scratch) {
         const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+        {
+            const unsigned long long t = wave_scan_u64((unsigned long long)v); // lane 63 holds the wave's sum
+            v = (long long)(((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(t >> 32), 63) << 32) |
+                            (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)t, 63));
+        }
         if (NW > 1) {
             if (lane == 0) scratch[wv] = v;
             __syncthreads();
@@ -218,6 +226,43 @@ struct Block {
             }
             __syncthreads();
         }
+    }
+    // minima of four values per thread over the workgroup (every thread gets them), one barrier pair
+    __device__ static void reduce_min4(int v[4], int *scratch /* [4*NW] */) {
+        const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+#pragma unroll
+        for (int q = 0; q < 4; q++) v[q] = wave_min_i32(v[q]);
+        if (NW > 1) {
+            if (lane == 0)
+#pragma unroll
+                for (int q = 0; q < 4; q++) scratch[q * NW + wv] = v[q];
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                int r = scratch[q * NW];
+                for (int k = 1; k < NW; k++) r = min(r, scratch[q * NW + k]);
+                v[q] = r;
+            }
+            __syncthreads();
+        }
+    }
+    // inclusive count of a 0/1 flag over the workgroup: ballot + popcount, one barrier pair
+    __device__ static int scan_flag(int flag, int *scratch /* [NW] */, int *total) {
+        const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+        const unsigned long long bal = __ballot(flag != 0);
+        int incl = __popcll(bal & ((2ull << lane) - 1ull));
+        int tot = __popcll(bal);
+        if (NW > 1) {
+            if (lane == 0) scratch[wv] = tot;
+            __syncthreads();
+            int base = 0;
+            tot = 0;
+            for (int k = 0; k < NW; k++) { int t = scratch[k]; if (k < wv) base += t; tot += t; }
+            incl += base;
+            __syncthreads();
+        }
+        *total = tot;
+        return incl;
     }
     // sums of six values per thread over the workgroup (every thread gets them), one barrier pair
     __device__ static void reduce_add6(long long v[6], long long *scratch /* [6*NW] */) {
@@ -711,8 +756,11 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(WPS, 8))) v
             }
         }
         int *iscr = reinterpret_cast<int *>(sScratch);
-        xmin = B::reduce_min(xmin, iscr); xmax = -B::reduce_min(-xmax, iscr);
-        ymin = B::reduce_min(ymin, iscr); ymax = -B::reduce_min(-ymax, iscr);
+        {
+            int bb[4] = {xmin, -xmax, ymin, -ymax};
+            B::reduce_min4(bb, iscr);
+            xmin = bb[0]; xmax = -bb[1]; ymin = bb[2]; ymax = -bb[3];
+        }
         if ((xmax - xmin) * (ymax - ymin) < a.min_tag_width) continue;
         if (a.stop_after == 10) continue;
         long long dot;
@@ -755,8 +803,8 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(WPS, 8))) v
             unsigned long long key = 0;
             int keep = 0;
             if (i < sz0) { key = sKeys[i]; keep = (i == 0) || (sKeys[i - 1] != key); }
-            long long tot = 0;
-            long long incl = B::scan_incl((long long)keep, sScratch, &tot);
+            int tot = 0;
+            const int incl = B::scan_flag(keep, iscr, &tot);
             __syncthreads();
             if (keep) sXY[sz + (int)incl - 1] = (uint32_t)(key & 0x3FFFFFFu);
             sz += (int)tot;
