@@ -673,8 +673,8 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(WPS, 8))) v
     constexpr int SL = CH + 2 * HALO;
     // granularity of the cumulative-moment table: fine for the LDS-resident classes so that a selected maximum needs only
     // a few points beyond its table entry (LPM lanes x 4 points), one entry per chunk for the large class
-    constexpr int G = (CAP <= 512) ? 16 : (CAP <= 4096) ? 32 : CH;
-    constexpr int LPM = G / 4;
+    constexpr int G = (CAP <= 4096) ? 32 : CH;
+    constexpr int LPM = (NTH >= MAXSEL * 8) ? 8 : 4; // lanes per selected maximum, G / LPM points each
     constexpr int NG = CAP / G;
     constexpr int MAXM = MLDS ? CAP / 2 : 1;
     // sKeys holds the 64-bit sort keys; after duplicate removal its first half is reused for the packed
@@ -685,20 +685,25 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(WPS, 8))) v
     // table after the chunk loop
     constexpr int SPB = 36 * SL > (int)sizeof(PairFit) * MAXSEL * MAXSEL ? 36 * SL : (int)sizeof(PairFit) * MAXSEL * MAXSEL;
     __shared__ __attribute__((aligned(16))) unsigned char sPraw[SPB];
-    __shared__ double sErr[SL], sSm[SL];
+    __shared__ double sErr[SL];
     __shared__ long long sTot[NG + 1][6];    // cumulative moments of the first k*G sorted points
     __shared__ long long sScratch[6 * (NTH / 64) + 2];
     __shared__ double sMaxVal[MAXM];
     __shared__ int sSelIdx[MAXSEL];
-    __shared__ long long sSelI[MAXSEL][6], sSelE[MAXSEL][6];
+    // moment prefix sums at the selected maxima: they are born after the maxima list has been consumed, so the
+    // LDS-resident classes keep them in its bytes
+    __shared__ long long sSelStore[MLDS ? 1 : 2 * MAXSEL * 6];
+    static_assert(!MLDS || sizeof(double) * MAXM >= sizeof(long long) * 2 * MAXSEL * 6, "selected-maxima sums must fit in sMaxVal");
+    long long (*sSelI)[6] = reinterpret_cast<long long (*)[6]>(MLDS ? reinterpret_cast<long long *>(sMaxVal) : sSelStore);
+    long long (*sSelE)[6] = sSelI + MAXSEL;
     __shared__ double sRed[NTH / 64 + 1];
     __shared__ int sRedI[NTH / 64 + 1];
     __shared__ uint32_t sWork;
     __shared__ int sNmax, sFlag;
     __shared__ double sLines[4][4];
     __shared__ double sQuad[4][2];
-    __shared__ uint16_t sCombos[496];
-    __shared__ double sRefine[4][16][2]; // per edge, per sample of the current round: refined point (x,y); x = NaN: no point
+    // per edge, per sample of the current round: refined point (x,y); x = NaN: no point.  Lives in the pair-fit table's bytes
+    double (*sRefine)[16][2] = reinterpret_cast<double (*)[16][2]>(sPraw);
     static_assert(SPB >= 2 * (1024 + 1) * 4 || CAP <= 512, "sort histogram must fit in sPraw");
     long long (*sP64)[SL] = reinterpret_cast<long long (*)[SL]>(sPraw);            // [3][SL]: Mxx, Mxy, Myy
     uint32_t (*sP32)[SL] = reinterpret_cast<uint32_t (*)[SL]>(sPraw + 24 * SL);     // [3][SL]: Mx, My, W
@@ -707,7 +712,6 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(WPS, 8))) v
     uint32_t *sXY = reinterpret_cast<uint32_t *>(sKeys);
     uint16_t *sW = reinterpret_cast<uint16_t *>(sKeys) + 2 * CAP; // bytes [4*CAP, 6*CAP)
     uint16_t *sMaxIdx = reinterpret_cast<uint16_t *>(sKeys) + 3 * CAP; // bytes [6*CAP, 8*CAP): free once the keys are packed
-    for (int i = tid; i < 495; i += NTH) sCombos[i] = g_combos[i]; // once per workgroup; the loop below starts with a barrier
 
     // static striding over the class work list: no dequeue atomics (520 k clusters per batch through one counter cost more
     // than any phase of the fit); clusters of one class are similar enough for the load to even out over ~100 per workgroup
@@ -918,23 +922,24 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(WPS, 8))) v
                 sErr[j] = e;
             }
             __syncthreads();
-            for (int j = HALO - 1 + tid; j < HALO + chn + 1; j += NTH) {
-                double acc = 0.0;
-#pragma unroll
-                for (int q = 0; q < 7; q++) acc += sErr[j + q - 3] * k_smooth[q];
-                sSm[j] = acc;
-            }
-            __syncthreads();
+            // smoothing and maxima in one pass: each point smooths itself and its two neighbours from nine errors (same
+            // operation order as the oracle's one-value-at-a-time loop, so the same bits)
             for (int j = HALO + tid; j < HALO + chn; j += NTH) {
-                double s = sSm[j];
-                if (s > sSm[j + 1] && s > sSm[j - 1]) {
+                double e9[9];
+#pragma unroll
+                for (int q = 0; q < 9; q++) e9[q] = sErr[j + q - 4];
+                double sp = 0.0, s = 0.0, sn = 0.0;
+#pragma unroll
+                for (int q = 0; q < 7; q++) { sp += e9[q] * k_smooth[q]; s += e9[q + 1] * k_smooth[q]; sn += e9[q + 2] * k_smooth[q]; }
+                if (s > sn && s > sp) {
                     int pos = atomicAdd(&sNmax, 1); // pos < sz/2
                     if (MLDS) { sMaxVal[pos] = s; sMaxIdx[pos] = (uint16_t)(cbase + j - HALO); }
                     else { gval[pos] = s; gidx[pos] = (uint32_t)(cbase + j - HALO); }
                 }
             }
-            __syncthreads();
+            // no barrier here: the next chunk writes sErr only after the barrier that follows its prefix sums
         }
+        __syncthreads();
         PROF(4);
         const int nmax_all = sNmax;
         if (nmax_all < 4) continue;
@@ -1019,7 +1024,7 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(WPS, 8))) v
         if (a.stop_after == 5) continue;
         // ---- 5b. moment prefix sums at the selected maxima (chunk totals + partial sums inside the chunk) ------------------
         if constexpr (G <= 32) {
-            // LPM lanes per selected maximum, four points each: the at most G points beyond the table entry
+            // LPM lanes per selected maximum, G / LPM points each: the at most G points beyond the table entry
             if (tid < MAXSEL * LPM) {
                 const int s = tid / LPM, part = tid % LPM;
                 M6 m = m6_zero();
@@ -1027,9 +1032,10 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(WPS, 8))) v
                 if (s < nsel) {
                     gi = sSelIdx[s];
                     blk = gi / G;
-                    const int i0 = blk * G + part * 4;
+                    constexpr int PPL = G / LPM;
+                    const int i0 = blk * G + part * PPL;
 #pragma unroll
-                    for (int e = 0; e < 4; e++) {
+                    for (int e = 0; e < PPL; e++) {
                         const int i = i0 + e;
                         if (i <= gi) m = m6_add(m, moments_of(sXY[i], sW[i]));
                     }
@@ -1092,7 +1098,7 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(WPS, 8))) v
         int bestc = 1 << 30;
         {
             for (int cb = tid; cb < 495; cb += NTH) { // every lane walks its own subsets; ties resolved by the packed index
-                const int pk = sCombos[cb];
+                const int pk = g_combos[cb];
                 const int m0 = pk >> 12, m1 = (pk >> 8) & 15, m2 = (pk >> 4) & 15, m3 = pk & 15;
                 if (m3 >= nsel) continue;
                 {
@@ -1424,7 +1430,7 @@ int ck_launch_fit_quads(ck_handle *h, const uint8_t *qframes, int qstride, size_
     }
     int cus = 256;
     a.list = lists; a.list_count = list_counts; a.head = heads;
-    hipLaunchKernelGGL((k_fit<64, 512, 64, true, 4>), dim3((unsigned)(cus * 8)), dim3(64), 0, h->stream, a);
+    hipLaunchKernelGGL((k_fit<64, 512, 64, true, 3>), dim3((unsigned)(cus * 12)), dim3(64), 0, h->stream, a);
     a.list = lists + list_cap; a.list_count = list_counts + 1; a.head = heads + 1;
     hipLaunchKernelGGL((k_fit<256, 4096, 256, true, 2>), dim3((unsigned)(cus * 2)), dim3(256), 0, h->stream, a);
     a.list = lists + 2 * (size_t)list_cap; a.list_count = list_counts + 2; a.head = heads + 2;
