@@ -37,6 +37,9 @@ struct ck_dev_family {
 };
 
 // One boundary point while it waits to be grouped (k_clusters.hip)
+// size classes of the quad fit (k_quads.hip): <= 512, <= 2048, <= 4096, <= 16384 points per cluster
+constexpr int CK_FIT_CLASSES = 4;
+
 struct ck_tmp_point {
     uint32_t slot;  // hash-table slot of its cluster
     uint32_t rank;  // position inside the cluster

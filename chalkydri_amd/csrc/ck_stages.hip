@@ -32,8 +32,8 @@ int ck_stage_alloc(ck_handle *h) {
     CK_HIP(hipMalloc(&ws.d_counters, sizeof(uint32_t) * CK_CNT_STRIDE * nb));
     CK_HIP(hipMalloc(&ws.d_quads, sizeof(ck_quad_t) * (size_t)ws.quad_cap * nb));
     CK_HIP(hipMalloc(&ws.d_dets, sizeof(ck_detection_t) * (size_t)ws.det_cap * nb));
-    // fit scratch: 3 work lists + counters, then the decode candidates
-    size_t list_bytes = ((size_t)3 * ws.cluster_cap * nb + 16) * sizeof(uint32_t);
+    // fit scratch: one work list per size class + counters, then the decode candidates
+    size_t list_bytes = ((size_t)CK_FIT_CLASSES * ws.cluster_cap * nb + 16) * sizeof(uint32_t);
     size_t cand_bytes = 256 + ((nb * 4 + 255) / 256) * 256 + sizeof(ck_detection_t) * (size_t)ws.quad_cap * cfg.n_families * nb;
     ws.fit_scratch_bytes = ((list_bytes + 255) / 256) * 256 + cand_bytes;
     CK_HIP(hipMalloc(&ws.d_fit_scratch, ws.fit_scratch_bytes));

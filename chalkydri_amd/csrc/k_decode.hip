@@ -306,7 +306,7 @@ int ck_launch_decode(ck_handle *h, const uint8_t *frames, int stride, size_t pit
     a.sharpening = h->cfg.decode_sharpening; a.max_hamming = h->cfg.max_hamming; a.n_families = h->cfg.n_families;
     a.fams = h->d_fams; a.ws = ws;
     // candidate buffer lives behind the work lists in the fit scratch
-    const size_t list_bytes = ((size_t)3 * ws.cluster_cap * h->cfg.max_batch + 16) * sizeof(uint32_t);
+    const size_t list_bytes = ((size_t)CK_FIT_CLASSES * ws.cluster_cap * h->cfg.max_batch + 16) * sizeof(uint32_t);
     uint8_t *base = reinterpret_cast<uint8_t *>(ws.d_fit_scratch) + ((list_bytes + 255) / 256) * 256;
     a.cand_cap = ws.quad_cap * h->cfg.n_families;
     a.cand_count = reinterpret_cast<uint32_t *>(base);

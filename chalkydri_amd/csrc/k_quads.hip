@@ -364,7 +364,7 @@ __device__ void refine_edge(const FitArgs &a, const uint8_t *im, const double p[
 // Diagnostic build only (-DCK_FIT_PROFILE): per-phase cycle totals of k_fit, written to a buffer of their own.
 #ifdef CK_FIT_PROFILE
 __device__ unsigned long long g_fit_prof[3][16];
-#define PROF_DECL unsigned long long prof_t0 = __builtin_readcyclecounter(); const int prof_cls = (CAP == 512) ? 0 : (CAP == 4096 ? 1 : 2)
+#define PROF_DECL unsigned long long prof_t0 = __builtin_readcyclecounter(); const int prof_cls = (CAP == 512) ? 0 : (CAP <= 4096 ? 1 : 2)
 #define PROF(k) do { unsigned long long t_ = __builtin_readcyclecounter(); if (tid == 0) atomicAdd(&g_fit_prof[prof_cls][k], t_ - prof_t0); prof_t0 = t_; } while (0)
 #else
 #define PROF_DECL
@@ -1335,7 +1335,7 @@ __global__ __launch_bounds__(256) void k_weight_image(const uint8_t *__restrict_
     wimg[i] = (uint16_t)W;
 }
 
-// builds the three per-size-class work lists from the cluster tables
+// builds the per-size-class work lists from the cluster tables
 __global__ __launch_bounds__(256) void k_classify(ck_stage_ws ws, int n, uint32_t *lists, uint32_t *list_counts, int list_cap) {
     const int frame = blockIdx.y;
     const uint32_t *counters = ws.d_counters + (size_t)frame * CK_CNT_STRIDE;
@@ -1345,8 +1345,8 @@ __global__ __launch_bounds__(256) void k_classify(ck_stage_ws ws, int n, uint32_
     for (uint32_t i0 = blockIdx.x * 256; i0 < nc; i0 += gridDim.x * 256) {
         uint32_t i = i0 + threadIdx.x;
         int k = -1;
-        if (i < nc) { uint32_t c = cls[i].count; k = c <= 512 ? 0 : (c <= 4096 ? 1 : 2); }
-        for (int kk = 0; kk < 3; kk++) { // one atomic per wave and class (ballot + prefix popcount)
+        if (i < nc) { uint32_t c = cls[i].count; k = c <= 512 ? 0 : (c <= 2048 ? 1 : (c <= 4096 ? 2 : 3)); }
+        for (int kk = 0; kk < CK_FIT_CLASSES; kk++) { // one atomic per wave and class (ballot + prefix popcount)
             unsigned long long m = __ballot(k == kk);
             if (!m) continue;
             uint32_t base = 0;
@@ -1362,7 +1362,7 @@ __global__ __launch_bounds__(256) void k_classify(ck_stage_ws ws, int n, uint32_
 }
 __global__ void k_clamp_counts(uint32_t *list_counts, int list_cap, ck_stage_ws ws, int n) {
     int t = threadIdx.x;
-    if (t < 3 && list_counts[t] > (uint32_t)list_cap) list_counts[t] = (uint32_t)list_cap;
+    if (t < CK_FIT_CLASSES && list_counts[t] > (uint32_t)list_cap) list_counts[t] = (uint32_t)list_cap;
     for (int f = t; f < n; f += blockDim.x) {
         uint32_t *c = ws.d_counters + (size_t)f * CK_CNT_STRIDE;
         if (c[CK_CNT_QUADS] > (uint32_t)ws.quad_cap) c[CK_CNT_QUADS] = (uint32_t)ws.quad_cap;
@@ -1384,12 +1384,12 @@ int ck_launch_fit_quads(ck_handle *h, const uint8_t *qframes, int qstride, size_
                         size_t pitch, int n) {
     ck_stage_ws &ws = h->ws;
     if (n > 4095 || ws.cluster_cap > (1 << 20)) return CK_EINVAL;
-    // work lists live in the fit scratch: [3][list_cap] entries + 3 counts + 3 heads
+    // work lists live in the fit scratch: [CK_FIT_CLASSES][list_cap] entries + counts + heads
     const int list_cap = ws.cluster_cap * h->cfg.max_batch;
     uint32_t *lists = reinterpret_cast<uint32_t *>(ws.d_fit_scratch);
-    uint32_t *list_counts = lists + (size_t)3 * list_cap;
-    uint32_t *heads = list_counts + 4;
-    CK_HIP(hipMemsetAsync(list_counts, 0, sizeof(uint32_t) * 8, h->stream));
+    uint32_t *list_counts = lists + (size_t)CK_FIT_CLASSES * list_cap;
+    uint32_t *heads = list_counts + 8;
+    CK_HIP(hipMemsetAsync(list_counts, 0, sizeof(uint32_t) * 16, h->stream));
     unsigned bx = (unsigned)((ws.cluster_cap + 255) / 256);
     if (bx > 64) bx = 64;
     hipLaunchKernelGGL(k_classify, dim3(bx, (unsigned)n), dim3(256), 0, h->stream, ws, n, lists, list_counts, list_cap);
@@ -1432,8 +1432,10 @@ int ck_launch_fit_quads(ck_handle *h, const uint8_t *qframes, int qstride, size_
     a.list = lists; a.list_count = list_counts; a.head = heads;
     hipLaunchKernelGGL((k_fit<64, 512, 64, true, 3>), dim3((unsigned)(cus * 12)), dim3(64), 0, h->stream, a);
     a.list = lists + list_cap; a.list_count = list_counts + 1; a.head = heads + 1;
-    hipLaunchKernelGGL((k_fit<256, 4096, 256, true, 2>), dim3((unsigned)(cus * 2)), dim3(256), 0, h->stream, a);
+    hipLaunchKernelGGL((k_fit<256, 2048, 256, true, 3>), dim3((unsigned)(cus * 3)), dim3(256), 0, h->stream, a);
     a.list = lists + 2 * (size_t)list_cap; a.list_count = list_counts + 2; a.head = heads + 2;
+    hipLaunchKernelGGL((k_fit<256, 4096, 256, true, 2>), dim3((unsigned)(cus * 2)), dim3(256), 0, h->stream, a);
+    a.list = lists + 3 * (size_t)list_cap; a.list_count = list_counts + 3; a.head = heads + 3;
     hipLaunchKernelGGL((k_fit<512, 16384, 256, false, 2>), dim3((unsigned)cus), dim3(512), 0, h->stream, a);
     hipLaunchKernelGGL(k_clamp_counts, dim3(1), dim3(64), 0, h->stream, list_counts, list_cap, ws, n);
     CK_HIP(hipGetLastError());
