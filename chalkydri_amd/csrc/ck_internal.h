@@ -40,13 +40,12 @@ struct ck_dev_family {
 // size classes of the quad fit (k_quads.hip): <= 512, <= 2048, <= 4096, <= 16384 points per cluster
 constexpr int CK_FIT_CLASSES = 4;
 
-struct ck_tmp_point {
-    uint32_t slot;  // hash-table slot of its cluster
-    uint32_t rank;  // position inside the cluster
-    uint16_t x, y;  // half-pixel coordinates
-    int8_t gx, gy;
-    uint16_t pad;
-};
+// A boundary point on its way from k_emit to k_scatter, packed into 64 bits:
+// [slot:20][rank:15][x:13][y:13][direction:2][sign:1] — slot = hash-table slot of its cluster, rank = position inside the
+// cluster (saturating: clusters that long are dropped anyway), x/y half-pixel coordinates, direction = which of the four
+// forward neighbours (1,0),(0,1),(-1,1),(1,1) the pair spans, sign = 1 when the gradient points along it.
+typedef unsigned long long ck_tmp_point;
+constexpr uint32_t CK_TMP_RANK_MAX = 32767;
 
 // Workspace of the irregular stages, sized for cfg.max_batch frames
 struct ck_stage_ws {

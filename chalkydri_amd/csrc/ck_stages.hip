@@ -15,7 +15,7 @@ int ck_stage_alloc(ck_handle *h) {
     ws.point_cap = cfg.max_points_per_frame > 0 ? cfg.max_points_per_frame : 2 * npix;
     ws.cluster_cap = cfg.max_clusters_per_frame > 0 ? cfg.max_clusters_per_frame : npix / 32;
     if (ws.cluster_cap < 1024) ws.cluster_cap = 1024;
-    if (ws.cluster_cap > (1 << 20) - 1) ws.cluster_cap = (1 << 20) - 1;
+    if (ws.cluster_cap > (1 << 19)) ws.cluster_cap = 1 << 19; // hash slots (2x) must fit the 20-bit field of ck_tmp_point
     ws.quad_cap = cfg.max_quads_per_frame > 0 ? cfg.max_quads_per_frame : 1024;
     ws.det_cap = 256;
     ws.ht_size = next_pow2(2 * ws.cluster_cap);

@@ -183,12 +183,9 @@ __global__ __launch_bounds__(NT) void k_emit(EmitArgs a) {
                 uint32_t ti = tile_base + sTBase[s] + lr;
                 if (ti >= (uint32_t)ws.point_cap) { atomicOr(&counters[CK_CNT_STATUS], (uint32_t)CK_FRAME_POINTS_OVERFLOW); continue; }
                 int v0 = sT[ly][lx], v1 = sT[ly + dys[k]][lx + dxs[k]];
-                ck_tmp_point tp;
-                tp.slot = slot; tp.rank = sBase[s] + lr;
-                tp.x = (uint16_t)(2 * gx + dxs[k]); tp.y = (uint16_t)(2 * gy + dys[k]);
-                int sgn = v1 > v0 ? 1 : -1;
-                tp.gx = (int8_t)(dxs[k] * sgn); tp.gy = (int8_t)(dys[k] * sgn); tp.pad = 0;
-                tmp[ti] = tp;
+                const uint32_t rank = min(sBase[s] + lr, CK_TMP_RANK_MAX);
+                tmp[ti] = ((unsigned long long)slot << 44) | ((unsigned long long)rank << 29) | ((unsigned long long)(2 * gx + dxs[k]) << 16) |
+                          ((unsigned long long)(2 * gy + dys[k]) << 3) | ((unsigned long long)k << 1) | (v1 > v0 ? 1ull : 0ull);
             }
         }
     }
@@ -250,12 +247,15 @@ __global__ __launch_bounds__(NT) void k_scatter(ck_stage_ws ws) {
     const uint32_t *goff = ws.d_ht_off + (size_t)frame * ws.ht_size;
     ck_cluster_point_t *pts = ws.d_points + (size_t)frame * ws.point_cap;
     for (uint32_t i = blockIdx.x * NT + threadIdx.x; i < n; i += gridDim.x * NT) {
-        ck_tmp_point tp = tmp[i];
-        uint32_t off = goff[tp.slot];
+        const ck_tmp_point tp = tmp[i];
+        uint32_t off = goff[(uint32_t)(tp >> 44)];
         if (off == SKIP) continue;
+        const int k = (int)(tp >> 1) & 3, sgn = (tp & 1ull) ? 1 : -1;
+        const int dx = k == 2 ? -1 : (k == 1 ? 0 : 1), dy = k == 0 ? 0 : 1;
         ck_cluster_point_t p;
-        p.x = tp.x; p.y = tp.y; p.gx = tp.gx; p.gy = tp.gy; p.pad = 0;
-        pts[off + tp.rank] = p;
+        p.x = (uint16_t)((tp >> 16) & 0x1FFF); p.y = (uint16_t)((tp >> 3) & 0x1FFF);
+        p.gx = (int8_t)(dx * sgn); p.gy = (int8_t)(dy * sgn); p.pad = 0;
+        pts[off + (uint32_t)((tp >> 29) & 0x7FFF)] = p;
     }
 }
 
