@@ -29,6 +29,7 @@ extern "C" int ck_create(const ck_config_t *cfg, ck_handle_t **out) {
         if (!cfg->families[i] || cfg->families[i]->nbits > 64 || cfg->families[i]->total_width > 16) return CK_EINVAL;
     int qw = cfg->width / cfg->quad_decimate, qh = cfg->height / cfg->quad_decimate;
     if ((qw & 3) || (qh & 3)) return CK_EUNSUPPORTED; // the threshold kernel assumes whole 4x4 tiles
+    if (cfg->min_component_px < 1 || cfg->min_component_px > 127) return CK_EUNSUPPORTED; // tile-local sizes saturate at 127 (k_ccl.hip)
     if (ck_device_count() <= 0) return CK_ENODEVICE;
     ck_handle *h = new (std::nothrow) ck_handle();
     if (!h) return CK_ENOMEM;

@@ -143,4 +143,36 @@ int ck_launch_decode(ck_handle *h, const uint8_t *frames, int stride, size_t pit
 int ck_run_pose(ck_handle *h, int n, const ck_process_params_t *pp, const double *gyro, const uint8_t *has_gyro,
                 ck_vision_measurement_t *out, int32_t *valid);
 
+#ifdef __HIPCC__
+// Wave-wide inclusive sums on the DPP path (no LDS crossbar, no lane-index arithmetic): four row_shr steps inside each
+// row of 16 lanes, then row_bcast:15 into rows 1 and 3 and row_bcast:31 into rows 2 and 3.  Lanes without a source add 0.
+template <int CTRL, int ROWS>
+__device__ __forceinline__ uint32_t dpp0(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROWS, 0xF, true); }
+template <int CTRL, int ROWS>
+__device__ __forceinline__ unsigned long long dpp0_64(unsigned long long v) {
+    return ((unsigned long long)dpp0<CTRL, ROWS>((uint32_t)(v >> 32)) << 32) | dpp0<CTRL, ROWS>((uint32_t)v);
+}
+__device__ __forceinline__ uint32_t wave_scan_u32(uint32_t x) {
+    x += dpp0<0x111, 0xF>(x); x += dpp0<0x112, 0xF>(x); x += dpp0<0x114, 0xF>(x); x += dpp0<0x118, 0xF>(x);
+    x += dpp0<0x142, 0xA>(x); x += dpp0<0x143, 0xC>(x);
+    return x;
+}
+__device__ __forceinline__ unsigned long long wave_scan_u64(unsigned long long x) {
+    x += dpp0_64<0x111, 0xF>(x); x += dpp0_64<0x112, 0xF>(x); x += dpp0_64<0x114, 0xF>(x); x += dpp0_64<0x118, 0xF>(x);
+    x += dpp0_64<0x142, 0xA>(x); x += dpp0_64<0x143, 0xC>(x);
+    return x;
+}
+
+__device__ __forceinline__ int wave_min_i32(int x) { // same DPP ladder with min; lanes without a source keep their own value
+    x = min(x, __builtin_amdgcn_update_dpp(x, x, 0x111, 0xF, 0xF, false));
+    x = min(x, __builtin_amdgcn_update_dpp(x, x, 0x112, 0xF, 0xF, false));
+    x = min(x, __builtin_amdgcn_update_dpp(x, x, 0x114, 0xF, 0xF, false));
+    x = min(x, __builtin_amdgcn_update_dpp(x, x, 0x118, 0xF, 0xF, false));
+    x = min(x, __builtin_amdgcn_update_dpp(x, x, 0x142, 0xA, 0xF, false));
+    x = min(x, __builtin_amdgcn_update_dpp(x, x, 0x143, 0xC, 0xF, false));
+    return __builtin_amdgcn_readlane(x, 63);
+}
+
+#endif // __HIPCC__
+
 #endif

@@ -29,59 +29,80 @@ constexpr int IMG_ROWS = TH + 8;
 constexpr int T4X = TW / 4 + 2, T4Y = TH / 4 + 2;
 constexpr int NSEG = TW / 64;
 
-constexpr int OFF_PARENT = 0;                              // u32[TH*TW]
-constexpr int OFF_UNION = TH * TW * 4;                     // phase A: image + minmax + thr; phase B: sizes
-constexpr int OFF_IMG = OFF_UNION;                         // IMG_ROWS*IMG_PITCH = 11520
+// LDS of k_tile, 26 KB, so that six workgroups (24 waves) share a CU — the union-find is bound by LDS round-trip
+// latency, and resident waves are what hides it:
+//   parent  u16[TH*TW]  tile-local node index of the parent (8192 nodes fit 13 bits); while the threshold is computed
+//                       the same bytes hold the staged image, the 4x4 min/max and the per-4x4 threshold words
+//   size    u8[TH*TW]   at the roots: pixel count saturating at 127 (only "< min_component_px" is ever asked, and
+//                       ck_create refuses min_component_px > 127) | bit 7 = component touches the tile ring
+//   masks   u64[TH][NSEG][2]
+constexpr int OFF_PARENT = 0;                              // u16[TH*TW] = 16384
+constexpr int OFF_IMG = 0;                                 // IMG_ROWS*IMG_PITCH = 11520
 constexpr int OFF_MINMAX = OFF_IMG + IMG_ROWS * IMG_PITCH; // u16[T4Y*T4X] (1224 -> 1280)
 constexpr int OFF_THR = OFF_MINMAX + 1280;                 // u16[(TH/4)*(TW/4)] = 1024
-constexpr int OFF_SIZE = OFF_UNION;                        // packed u16[TH*TW] = 16384 (bit 15 = ring flag)
-constexpr int UNION_BYTES = TH * TW * 2;
-constexpr int OFF_MASK = OFF_UNION + UNION_BYTES;          // u64[TH][NSEG][2]
+constexpr int OFF_SIZE = TH * TW * 2;                      // u8[TH*TW] = 8192
+constexpr int OFF_MASK = OFF_SIZE + TH * TW;               // u64[TH][NSEG][2]
 constexpr int LDS_BYTES = OFF_MASK + TH * NSEG * 2 * 8;
-static_assert(OFF_THR + 1024 <= OFF_UNION + UNION_BYTES, "phase A scratch must fit in the size array");
-static_assert(LDS_BYTES + 2 * (TW + TH) * 2 + 64 <= 53248, "keep three workgroups per CU");
+constexpr uint32_t SIZE_SAT = 127;
+static_assert(OFF_THR + 1024 <= OFF_SIZE, "threshold scratch must fit in the parent array");
+static_assert(LDS_BYTES + 64 <= 27136, "keep six workgroups per CU");
 static_assert(TH * NSEG * 2 == KNT, "k_tile thread mapping: colour x row x segment");
+static_assert(TH * TW <= 65536, "node indices are u16");
 
-// find with path halving.  Plain stores race with the atomicMin hooks of lds_union, but every value ever
-// written to p[a] is an ancestor of a, so the forest stays valid (a lost hook is re-issued by its own union).
-__device__ __forceinline__ uint32_t lds_find(volatile uint32_t *p, uint32_t a) {
-    for (;;) {
-        uint32_t n = p[a];
-        if (n == a) return a;
-        uint32_t g = p[n];
-        if (g == n) return n;
-        p[a] = g;
-        a = g;
-    }
-}
-// read-only find for the flatten phases: there the only stores are owners writing the final root into their
-// own entry, so a halving store from another walker must not be allowed to overwrite one with a stale ancestor
-__device__ __forceinline__ uint32_t lds_find_ro(const volatile uint32_t *p, uint32_t a) {
-    uint32_t n;
-    while ((n = p[a]) != a) a = n;
-    return a;
-}
-// root = smaller index
+// find with path halving.  Plain stores race with the min-hooks of lds_union, but every value ever written to p[a]
+// is an ancestor of a, so the forest stays valid (a lost hook is re-issued by its own union).
 // two halving finds walked in lockstep: both chains have a read in flight at every step (the kernel is bound by LDS
 // round-trip latency, not LDS bandwidth)
-__device__ __forceinline__ void lds_find2(volatile uint32_t *p, uint32_t &a, uint32_t &b) {
+__device__ __forceinline__ void lds_find2(volatile uint16_t *p, uint32_t &a, uint32_t &b) {
     for (;;) {
         uint32_t na = p[a], nb = p[b];
         bool da = (na == a), db = (nb == b);
         if (da && db) return;
         uint32_t ga = p[na], gb = p[nb];
-        if (!da) { if (ga != na) p[a] = ga; a = ga; }
-        if (!db) { if (gb != nb) p[b] = gb; b = gb; }
+        if (!da) { if (ga != na) p[a] = (uint16_t)ga; a = ga; }
+        if (!db) { if (gb != nb) p[b] = (uint16_t)gb; b = gb; }
     }
 }
-__device__ __forceinline__ void lds_union(uint32_t *p, uint32_t a, uint32_t b) {
+// atomic min on one u16 entry (LDS has no 16-bit atomics): compare-and-swap on the word that holds it.  Returns the
+// entry's previous value.  A concurrent halving store to the other half only makes the swap fail and retry.
+__device__ __forceinline__ uint32_t lds_min16(uint16_t *p, uint32_t idx, uint32_t val) {
+    uint32_t *wp = reinterpret_cast<uint32_t *>(p) + (idx >> 1);
+    const uint32_t sh = (idx & 1u) * 16u;
+    uint32_t wv = *reinterpret_cast<volatile uint32_t *>(wp);
+    for (;;) {
+        const uint32_t cur = (wv >> sh) & 0xFFFFu;
+        if (cur <= val) return cur;
+        const uint32_t prev = atomicCAS(wp, wv, (wv & ~(0xFFFFu << sh)) | (val << sh));
+        if (prev == wv) return cur;
+        wv = prev;
+    }
+}
+// root = smaller index
+__device__ __forceinline__ void lds_union(uint16_t *p, uint32_t a, uint32_t b) {
     for (;;) {
         lds_find2(p, a, b);
         if (a == b) return;
         if (a < b) { uint32_t t = a; a = b; b = t; }
-        uint32_t old = atomicMin(&p[a], b);
+        uint32_t old = lds_min16(p, a, b);
         if (old == a) return;
         a = old;
+    }
+}
+// adds `add` pixels (and the ring flag) to the size byte of a root: saturating, and free once nothing would change —
+// the one huge component of a noisy tile saturates after a few adds and every later run only reads
+__device__ __forceinline__ void lds_size_add(uint8_t *sz, uint32_t root, uint32_t add, bool ring) {
+    uint32_t *wp = reinterpret_cast<uint32_t *>(sz) + (root >> 2);
+    const uint32_t sh = (root & 3u) * 8u;
+    uint32_t wv = *reinterpret_cast<volatile uint32_t *>(wp);
+    for (;;) {
+        const uint32_t cur = (wv >> sh) & 0xFFu;
+        uint32_t cnt = (cur & 0x7Fu) + add;
+        cnt = cnt > SIZE_SAT ? SIZE_SAT : cnt;
+        const uint32_t nv = cnt | (cur & 0x80u) | (ring ? 0x80u : 0u);
+        if (nv == cur) return;
+        const uint32_t prev = atomicCAS(wp, wv, (wv & ~(0xFFu << sh)) | (nv << sh));
+        if (prev == wv) return;
+        wv = prev;
     }
 }
 // start bit of the run that contains bit i, given the run-start mask S (bit i's run start is <= i)
@@ -120,23 +141,18 @@ __global__ __launch_bounds__(KNT) void k_tile(const uint8_t *__restrict__ frames
                                              ck_border_root *__restrict__ broots,
                                              uint32_t *__restrict__ broot_count, int broot_cap, int stop_after) {
     __shared__ __attribute__((aligned(16))) uint8_t lds[LDS_BYTES];
-    constexpr int RLIST = 2 * (TW + TH);          // a tile has at most this many ring-touching components
-    __shared__ uint16_t sRootList[RLIST];         // tile-local node index of every ring-touching root
-    __shared__ uint32_t sRootCnt;
     const int tid = threadIdx.x;
-    if (tid == 0) sRootCnt = 0;                    // ordered before its first use by the barriers below
     const int tiles = tiles_x * tiles_y;
     const int frame = blockIdx.x / tiles, tile = blockIdx.x - frame * tiles;
     const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
     const int tx0 = tx * TW, ty0 = ty * TH;
     const uint8_t *img = frames + (size_t)frame * frame_pitch;
     const size_t fbase = (size_t)frame * (size_t)w * (size_t)h;
-    uint32_t *parent = reinterpret_cast<uint32_t *>(lds + OFF_PARENT);
+    uint16_t *parent = reinterpret_cast<uint16_t *>(lds + OFF_PARENT);
+    uint8_t *size8 = lds + OFF_SIZE;
 
     TPROF_DECL;
-    // ---- P0: parent[i] = i; stage the tile and its 4-pixel halo -------------------------------------
-    for (int i = tid * 4; i < TH * TW; i += KNT * 4)
-        *reinterpret_cast<uint4 *>(&parent[i]) = make_uint4(i, i + 1, i + 2, i + 3);
+    // ---- P0: stage the tile and its 4-pixel halo ----------------------------------------------------------
     for (int item = tid; item < IMG_ROWS * 8; item += KNT) {
         int r = item >> 3, c = item & 7;
         int gy = ty0 - 4 + r, gx = tx0 + 16 * c;
@@ -248,8 +264,12 @@ __global__ __launch_bounds__(KNT) void k_tile(const uint8_t *__restrict__ frames
     TPROF(2);
 
     if (stop_after == 2) return; // diagnostics (CK_TILE_STOP_AFTER)
-    // ---- P4: the image scratch is dead; it becomes the size array ---------------------------------------------
-    for (int i = tid * 16; i < UNION_BYTES; i += KNT * 16) *reinterpret_cast<uint4 *>(lds + OFF_SIZE + i) = make_uint4(0, 0, 0, 0);
+    // ---- P4: the image scratch is dead; it becomes the parent array (parent[i] = i), sizes start at zero -------------
+    for (int i = tid * 8; i < TH * TW; i += KNT * 8) {
+        const uint32_t lo = (uint32_t)i | ((uint32_t)(i + 1) << 16);
+        *reinterpret_cast<uint4 *>(&parent[i]) = make_uint4(lo, lo + 0x00020002u, lo + 0x00040004u, lo + 0x00060006u);
+    }
+    for (int i = tid * 16; i < TH * TW; i += KNT * 16) *reinterpret_cast<uint4 *>(size8 + i) = make_uint4(0, 0, 0, 0);
 
     // ---- P5: unions.  thread = (colour, row, segment) --------------------------------------------------------------
     const uint64_t *masks = reinterpret_cast<const uint64_t *>(lds + OFF_MASK);
@@ -303,6 +323,7 @@ __global__ __launch_bounds__(KNT) void k_tile(const uint8_t *__restrict__ frames
     auto up_right_node = [&](int i) -> uint32_t { // bit 0 of the segment on the right always starts a run
         return (i < 63) ? base - TW + (uint32_t)run_start(Su, i + 1) : base - TW + 64;
     };
+    __syncthreads(); // parent[] initialised everywhere before the first adoption lands
     if (stop_after == 3) return; // diagnostics (CK_TILE_STOP_AFTER)
     // ---- P5a: every run adopts ONE earlier run as its parent with a plain store.  Only the owner writes the entry
     // and nothing reads parent[] in this phase, so no find and no atomic is needed for these links; the target always
@@ -316,10 +337,10 @@ __global__ __launch_bounds__(KNT) void k_tile(const uint8_t *__restrict__ frames
             uint64_t above = rest ? (rest & (0ull - rest)) : 0ull;
             uint64_t span = above ? (above - (1ull << i)) : (~0ull << i);
             uint64_t e;
-            if ((e = Ev & span)) { int j = __builtin_ctzll(e); Ev &= ~(1ull << j); parent[base + i] = base - TW + (uint32_t)run_start(Su, j); }
-            else if ((e = DL & span)) { int j = __builtin_ctzll(e); DL &= ~(1ull << j); parent[base + i] = up_left_node(j); }
-            else if ((e = DR & span)) { int j = __builtin_ctzll(e); DR &= ~(1ull << j); parent[base + i] = up_right_node(j); }
-            else if (i == 0 && hleft) { hleft = false; parent[base] = left_node; }
+            if ((e = Ev & span)) { int j = __builtin_ctzll(e); Ev &= ~(1ull << j); parent[base + i] = (uint16_t)(base - TW + (uint32_t)run_start(Su, j)); }
+            else if ((e = DL & span)) { int j = __builtin_ctzll(e); DL &= ~(1ull << j); parent[base + i] = (uint16_t)up_left_node(j); }
+            else if ((e = DR & span)) { int j = __builtin_ctzll(e); DR &= ~(1ull << j); parent[base + i] = (uint16_t)up_right_node(j); }
+            else if (i == 0 && hleft) { hleft = false; parent[base] = (uint16_t)left_node; }
         }
     }
     __syncthreads();
@@ -347,10 +368,13 @@ __global__ __launch_bounds__(KNT) void k_tile(const uint8_t *__restrict__ frames
     __syncthreads(); // halving stores must land before the owners publish final roots
     if (stop_after == 6) return; // diagnostics (CK_TILE_STOP_AFTER)
     // ---- P6: flatten run starts, accumulate sizes and ring flags at the roots ---------------------------------------
-    uint32_t *size32 = reinterpret_cast<uint32_t *>(lds + OFF_SIZE);
     {
         const bool ring_row = (r == 0 && ty0 > 0) || (r == TH - 1 && ty0 + TH < h);
         uint64_t St = S;
+        // consecutive runs of a segment usually end at the same root (in a noisy tile nearly every white run belongs to
+        // the one spanning component): their pixels are summed in registers and flushed once per change of root
+        uint32_t acc_root = 0xFFFFFFFFu, acc_add = 0;
+        bool acc_ring = false;
         while (St) { // four runs per round: their root walks proceed in lockstep
             uint32_t node[4], root[4], add[4];
             bool ring[4], live[4];
@@ -371,7 +395,7 @@ __global__ __launch_bounds__(KNT) void k_tile(const uint8_t *__restrict__ frames
                 }
                 root[q] = node[q];
             }
-            const volatile uint32_t *vp = parent;
+            const volatile uint16_t *vp = parent;
             for (int it = 0; it < 8192; it++) {
                 uint32_t n0 = vp[root[0]], n1 = vp[root[1]], n2 = vp[root[2]], n3 = vp[root[3]];
                 if (n0 == root[0] && n1 == root[1] && n2 == root[2] && n3 == root[3]) break;
@@ -380,79 +404,78 @@ __global__ __launch_bounds__(KNT) void k_tile(const uint8_t *__restrict__ frames
 #pragma unroll
             for (int q = 0; q < 4; q++)
                 if (live[q]) {
-                    parent[node[q]] = root[q];
-                    uint32_t sh = 16 * (root[q] & 1);
-                    atomicAdd(&size32[root[q] >> 1], add[q] << sh);
-                    if (ring[q]) atomicOr(&size32[root[q] >> 1], 0x8000u << sh);
+                    parent[node[q]] = (uint16_t)root[q];
+                    if (root[q] == acc_root) { acc_add += add[q]; acc_ring = acc_ring || ring[q]; }
+                    else {
+                        if (acc_root != 0xFFFFFFFFu) lds_size_add(size8, acc_root, acc_add, acc_ring);
+                        acc_root = root[q]; acc_add = add[q]; acc_ring = ring[q];
+                    }
                 }
         }
+        if (acc_root != 0xFFFFFFFFu) lds_size_add(size8, acc_root, acc_add, acc_ring);
     }
     __syncthreads();
     TPROF(4);
 
     if (stop_after == 7) return; // diagnostics (CK_TILE_STOP_AFTER)
     // ---- P7: write label words (16 pixels per item) -------------------------------------------------------------------
-    const uint16_t *size16 = reinterpret_cast<const uint16_t *>(lds + OFF_SIZE);
-    for (int item = tid; item < TH * 8; item += KNT) {
+    const uint32_t nitems = TH * 8;
+    for (uint32_t item0 = 0; item0 < nitems; item0 += KNT) { // uniform trip count: the ring-root append below votes per wave
+        const int item = (int)item0 + tid;
         int rr = item >> 3, c = item & 7;
         int gy = ty0 + rr, gx = tx0 + 16 * c;
-        if (gy >= h || gx >= w) continue;
-        int seg = c >> 2, piece = c & 3;
-        uint64_t Wm = masks[(rr * NSEG + seg) * 2], Bm = masks[(rr * NSEG + seg) * 2 + 1];
-        uint64_t Oo = origin_mask(tx0 + 64 * seg, w);
-        uint64_t SW = Wm & ~((Wm << 1) & Oo), SB = Bm & ~((Bm << 1) & Oo);
-        uint32_t sbase = (uint32_t)(rr * TW + 64 * seg);
+        uint32_t nroots = 0;
+        uint32_t roots_mask = 0;
         uint32_t outw[16];
+        const bool inside = gy < h && gx < w;
+        int seg = c >> 2, piece = c & 3;
+        uint32_t sbase = (uint32_t)(rr * TW + 64 * seg);
+        if (inside) {
+            uint64_t Wm = masks[(rr * NSEG + seg) * 2], Bm = masks[(rr * NSEG + seg) * 2 + 1];
+            uint64_t Oo = origin_mask(tx0 + 64 * seg, w);
+            uint64_t SW = Wm & ~((Wm << 1) & Oo), SB = Bm & ~((Bm << 1) & Oo);
 #pragma unroll
-        for (int k = 0; k < 16; k++) {
-            int bit = 16 * piece + k;
-            uint32_t word = CK_LBL_INVALID;
-            bool isw = (Wm >> bit) & 1ull, isb = (Bm >> bit) & 1ull;
-            if (isw || isb) {
-                uint32_t node = sbase + run_start(isw ? SW : SB, bit);
-                uint32_t root = parent[node];
-                uint32_t sw = size16[root];
-                uint32_t gidx = (uint32_t)(ty0 + (int)(root / TW)) * (uint32_t)w + (uint32_t)(tx0 + (int)(root % TW));
-                word = gidx | ((sw & 0x8000u) ? CK_LBL_BORDER : ((int)(sw & 0x7FFFu) < min_comp ? CK_LBL_SMALL : 0u));
+            for (int k = 0; k < 16; k++) {
+                int bit = 16 * piece + k;
+                uint32_t word = CK_LBL_INVALID;
+                bool isw = (Wm >> bit) & 1ull, isb = (Bm >> bit) & 1ull;
+                if (isw || isb) {
+                    uint32_t node = sbase + run_start(isw ? SW : SB, bit);
+                    uint32_t root = parent[node];
+                    uint32_t sw = size8[root];
+                    uint32_t gidx = (uint32_t)(ty0 + (int)(root / TW)) * (uint32_t)w + (uint32_t)(tx0 + (int)(root % TW));
+                    word = gidx | ((sw & 0x80u) ? CK_LBL_BORDER : ((int)(sw & 0x7Fu) < min_comp ? CK_LBL_SMALL : 0u));
+                    // a ring-touching root: a run start whose label word points at itself
+                    if ((sw & 0x80u) && root == sbase + (uint32_t)bit) roots_mask |= 1u << k;
+                }
+                outw[k] = word;
             }
-            outw[k] = word;
-        }
-        uint32_t *dst = labels + fbase + (size_t)gy * w + gx;
+            uint32_t *dst = labels + fbase + (size_t)gy * w + gx;
 #pragma unroll
-        for (int q = 0; q < 4; q++)
-            if (gx + 4 * q < w)
-                *reinterpret_cast<uint4 *>(dst + 4 * q) = make_uint4(outw[4 * q], outw[4 * q + 1], outw[4 * q + 2], outw[4 * q + 3]);
-        // ring-touching roots that start in this 16-pixel chunk: a root is a run start whose label word points at itself
-        uint32_t chunk_bits = 0xFFFFu << (16 * piece);
-        uint64_t starts = (SW | SB) & (uint64_t)0xFFFF << (16 * piece);
-        (void)chunk_bits;
-        while (starts) {
-            int bit = __builtin_ctzll(starts);
-            starts &= starts - 1;
-            uint32_t word = outw[bit - 16 * piece];
-            uint32_t self = (uint32_t)gy * (uint32_t)w + (uint32_t)(tx0 + 64 * seg + bit);
-            if ((word & CK_LBL_BORDER) && (word & CK_LBL_IDX_MASK) == self) {
-                uint32_t node = sbase + (uint32_t)bit;
-                uint32_t pos = atomicAdd(&sRootCnt, 1u);
-                if (pos < RLIST) sRootList[pos] = (uint16_t)node;
-            }
+            for (int q = 0; q < 4; q++)
+                if (gx + 4 * q < w)
+                    *reinterpret_cast<uint4 *>(dst + 4 * q) = make_uint4(outw[4 * q], outw[4 * q + 1], outw[4 * q + 2], outw[4 * q + 3]);
+            nroots = (uint32_t)__popc(roots_mask);
         }
-    }
-    __syncthreads();
-    // ---- P8: one global reservation per tile for its ring-touching roots, then a coalesced copy of the list -----------
-    {
-        __shared__ uint32_t sRootBase;
-        uint32_t cnt = min(sRootCnt, (uint32_t)RLIST);
-        if (tid == 0 && cnt) sRootBase = atomicAdd(&broot_count[frame], cnt);
-        __syncthreads();
-        for (uint32_t i = tid; i < cnt; i += KNT) {
-            uint32_t pos = sRootBase + i;
-            if (pos < (uint32_t)broot_cap) {
-                uint32_t node = sRootList[i];
-                ck_border_root br;
-                br.root = (uint32_t)(ty0 + (int)(node / TW)) * (uint32_t)w + (uint32_t)(tx0 + (int)(node % TW));
-                br.size = size16[node] & 0x7FFFu;
-                broots[(size_t)frame * broot_cap + pos] = br;
+        // ---- P8: ring-touching roots go to the frame's list: one global reservation per wave and round -----------------
+        const uint32_t incl = wave_scan_u32(nroots);
+        const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        if (total) {
+            uint32_t wbase = 0;
+            if ((tid & 63) == 63) wbase = atomicAdd(&broot_count[frame], total);
+            wbase = (uint32_t)__builtin_amdgcn_readlane((int)wbase, 63);
+            uint32_t pos = wbase + incl - nroots;
+            while (roots_mask) {
+                int k = __builtin_ctz(roots_mask);
+                roots_mask &= roots_mask - 1;
+                if (pos < (uint32_t)broot_cap) {
+                    uint32_t node = sbase + (uint32_t)(16 * piece + k);
+                    ck_border_root br;
+                    br.root = (uint32_t)gy * (uint32_t)w + (uint32_t)(tx0 + 64 * seg + 16 * piece + k);
+                    br.size = size8[node] & 0x7Fu;
+                    broots[(size_t)frame * broot_cap + pos] = br;
+                }
+                pos++;
             }
         }
     }

@@ -94,7 +94,7 @@ typedef struct ck_config {
     /* AprilTag-3 detector defaults the reference inherits unchanged */
     int32_t quad_decimate;        /* 1 (full resolution) or 2 (AT3 default) */
     int32_t min_white_black_diff; /* 5 */
-    int32_t min_component_px;     /* 25: components smaller than this emit no boundary points */
+    int32_t min_component_px;     /* 25: components smaller than this emit no boundary points (1..127) */
     int32_t min_cluster_pixels;   /* 24: smallest cluster handed to the quad fitter */
     int32_t max_nmaxima;          /* 10 */
     double cos_critical_rad;      /* cos(10 deg) */
