@@ -687,8 +687,16 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(WPS, 8))) v
     // static striding over the class work list: no dequeue atomics (520 k clusters per batch through one counter cost more
     // than any phase of the fit); clusters of one class are similar enough for the load to even out over ~100 per workgroup
     const uint32_t n_work = *a.list_count;
-    for (uint32_t work = blockIdx.x; work < n_work; work += gridDim.x) {
+    // the big classes hold few, very unequal clusters: they dequeue (one atomic per cluster is nothing there)
+    constexpr bool DYN = CAP > 2048;
+    for (uint32_t work = blockIdx.x;; work += gridDim.x) {
         __syncthreads();
+        if constexpr (DYN) {
+            if (tid == 0) sWork = atomicAdd(a.head, 1u);
+            __syncthreads();
+            work = sWork;
+        }
+        if (work >= n_work) break;
         const uint32_t item = a.list[work];
         const int frame = (int)(item >> 20), ci = (int)(item & 0xFFFFFu);
         const ck_cluster_t cl = ws.d_clusters[(size_t)frame * ws.cluster_cap + ci];
