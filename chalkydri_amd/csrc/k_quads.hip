@@ -1062,15 +1062,33 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(WPS, 8))) v
         if (a.stop_after == 6) continue;
         // ---- 5c. one line fit per ordered pair of maxima; the 4-subset search is then table lookups ------------------------
         PairFit *sF = reinterpret_cast<PairFit *>(sPraw);
-        for (int pr = tid; pr < nsel * nsel; pr += NTH) {
-            int sa = pr / nsel, sb = pr - sa * nsel;
-            if (sa == sb) continue;
-            int N;
-            double lp[4], e, ms;
-            M6 m = rangeM(sa, sb, &N);
-            fit_line_m(m, N, lp, &e, &ms);
-            PairFit f; f.err = e; f.mse = ms; f.nx = lp[2]; f.ny = lp[3];
-            sF[sa * MAXSEL + sb] = f;
+        {   // a one-wave workgroup needs two rounds for its up to 132 pairs: both fits of a lane are issued together so
+            // that their long f64 dependency chains overlap (an unused slot fits pair (0,1) and stores nothing)
+            constexpr int PU = (NTH == 64) ? 2 : 1;
+            const int npairs = nsel * nsel;
+            for (int pr0 = tid; pr0 < npairs; pr0 += PU * NTH) {
+                int sa[PU], sb[PU], Np[PU];
+                bool valid[PU];
+                M6 mm[PU];
+#pragma unroll
+                for (int u = 0; u < PU; u++) {
+                    const int pr = pr0 + u * NTH;
+                    sa[u] = pr / nsel; sb[u] = pr - sa[u] * nsel;
+                    valid[u] = pr < npairs && sa[u] != sb[u];
+                    if (!valid[u]) { sa[u] = 0; sb[u] = 1; }
+                    mm[u] = rangeM(sa[u], sb[u], &Np[u]);
+                }
+                PairFit f[PU];
+#pragma unroll
+                for (int u = 0; u < PU; u++) {
+                    double lp[4], e, ms;
+                    fit_line_m(mm[u], Np[u], lp, &e, &ms);
+                    f[u].err = e; f[u].mse = ms; f[u].nx = lp[2]; f[u].ny = lp[3];
+                }
+#pragma unroll
+                for (int u = 0; u < PU; u++)
+                    if (valid[u]) sF[sa[u] * MAXSEL + sb[u]] = f[u];
+            }
         }
         __syncthreads();
         double best = HUGE_VAL;
@@ -1119,61 +1137,71 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(WPS, 8))) v
         if (best / (double)sz >= a.max_mse) continue;
 
         if (a.stop_after == 7) continue;
-        // ---- 5d. lines, corners, geometric checks (one lane; sequential like the oracle) ---------------------------------------
-        if (tid == 0) {
-            int sel[4] = {(bestc >> 12) & 15, (bestc >> 8) & 15, (bestc >> 4) & 15, bestc & 15};
-            double lines[4][4];
+        // ---- 5d. lines, corners, geometric checks: lane i of the first wave owns side i / corner i, lanes 0 and 1 the two
+        // triangles of the area; every value is formed by the same operations as in the oracle's sequential code, and the
+        // verdict is the conjunction of all checks, so their order does not matter ---------------------------------------------
+        if (tid < 64) {
+            const int li = tid & 3;
+            const int sel[4] = {(bestc >> 12) & 15, (bestc >> 8) & 15, (bestc >> 4) & 15, bestc & 15};
             int ok = 1;
-            for (int i = 0; i < 4 && ok; i++) {
+            double line[4];
+            {
                 int N;
                 double mse;
-                M6 m = rangeM(sel[i], sel[(i + 1) & 3], &N);
-                fit_line_m(m, N, lines[i], nullptr, &mse);
+                M6 m = rangeM(sel[li], sel[(li + 1) & 3], &N);
+                fit_line_m(m, N, line, nullptr, &mse);
                 if (mse > a.max_mse) ok = 0;
             }
-            double P[4][2];
-            for (int i = 0; i < 4 && ok; i++) {
-                int j = (i + 1) & 3;
-                double A00 = lines[i][3], A01 = -lines[j][3], A10 = -lines[i][2], A11 = lines[j][2];
-                double B0 = -lines[i][0] + lines[j][0], B1 = -lines[i][1] + lines[j][1];
+            double ln[4]; // the next side's line
+#pragma unroll
+            for (int q = 0; q < 4; q++) ln[q] = __shfl(line[q], (tid & ~3) | ((li + 1) & 3), 64);
+            double Px, Py;
+            {
+                double A00 = line[3], A01 = -ln[3], A10 = -line[2], A11 = ln[2];
+                double B0 = -line[0] + ln[0], B1 = -line[1] + ln[1];
                 double det = A00 * A11 - A10 * A01;
-                if (fabs(det) < 0.001) { ok = 0; break; }
+                if (fabs(det) < 0.001) ok = 0;
                 double W00 = A11 / det, W01 = -A01 / det;
                 double L0 = W00 * B0 + W01 * B1;
-                P[i][0] = lines[i][0] + L0 * A00;
-                P[i][1] = lines[i][1] + L0 * A10;
+                Px = line[0] + L0 * A00;
+                Py = line[1] + L0 * A10;
             }
-            if (ok) {
-                double area = 0.0;
-                const int tri[2][3] = {{0, 1, 2}, {2, 3, 0}};
-                for (int t = 0; t < 2; t++) {
-                    double len[3];
-                    for (int i = 0; i < 3; i++) {
-                        int pa = tri[t][i], pb = tri[t][(i + 1) % 3];
-                        double ddx = P[pb][0] - P[pa][0], ddy = P[pb][1] - P[pa][1];
-                        len[i] = sqrt(ddx * ddx + ddy * ddy);
-                    }
-                    double pp = (len[0] + len[1] + len[2]) / 2.0;
-                    area += sqrt(pp * (pp - len[0]) * (pp - len[1]) * (pp - len[2]));
+            double P[4][2];
+#pragma unroll
+            for (int q = 0; q < 4; q++) { P[q][0] = __shfl(Px, (tid & ~3) | q, 64); P[q][1] = __shfl(Py, (tid & ~3) | q, 64); }
+            {   // Heron: triangle (0,1,2) on even lanes, (2,3,0) on odd ones; area = first + second
+                const int t = li & 1;
+                const int va = t ? 2 : 0, vb = t ? 3 : 1, vc = t ? 0 : 2;
+                double len[3];
+                const int pa[3] = {va, vb, vc}, pb[3] = {vb, vc, va};
+#pragma unroll
+                for (int i = 0; i < 3; i++) {
+                    double ddx = P[pb[i]][0] - P[pa[i]][0], ddy = P[pb[i]][1] - P[pa[i]][1];
+                    len[i] = sqrt(ddx * ddx + ddy * ddy);
                 }
+                double pp = (len[0] + len[1] + len[2]) / 2.0;
+                double term = sqrt(pp * (pp - len[0]) * (pp - len[1]) * (pp - len[2]));
+                double t0 = __shfl(term, tid & ~3, 64), t1 = __shfl(term, (tid & ~3) | 1, 64);
+                double area = 0.0;
+                area += t0; area += t1;
                 double tw = (double)a.min_tag_width;
                 if (area < 0.95 * tw * tw) ok = 0;
             }
-            for (int i = 0; i < 4 && ok; i++) {
-                int i0 = i, i1 = (i + 1) & 3, i2 = (i + 2) & 3;
+            {
+                const int i0 = li, i1 = (li + 1) & 3, i2 = (li + 2) & 3;
                 double dx1 = P[i1][0] - P[i0][0], dy1 = P[i1][1] - P[i0][1];
                 double dx2 = P[i2][0] - P[i1][0], dy2 = P[i2][1] - P[i1][1];
                 double cs = (dx1 * dx2 + dy1 * dy2) / sqrt((dx1 * dx1 + dy1 * dy1) * (dx2 * dx2 + dy2 * dy2));
                 if (cs > a.cos_critical || cs < -a.cos_critical) ok = 0;
                 if (dx1 * dy2 < dy1 * dx2) ok = 0;
             }
-            if (ok && a.decimate > 1)
-                for (int i = 0; i < 4; i++) {
-                    P[i][0] = (P[i][0] - 0.5) * (double)a.decimate + 0.5;
-                    P[i][1] = (P[i][1] - 0.5) * (double)a.decimate + 0.5;
-                }
-            if (ok) for (int i = 0; i < 4; i++) { sQuad[i][0] = P[i][0]; sQuad[i][1] = P[i][1]; }
-            sFlag = ok;
+            const int all_ok = (__ballot(ok != 0) & 0xFull) == 0xFull;
+            if (tid < 4 && all_ok) {
+                double qx = Px, qy = Py;
+                if (a.decimate > 1) { qx = (qx - 0.5) * (double)a.decimate + 0.5; qy = (qy - 0.5) * (double)a.decimate + 0.5; }
+                sQuad[li][0] = qx; sQuad[li][1] = qy;
+            }
+            if (tid == 0) sFlag = all_ok;
         }
         __syncthreads();
         PROF(9);
