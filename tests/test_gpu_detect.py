@@ -153,10 +153,14 @@ def _same_dets(have, want):
     (640, 480, 4, ("tag36h11",), 3, {"noise_amp": 0, "ramp_amp": 0}),
     (640, 480, 4, ("tag16h5", "tag36h11"), 1, {"family_mode": 1}),   # 16h5 (distance 5) cannot take 3 corrected bits
     (1280, 800, 6, ("tag36h11",), 3, {}),
+    # BASELINE config 5: 5 MP, mixed families (16h5 at one corrected bit needs larger tags to survive the noise)
+    (2448, 2048, 20, ("tag16h5", "tag36h11"), 1, {"family_mode": 1, "truth_min_side": 40}),
 ])
 def test_detect_matches_oracle_and_truth(oracle, w, h, n_tags, fams, bits, kw):
     from chalkydri_amd.detector import AprilTagDetector
     n = 3
+    kw = dict(kw)
+    truth_min_side = kw.pop("truth_min_side", 28)
     frames, truths = synth.render_batch(13, n, w, h, n_tags, fams, **kw)
     det = AprilTagDetector(w, h, max_batch=n, families=fams, bits_corrected=bits)
     got, status = det.detect_batch(frames, cap=64, return_status=True)
@@ -167,8 +171,11 @@ def test_detect_matches_oracle_and_truth(oracle, w, h, n_tags, fams, bits, kw):
         _same_dets(got[i], want)
         # and both agree with the renderer's ground truth: every rendered tag found, corners within 1.5 px
         for t in truths[i]:
-            if min(np.linalg.norm(t["corners"][k] - t["corners"][(k + 1) % 4]) for k in range(4)) < 28:
-                continue   # strongly foreshortened / tiny tags may be missed or loose
+            sides = [np.linalg.norm(t["corners"][k] - t["corners"][(k + 1) % 4]) for k in range(4)]
+            xs, ys = np.asarray(t["corners"])[:, 0], np.asarray(t["corners"])[:, 1]
+            area = 0.5 * abs(np.dot(xs, np.roll(ys, -1)) - np.dot(ys, np.roll(xs, -1)))
+            if min(sides) < truth_min_side or area < 0.35 * max(sides) ** 2:
+                continue   # strongly foreshortened / tiny / near-degenerate tags may be missed or loose
             cand = [d for d in got[i] if (d.family(), d.id()) == (t["family"], t["id"])]
             assert cand, f"tag {t['id']} missed"
             d = min(cand, key=lambda d: np.abs(d.center() - t["center"]).max())

@@ -132,3 +132,35 @@ def test_bench_stream_validity_matches_oracle(oracle):
         assert r.tag_count == out.tag_count == 6
         assert abs(r.pose_x - out.pose_x) < 1e-6 and abs(r.pose_y - out.pose_y) < 1e-6 and abs(r.pose_rot - out.pose_rot) < 1e-7
     task.detector.close()
+
+
+def test_dense_1080p_full_pipeline(oracle):
+    """BASELINE config 3: 1920x1080, 30 tags per frame, detect + SQPnP: records equal the oracle's and recover the pose."""
+    from chalkydri_amd.apriltags import AprilTags
+    w, h, f, n = 1920, 1080, 1000.0, 2
+    layout = scenes.wall_layout(30, cols=10)
+    r2c = {"roll": 0.0, "pitch": 0.0, "yaw": 0.0, "x": 0.2, "y": 0.0, "z": 0.6}
+    calib = scenes.pinhole_calib(f, w / 2.0, h / 2.0)
+    rng = np.random.default_rng(30)
+    frames, truths, gyros = [], [], []
+    for i in range(n):
+        pose = (rng.uniform(0.9, 1.3), rng.uniform(-0.2, 0.2), rng.uniform(-0.05, 0.05))
+        fr, tr = scenes.render_view(3000 + i, w, h, f, layout, pose, r2c, noise_amp=3)
+        frames.append(fr); truths.append(tr); gyros.append(pose[2] + rng.uniform(-0.02, 0.02))
+    frames = np.stack(frames)
+    task = AprilTags(w, h, layout, calib, r2c, cam_id=3, max_batch=n)
+    recs, valid = task.process_batch(frames, gyros)
+    cfg = default_config(w, h)
+    for i in range(n):
+        assert len(truths[i]["tags"]) == 30
+        out = A.VisionMeasurement()
+        v = C.c_int(0)
+        oracle.lib().ora_process_frame(C.c_void_p(frames[i].ctypes.data), w, h, w, C.byref(cfg), C.byref(task._pp),
+                                       C.c_double(gyros[i]), 1, C.byref(out), C.byref(v))
+        r = recs[i]
+        assert bool(v.value) and bool(valid[i])
+        assert r.tag_count == out.tag_count == 30
+        assert abs(r.pose_x - out.pose_x) < 1e-6 and abs(r.pose_y - out.pose_y) < 1e-6 and abs(r.pose_rot - out.pose_rot) < 1e-7
+        assert abs(r.pose_x - truths[i]["twr"][0]) < 0.03 and abs(r.pose_y - truths[i]["twr"][1]) < 0.03
+        assert abs((r.pose_rot - truths[i]["yaw"] + np.pi) % (2 * np.pi) - np.pi) < 0.03
+    task.detector.close()
