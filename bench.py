@@ -129,6 +129,18 @@ def main():
         valid_frac = float(np.count_nonzero(recs["tag_count"] > 0)) / len(recs)
         ms_thr = float(np.mean(thr_ms))
         achieved = ALG_BYTES_PER_PX * w * h * n / (ms_thr * 1e-3) / 1e9
+        # attainable ceiling next to the spec peak: a 1 GiB device-to-device copy, read + write bytes
+        src = torch.empty(1 << 30, dtype=torch.uint8, device=dev)
+        dst = torch.empty_like(src)
+        dst.copy_(src)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            dst.copy_(src)
+        e1.record()
+        torch.cuda.synchronize()
+        copy_gbps = 5 * 2 * (1 << 30) / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        del src, dst
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
         if os.path.exists(tpath):
@@ -145,7 +157,7 @@ def main():
                                    f"noise+-{args.noise}, quad_decimate={args.decimate}, detect+pose, one stream per GPU",
                        "frames_with_pose": round(valid_frac, 4), "gather": "RCCL all_gather of 64-byte records" if world > 1 else "none (1 GPU)"},
             "roofline": {"bound": "hbm", "kernel": "threshold+segment (k_tile + k_merge + k_roots_a/b)", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "measured_copy_GBps": round(copy_gbps, 1),
                          "algorithmic_bytes_per_launch": ALG_BYTES_PER_PX * w * h * n, "avg_launch_ms": round(ms_thr, 4)},
             "stage_ms_last_step": {k: round(v, 3) for k, v in stage.items()},
         }

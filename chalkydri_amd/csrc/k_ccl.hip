@@ -607,7 +607,7 @@ __global__ __launch_bounds__(NT) void k_roots_a(uint32_t *__restrict__ labels, u
 }
 __global__ __launch_bounds__(NT) void k_roots_b(const uint32_t *__restrict__ labels, uint32_t *__restrict__ csize,
                                                 const ck_border_root *__restrict__ broots,
-                                                const uint32_t *__restrict__ broot_count, int broot_cap, size_t npix) {
+                                                const uint32_t *__restrict__ broot_count, int broot_cap, size_t npix, int min_comp) {
     const int frame = blockIdx.y;
     uint32_t n = min(broot_count[frame], (uint32_t)broot_cap);
     const uint32_t *L = labels + (size_t)frame * npix;
@@ -615,7 +615,12 @@ __global__ __launch_bounds__(NT) void k_roots_b(const uint32_t *__restrict__ lab
     for (uint32_t k = blockIdx.x * NT + threadIdx.x; k < n; k += gridDim.x * NT) {
         ck_border_root br = broots[(size_t)frame * broot_cap + k];
         uint32_t g = L[br.root] & CK_LBL_IDX_MASK;
-        if (g != br.root) atomicAdd(&C[g], br.size);
+        if (g == br.root) continue;
+        // csize[] is only ever compared with min_component_px: a part that is large enough on its own settles the answer
+        // with a plain store (thousands of parts of one frame-spanning component would otherwise queue on one address);
+        // small parts still add up exactly
+        if ((int)br.size >= min_comp) __hip_atomic_store(&C[g], SIZE_SAT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else atomicAdd(&C[g], br.size);
     }
 }
 
@@ -677,7 +682,7 @@ int ck_launch_threshold_segment(ck_handle *h, const uint8_t *frames, int stride,
     hipLaunchKernelGGL(k_roots_a, dim3((unsigned)bx, (unsigned)n), dim3(NT), 0, h->stream, h->d_labels, h->d_csize, h->d_broots,
                        h->d_broot_count, h->broot_cap, h->npix);
     hipLaunchKernelGGL(k_roots_b, dim3((unsigned)bx, (unsigned)n), dim3(NT), 0, h->stream, h->d_labels, h->d_csize, h->d_broots,
-                       h->d_broot_count, h->broot_cap, h->npix);
+                       h->d_broot_count, h->broot_cap, h->npix, h->cfg.min_component_px);
     CK_HIP(hipGetLastError());
     return CK_OK;
 }
