@@ -1166,31 +1166,31 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(WPS, 8))) v
                 Px = line[0] + L0 * A00;
                 Py = line[1] + L0 * A10;
             }
-            double P[4][2];
-#pragma unroll
-            for (int q = 0; q < 4; q++) { P[q][0] = __shfl(Px, (tid & ~3) | q, 64); P[q][1] = __shfl(Py, (tid & ~3) | q, 64); }
+            // corners of the other lanes come by shuffle with a computed source lane (an indexed local array would live in
+            // scratch memory)
+            const int g0 = tid & ~3;
+            auto corner_x = [&](int q) { return __shfl(Px, g0 | (q & 3), 64); };
+            auto corner_y = [&](int q) { return __shfl(Py, g0 | (q & 3), 64); };
             {   // Heron: triangle (0,1,2) on even lanes, (2,3,0) on odd ones; area = first + second
                 const int t = li & 1;
                 const int va = t ? 2 : 0, vb = t ? 3 : 1, vc = t ? 0 : 2;
+                const double ax = corner_x(va), ay = corner_y(va), bx = corner_x(vb), by = corner_y(vb), cx = corner_x(vc), cy = corner_y(vc);
                 double len[3];
-                const int pa[3] = {va, vb, vc}, pb[3] = {vb, vc, va};
-#pragma unroll
-                for (int i = 0; i < 3; i++) {
-                    double ddx = P[pb[i]][0] - P[pa[i]][0], ddy = P[pb[i]][1] - P[pa[i]][1];
-                    len[i] = sqrt(ddx * ddx + ddy * ddy);
-                }
+                { double ddx = bx - ax, ddy = by - ay; len[0] = sqrt(ddx * ddx + ddy * ddy); }
+                { double ddx = cx - bx, ddy = cy - by; len[1] = sqrt(ddx * ddx + ddy * ddy); }
+                { double ddx = ax - cx, ddy = ay - cy; len[2] = sqrt(ddx * ddx + ddy * ddy); }
                 double pp = (len[0] + len[1] + len[2]) / 2.0;
                 double term = sqrt(pp * (pp - len[0]) * (pp - len[1]) * (pp - len[2]));
-                double t0 = __shfl(term, tid & ~3, 64), t1 = __shfl(term, (tid & ~3) | 1, 64);
+                double t0 = __shfl(term, g0, 64), t1 = __shfl(term, g0 | 1, 64);
                 double area = 0.0;
                 area += t0; area += t1;
                 double tw = (double)a.min_tag_width;
                 if (area < 0.95 * tw * tw) ok = 0;
             }
             {
-                const int i0 = li, i1 = (li + 1) & 3, i2 = (li + 2) & 3;
-                double dx1 = P[i1][0] - P[i0][0], dy1 = P[i1][1] - P[i0][1];
-                double dx2 = P[i2][0] - P[i1][0], dy2 = P[i2][1] - P[i1][1];
+                const double x1 = corner_x(li + 1), y1 = corner_y(li + 1), x2 = corner_x(li + 2), y2 = corner_y(li + 2);
+                double dx1 = x1 - Px, dy1 = y1 - Py;
+                double dx2 = x2 - x1, dy2 = y2 - y1;
                 double cs = (dx1 * dx2 + dy1 * dy2) / sqrt((dx1 * dx1 + dy1 * dy1) * (dx2 * dx2 + dy2 * dy2));
                 if (cs > a.cos_critical || cs < -a.cos_critical) ok = 0;
                 if (dx1 * dy2 < dy1 * dx2) ok = 0;
