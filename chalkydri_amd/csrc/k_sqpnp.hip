@@ -129,8 +129,14 @@ __device__ void nearest_so3(const double r_vec[9], double out[9]) { // column-ma
         for (int r = 0; r < 3; r++) out[c * 3 + r] = rot[r * 3 + c];
 }
 
-// one SQP refinement on one lane; lhs/rhs are that lane's 15x15 / 15 LDS scratch (lib.rs:98-115, 463-480)
-__device__ double optimization(int max_iter, double tol_sq, double r[9], const double *omega, double *lhs, double *rhs) {
+// One SQP refinement by a group of 16 lanes (lib.rs:98-115, 463-480): lane `gl` of the group owns one row of the
+// 15x15 KKT system [[Omega, J^T], [J, 0]] in registers (lane 15 idles); r and the solution are replicated in every lane.
+// LU with partial pivoting without moving rows: a lane remembers which logical row it holds (`lrow`), the pivot of a
+// column is the unpivoted lane with the largest |entry| (smallest logical row on ties, like the sequential scan), its row
+// is broadcast by shuffles and every other unpivoted lane eliminates in registers.  Each entry sees exactly the operations
+// of the sequential code, in the same order, so the result is bit-identical to it.
+__device__ double optimization16(int max_iter, double tol_sq, double r[9], const double *omega, int gl) {
+    const int row = gl; // 0..14 own a row; 15 computes along on a zero row and is never a pivot
     for (int it = 0; it < max_iter; it++) {
         const double *c1 = r, *c2 = r + 3, *c3 = r + 6;
         double h[6];
@@ -140,62 +146,100 @@ __device__ double optimization(int max_iter, double tol_sq, double r[9], const d
         h[3] = c1[0] * c2[0] + c1[1] * c2[1] + c1[2] * c2[2];
         h[4] = c1[0] * c3[0] + c1[1] * c3[1] + c1[2] * c3[2];
         h[5] = c2[0] * c3[0] + c2[1] * c3[1] + c2[2] * c3[2];
-        for (int i = 0; i < 225; i++) lhs[i] = 0.0;
-        for (int i = 0; i < 9; i++)
-            for (int j = 0; j < 9; j++) lhs[i * 15 + j] = omega[i * 9 + j];
+        // J (6x9), rows: 0:(2c1,0,0) 1:(0,2c2,0) 2:(0,0,2c3) 3:(c2,c1,0) 4:(c3,0,c1) 5:(0,c3,c2)
+        double J[6][9];
+#pragma unroll
+        for (int i = 0; i < 6; i++)
+#pragma unroll
+            for (int j = 0; j < 9; j++) J[i][j] = 0.0;
+#pragma unroll
         for (int k = 0; k < 3; k++) {
-            double J0 = 2.0 * c1[k], J1 = 2.0 * c2[k], J2 = 2.0 * c3[k];
-            // rows of J: 0:(2c1,0,0) 1:(0,2c2,0) 2:(0,0,2c3) 3:(c2,c1,0) 4:(c3,0,c1) 5:(0,c3,c2)
-            lhs[(0 + k) * 15 + 9] = J0; lhs[9 * 15 + 0 + k] = J0;
-            lhs[(3 + k) * 15 + 10] = J1; lhs[10 * 15 + 3 + k] = J1;
-            lhs[(6 + k) * 15 + 11] = J2; lhs[11 * 15 + 6 + k] = J2;
-            lhs[(0 + k) * 15 + 12] = c2[k]; lhs[12 * 15 + 0 + k] = c2[k];
-            lhs[(3 + k) * 15 + 12] = c1[k]; lhs[12 * 15 + 3 + k] = c1[k];
-            lhs[(0 + k) * 15 + 13] = c3[k]; lhs[13 * 15 + 0 + k] = c3[k];
-            lhs[(6 + k) * 15 + 13] = c1[k]; lhs[13 * 15 + 6 + k] = c1[k];
-            lhs[(3 + k) * 15 + 14] = c3[k]; lhs[14 * 15 + 3 + k] = c3[k];
-            lhs[(6 + k) * 15 + 14] = c2[k]; lhs[14 * 15 + 6 + k] = c2[k];
+            J[0][k] = 2.0 * c1[k]; J[1][3 + k] = 2.0 * c2[k]; J[2][6 + k] = 2.0 * c3[k];
+            J[3][k] = c2[k]; J[3][3 + k] = c1[k];
+            J[4][k] = c3[k]; J[4][6 + k] = c1[k];
+            J[5][3 + k] = c3[k]; J[5][6 + k] = c2[k];
         }
-        for (int i = 0; i < 9; i++) {
-            double s = 0;
-            for (int j = 0; j < 9; j++) s += omega[i * 9 + j] * r[j];
-            rhs[i] = -s;
-        }
-        for (int i = 0; i < 6; i++) rhs[9 + i] = -h[i];
-        // LU with partial pivoting
-        bool singular = false;
-        for (int col = 0; col < 15 && !singular; col++) {
-            int piv = col;
-            double best = fabs(lhs[col * 15 + col]);
-            for (int rr = col + 1; rr < 15; rr++)
-                if (fabs(lhs[rr * 15 + col]) > best) { best = fabs(lhs[rr * 15 + col]); piv = rr; }
-            if (best == 0.0) { singular = true; break; }
-            if (piv != col) {
-                for (int k = 0; k < 15; k++) { double t = lhs[col * 15 + k]; lhs[col * 15 + k] = lhs[piv * 15 + k]; lhs[piv * 15 + k] = t; }
-                double t = rhs[col]; rhs[col] = rhs[piv]; rhs[piv] = t;
+        double A[15], b = 0.0;
+#pragma unroll
+        for (int j = 0; j < 15; j++) A[j] = 0.0;
+        if (row < 9) {
+            double sacc = 0;
+#pragma unroll
+            for (int j = 0; j < 9; j++) { const double o = omega[row * 9 + j]; A[j] = o; sacc += o * r[j]; }
+            b = -sacc;
+#pragma unroll
+            for (int i = 0; i < 6; i++) {
+                double v = 0.0;
+#pragma unroll
+                for (int j = 0; j < 9; j++) v = (j == row) ? J[i][j] : v;
+                A[9 + i] = v;
             }
-            for (int rr = col + 1; rr < 15; rr++) {
-                double f = lhs[rr * 15 + col] / lhs[col * 15 + col];
-                if (f == 0.0) continue;
-                for (int k = col; k < 15; k++) lhs[rr * 15 + k] -= f * lhs[col * 15 + k];
-                rhs[rr] -= f * rhs[col];
+        } else if (row < 15) {
+#pragma unroll
+            for (int i = 0; i < 6; i++)
+                if (i == row - 9) {
+#pragma unroll
+                    for (int j = 0; j < 9; j++) A[j] = J[i][j];
+                    b = -h[i];
+                }
+        }
+        int lrow = row;          // logical row currently held by this lane
+        bool pivoted = row >= 15; // lane 15 never takes part
+        bool singular = false;
+#pragma unroll
+        for (int col = 0; col < 15; col++) {
+            // pivot: largest |A[.][col]| among unpivoted lanes, smallest logical row on ties (the sequential scan keeps the
+            // first maximum because it only replaces on a strictly larger value)
+            double best = pivoted ? -1.0 : fabs(A[col]);
+            int bl = pivoted ? 99 : lrow, bs = gl;
+#pragma unroll
+            for (int d = 8; d >= 1; d >>= 1) {
+                const double ob = __shfl_xor(best, d, 16);
+                const int ol = __shfl_xor(bl, d, 16), os = __shfl_xor(bs, d, 16);
+                if (ob > best || (ob == best && ol < bl)) { best = ob; bl = ol; bs = os; }
+            }
+            if (best == 0.0) { singular = true; break; }
+            // the lane that held logical row `col` takes over the pivot lane's logical row (a swap, without moving data)
+            if (!pivoted && lrow == col && gl != bs) lrow = bl;
+            const bool is_piv = gl == bs;
+            if (is_piv) { lrow = col; }
+            double P[15];
+#pragma unroll
+            for (int k = col; k < 15; k++) P[k] = __shfl(A[k], bs, 16);
+            const double pb = __shfl(b, bs, 16);
+            if (is_piv) pivoted = true;
+            else if (!pivoted) {
+                const double f = A[col] / P[col];
+                if (f != 0.0) {
+#pragma unroll
+                    for (int k = col; k < 15; k++) A[k] -= f * P[k];
+                    b -= f * pb;
+                }
             }
         }
         if (singular) break;
+        // back substitution over logical rows 14..0; the owner of a row finishes it and broadcasts the unknown
+        double x[15];
+#pragma unroll
         for (int rr = 14; rr >= 0; rr--) {
-            double s = rhs[rr];
-            for (int k = rr + 1; k < 15; k++) s -= lhs[rr * 15 + k] * rhs[k];
-            rhs[rr] = s / lhs[rr * 15 + rr];
+            double sv = b;
+#pragma unroll
+            for (int k = rr + 1; k < 15; k++) sv -= A[k] * x[k];
+            sv = sv / A[rr];
+            const unsigned long long own = __ballot(lrow == rr && gl < 15);
+            const int src = (int)(__builtin_ctzll((own >> (threadIdx.x & 48)) & 0xFFFFull)); // owner inside this group of 16
+            x[rr] = __shfl(sv, src, 16);
         }
         double n2 = 0;
-        for (int k = 0; k < 9; k++) { r[k] += rhs[k]; n2 += rhs[k] * rhs[k]; }
+#pragma unroll
+        for (int k = 0; k < 9; k++) { r[k] += x[k]; n2 += x[k] * x[k]; }
         if (n2 < tol_sq) break;
     }
     double e = 0;
     for (int i = 0; i < 9; i++) {
-        double s = 0;
-        for (int j = 0; j < 9; j++) s += omega[i * 9 + j] * r[j];
-        e += r[i] * s;
+        double sacc = 0;
+        for (int j = 0; j < 9; j++) sacc += omega[i * 9 + j] * r[j];
+        e += r[i] * sacc;
     }
     return e;
 }
@@ -211,10 +255,10 @@ struct SolveArgs {
     double *world;  // [n][max_points][3]
 };
 
-__global__ __launch_bounds__(64) void k_sqpnp(SolveArgs a) {
+constexpr int SQ_NT = 128; // two waves: six candidate groups of 16 lanes in the refinement, 128-wide loops elsewhere
+__global__ __launch_bounds__(SQ_NT) void k_sqpnp(SolveArgs a) {
     __shared__ double sQrr[81], sQrt[27], sQtt[9], sQttInv[9], sOmega[81], sA[81], sV[81], sW[9];
     __shared__ double sCandR[6][9], sCandE[6];
-    __shared__ double sLhs[6][225], sRhs[6][15];
     __shared__ double sCentroid[3], sRot[2];
     __shared__ int sIdx[9];
     const int lane = threadIdx.x, pi = blockIdx.x;
@@ -229,7 +273,7 @@ __global__ __launch_bounds__(64) void k_sqpnp(SolveArgs a) {
     double *world = a.world + (size_t)pi * a.max_points * 3;
     const double cp[4][3] = {{0, -CORNER_DISTANCE, -CORNER_DISTANCE}, {0, CORNER_DISTANCE, -CORNER_DISTANCE},
                              {0, CORNER_DISTANCE, CORNER_DISTANCE}, {0, -CORNER_DISTANCE, CORNER_DISTANCE}};
-    for (int i = lane; i < n; i += 64) { // corner_points_from_center (lib.rs:379-394)
+    for (int i = lane; i < n; i += SQ_NT) { // corner_points_from_center (lib.rs:379-394)
         int t = i >> 2, c = i & 3;
         double R[9], p[3];
         quat_to_mat(tags[t].q, R);
@@ -244,7 +288,7 @@ __global__ __launch_bounds__(64) void k_sqpnp(SolveArgs a) {
     }
     __syncthreads();
     // build_linear_system (lib.rs:124-180): entry e of [Q_rr(81) | Q_rt(27) | Q_tt(9)] belongs to one lane
-    for (int e = lane; e < 117; e += 64) {
+    for (int e = lane; e < 117; e += SQ_NT) {
         double acc = 0;
         for (int k = 0; k < n; k++) {
             const double *v = p2 + 3 * k;
@@ -275,7 +319,7 @@ __global__ __launch_bounds__(64) void k_sqpnp(SolveArgs a) {
         for (int i = 0; i < 9; i++) sQttInv[i] = inv[i];
     }
     __syncthreads();
-    for (int e = lane; e < 81; e += 64) {
+    for (int e = lane; e < 81; e += SQ_NT) {
         int i = e / 9, j = e - i * 9;
         double t0 = sQrt[i * 3] * sQttInv[0] + sQrt[i * 3 + 1] * sQttInv[3] + sQrt[i * 3 + 2] * sQttInv[6];
         double t1 = sQrt[i * 3] * sQttInv[1] + sQrt[i * 3 + 1] * sQttInv[4] + sQrt[i * 3 + 2] * sQttInv[7];
@@ -319,23 +363,29 @@ __global__ __launch_bounds__(64) void k_sqpnp(SolveArgs a) {
     double Rrc[9];
     quat_to_mat(pr.robot_to_cam.q, Rrc);
     const double fwd[3] = {Rrc[0], Rrc[3], Rrc[6]}; // column 0 (lib.rs:313-318)
-    if (lane < 6) { // solve_rotation_candidates (lib.rs:403-425): lane = 2*t + sign index
-        int t = lane >> 1;
-        double sign = (lane & 1) ? 1.0 : -1.0, guess[9], r[9];
-        for (int k = 0; k < 9; k++) guess[k] = sV[k * 9 + sIdx[t]] * sign;
-        nearest_so3(guess, r);
-        double energy = optimization(a.prm.max_iter, a.prm.tol_sq, r, sOmega, sLhs[lane], sRhs[lane]);
-        double fx = r[0] * fwd[0] + r[1] * fwd[1] + r[2] * fwd[2];
-        double fy = r[3] * fwd[0] + r[4] * fwd[1] + r[5] * fwd[2];
-        double dot = fx * sRot[0] + fy * sRot[1];
-        double ae = 1.0 - dot;
-        if (ae < 0.0) ae = 0.0;
-        energy += pr.sign_change_error * ae;
-        for (int k = 0; k < 9; k++) sCandR[lane][k] = r[k];
-        sCandE[lane] = energy;
+    {   // solve_rotation_candidates (lib.rs:403-425): group g of 16 lanes = candidate 2*t + sign index
+        const int g = lane >> 4, gl = lane & 15;
+        if (g < 6) {
+            int t = g >> 1;
+            double sign = (g & 1) ? 1.0 : -1.0, guess[9], r[9];
+            for (int k = 0; k < 9; k++) guess[k] = sV[k * 9 + sIdx[t]] * sign;
+            nearest_so3(guess, r);
+            double energy = optimization16(a.prm.max_iter, a.prm.tol_sq, r, sOmega, gl);
+            double fx = r[0] * fwd[0] + r[1] * fwd[1] + r[2] * fwd[2];
+            double fy = r[3] * fwd[0] + r[4] * fwd[1] + r[5] * fwd[2];
+            double dot = fx * sRot[0] + fy * sRot[1];
+            double ae = 1.0 - dot;
+            if (ae < 0.0) ae = 0.0;
+            energy += pr.sign_change_error * ae;
+            if (gl == 0) {
+                for (int k = 0; k < 9; k++) sCandR[g][k] = r[k];
+                sCandE[g] = energy;
+            }
+        }
     }
     __syncthreads();
-    if (lane != 0) return;
+    if (lane >= 64) return; // the first wave picks the winner: every lane replays the (cheap) selection, the cheirality test
+                            // over the points is spread over the lanes
     int order[6] = {0, 1, 2, 3, 4, 5};
     for (int i = 1; i < 6; i++) { // stable sort by penalised energy (lib.rs:427)
         int v = order[i], j = i - 1;
@@ -358,13 +408,13 @@ __global__ __launch_bounds__(64) void k_sqpnp(SolveArgs a) {
         mat3_vec(sQttInv, qtr, tl);
         mat3_vec(Rm, sCentroid, Rc);
         for (int k = 0; k < 3; k++) t[k] = -tl[k] - Rc[k];
-        bool front = true;
-        for (int i = 0; i < n && front; i++) {
+        bool behind = false;
+        for (int i = lane; i < n; i += 64) {
             double pc[3];
             mat3_vec(Rm, world + 3 * i, pc);
-            if (!(pc[2] + t[2] > 0.0)) front = false;
+            if (!(pc[2] + t[2] > 0.0)) behind = true;
         }
-        if (!front) continue;
+        if (__ballot(behind)) continue; // uniform: all points must be in front (lib.rs:276-283)
         if (sCandE[order[oi]] < best_score) {
             best_score = sCandE[order[oi]];
             double e = 0;
@@ -379,7 +429,7 @@ __global__ __launch_bounds__(64) void k_sqpnp(SolveArgs a) {
             found = true;
         }
     }
-    if (!found) return;
+    if (!found || lane != 0) return;
     // compute_std_devs (lib.rs:224-246)
     double distance = sqrt(bestT[0] * bestT[0] + bestT[1] * bestT[1] + bestT[2] * bestT[2]);
     {
@@ -545,7 +595,7 @@ extern "C" int ck_sqpnp_solve_batch(ck_handle_t *h, const ck_sqpnp_params_t *par
     if (n_bearings_total) CK_HIP(hipMemcpyAsync(db.p, bearings, sizeof(double) * 3 * (size_t)n_bearings_total, hipMemcpyHostToDevice, h->stream));
     SolveArgs a;
     a.prm = *params; a.problems = dp.p; a.tags = dt.p; a.bearings = db.p; a.out = dr.p; a.n = n; a.max_points = max_pts; a.world = dw.p;
-    hipLaunchKernelGGL(k_sqpnp, dim3((unsigned)n), dim3(64), 0, h->stream, a);
+    hipLaunchKernelGGL(k_sqpnp, dim3((unsigned)n), dim3(SQ_NT), 0, h->stream, a);
     CK_HIP(hipGetLastError());
     CK_HIP(hipMemcpyAsync(out, dr.p, sizeof(ck_sqpnp_result_t) * (size_t)n, hipMemcpyDeviceToHost, h->stream));
     CK_HIP(hipStreamSynchronize(h->stream));
@@ -609,7 +659,7 @@ int ck_run_pose(ck_handle *h, int n, const ck_process_params_t *pp, const double
     SolveArgs a;
     a.prm = pp->sqpnp; a.problems = ws.d_problems; a.tags = ws.d_pose_tags; a.bearings = ws.d_bearings; a.out = ws.d_results; a.n = n;
     a.max_points = ws.det_cap * 4; a.world = ws.d_world;
-    hipLaunchKernelGGL(k_sqpnp, dim3((unsigned)n), dim3(64), 0, h->stream, a);
+    hipLaunchKernelGGL(k_sqpnp, dim3((unsigned)n), dim3(SQ_NT), 0, h->stream, a);
     hipLaunchKernelGGL(k_measure, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, h->stream, ws, ws.d_results, pp->camera_id, ws.d_meas, ws.d_valid, n);
     CK_HIP(hipGetLastError());
     CK_HIP(hipMemcpyAsync(out, ws.d_meas, sizeof(ck_vision_measurement_t) * (size_t)n, hipMemcpyDefault, h->stream));
