@@ -193,49 +193,53 @@ __global__ __launch_bounds__(NT) void k_emit(EmitArgs a) {
 
 // ---- per-frame scan of the hash table -------------------------------------------------------------------------
 constexpr int SNT = 1024;
+// One workgroup per frame; every wave owns a contiguous 1/16 of the table and walks it 64 slots at a time (coalesced
+// reads, DPP wave scans, running offsets in registers): one pass for the wave totals, one to hand out the offsets.
 __global__ __launch_bounds__(SNT) void k_scan(ck_stage_ws ws, int min_cluster, int max_cluster) {
-    __shared__ uint32_t sPts[SNT], sCl[SNT];
-    const int frame = blockIdx.x, tid = threadIdx.x;
+    __shared__ uint32_t sPts[SNT / 64], sCl[SNT / 64];
+    const int frame = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const unsigned long long *gkeys = ws.d_ht_keys + (size_t)frame * ws.ht_size;
     const uint32_t *gcount = ws.d_ht_count + (size_t)frame * ws.ht_size;
     uint32_t *goff = ws.d_ht_off + (size_t)frame * ws.ht_size;
     uint32_t *counters = ws.d_counters + (size_t)frame * CK_CNT_STRIDE;
     ck_cluster_t *clusters = ws.d_clusters + (size_t)frame * ws.cluster_cap;
-    const int per = ws.ht_size / SNT; // ht_size is a multiple of SNT
+    const int seg = ws.ht_size / (SNT / 64); // ht_size is a multiple of SNT, so seg is a multiple of 64
+    const int base = wv * seg;
     uint32_t pts = 0, cl = 0;
-    for (int i = 0; i < per; i++) {
-        uint32_t c = gcount[tid * per + i];
-        if ((int)c >= min_cluster && (int)c <= max_cluster) { pts += c; cl++; }
+    for (int r = 0; r < seg; r += 64) {
+        uint32_t c = gcount[base + r + lane];
+        bool ok = (int)c >= min_cluster && (int)c <= max_cluster;
+        pts += ok ? c : 0u; cl += ok ? 1u : 0u;
     }
-    sPts[tid] = pts; sCl[tid] = cl;
+    pts = (uint32_t)__builtin_amdgcn_readlane((int)wave_scan_u32(pts), 63);
+    cl = (uint32_t)__builtin_amdgcn_readlane((int)wave_scan_u32(cl), 63);
+    if (lane == 0) { sPts[wv] = pts; sCl[wv] = cl; }
     __syncthreads();
-    for (int d = 1; d < SNT; d <<= 1) { // inclusive Hillis-Steele scan
-        uint32_t a = 0, b = 0;
-        if (tid >= d) { a = sPts[tid - d]; b = sCl[tid - d]; }
-        __syncthreads();
-        sPts[tid] += a; sCl[tid] += b;
-        __syncthreads();
-    }
-    uint32_t po = sPts[tid] - pts, co = sCl[tid] - cl;
-    for (int i = 0; i < per; i++) {
-        int e = tid * per + i;
-        uint32_t c = gcount[e];
+    uint32_t po = 0, co = 0;
+    for (int k = 0; k < wv; k++) { po += sPts[k]; co += sCl[k]; }
+    for (int r = 0; r < seg; r += 64) {
+        const int e = base + r + lane;
+        const uint32_t c = gcount[e];
+        const bool ok = (int)c >= min_cluster && (int)c <= max_cluster;
+        const uint32_t ip = wave_scan_u32(ok ? c : 0u), ic = wave_scan_u32(ok ? 1u : 0u);
         uint32_t off = SKIP;
-        if ((int)c >= min_cluster && (int)c <= max_cluster) {
-            if (co < (uint32_t)ws.cluster_cap && po + c <= (uint32_t)ws.point_cap) {
-                off = po;
+        if (ok) {
+            const uint32_t my_po = po + ip - c, my_co = co + ic - 1u;
+            if (my_co < (uint32_t)ws.cluster_cap && my_po + c <= (uint32_t)ws.point_cap) {
+                off = my_po;
                 unsigned long long key = gkeys[e];
                 ck_cluster_t ck;
-                ck.rep0 = (uint32_t)(key >> 32); ck.rep1 = (uint32_t)key; ck.start = po; ck.count = c;
-                clusters[co] = ck;
+                ck.rep0 = (uint32_t)(key >> 32); ck.rep1 = (uint32_t)key; ck.start = my_po; ck.count = c;
+                clusters[my_co] = ck;
             } else atomicOr(&counters[CK_CNT_STATUS], (uint32_t)CK_FRAME_CLUSTERS_OVERFLOW);
-            po += c; co++;
         }
         goff[e] = off;
+        po += (uint32_t)__builtin_amdgcn_readlane((int)ip, 63);
+        co += (uint32_t)__builtin_amdgcn_readlane((int)ic, 63);
     }
     if (tid == SNT - 1) {
-        counters[CK_CNT_CLUSTERS] = min(sCl[tid], (uint32_t)ws.cluster_cap);
-        counters[CK_CNT_POINTS] = min(sPts[tid], (uint32_t)ws.point_cap);
+        counters[CK_CNT_CLUSTERS] = min(co, (uint32_t)ws.cluster_cap);
+        counters[CK_CNT_POINTS] = min(po, (uint32_t)ws.point_cap);
     }
 }
 

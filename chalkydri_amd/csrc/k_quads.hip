@@ -1324,47 +1324,58 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(WPS, 8))) v
 }
 
 // Gradient-magnitude weights of a whole batch in one streaming pass (1 B read, 2 B written per pixel): the fitter then needs
-// ONE 2-byte gather per contour point instead of four byte gathers.
+// ONE 2-byte gather per contour point instead of four byte gathers.  Four pixels per thread: three aligned 4-byte loads (row above, row, row below) plus the two bytes beside the group.
+// Rows are 4-byte aligned (staged frames have 16-byte rows, qw is a multiple of 4).
 __global__ __launch_bounds__(256) void k_weight_image(const uint8_t *__restrict__ qim, size_t qpitch, int qstride, int qw, int qh,
-                                                      uint16_t *__restrict__ wimg, size_t total) {
+                                                      uint16_t *__restrict__ wimg, size_t total4) {
     size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= total) return;
-    size_t npix = (size_t)qw * qh;
-    size_t fr = i / npix, rem = i - fr * npix;
-    int iy = (int)(rem / qw), ix = (int)(rem - (size_t)iy * qw);
-    uint32_t W = 1;
-    if (ix > 0 && ix + 1 < qw && iy > 0 && iy + 1 < qh) {
+    if (i >= total4) return;
+    const int w4 = qw >> 2;
+    const size_t per_frame = (size_t)w4 * qh;
+    const size_t fr = i / per_frame, rem = i - fr * per_frame;
+    const int iy = (int)(rem / w4), ix = 4 * (int)(rem - (size_t)iy * w4);
+    uint16_t out[4] = {1, 1, 1, 1};
+    if (iy > 0 && iy + 1 < qh) {
         const uint8_t *row = qim + fr * qpitch + (size_t)iy * qstride + ix;
-        int gx = (int)row[1] - (int)row[-1];
-        int gy = (int)row[qstride] - (int)row[-qstride];
-        W = isqrt_u32((uint32_t)(gx * gx + gy * gy)) + 1;
+        const uint32_t mid = *reinterpret_cast<const uint32_t *>(row);
+        const uint32_t up = *reinterpret_cast<const uint32_t *>(row - qstride), dn = *reinterpret_cast<const uint32_t *>(row + qstride);
+        const int left = ix > 0 ? (int)row[-1] : 0, right = ix + 4 < qw ? (int)row[4] : 0;
+        const int m[6] = {left, (int)(mid & 255u), (int)((mid >> 8) & 255u), (int)((mid >> 16) & 255u), (int)(mid >> 24), right};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int x = ix + k;
+            if (x > 0 && x + 1 < qw) {
+                const int gx = m[k + 2] - m[k];
+                const int gy = (int)((dn >> (8 * k)) & 255u) - (int)((up >> (8 * k)) & 255u);
+                out[k] = (uint16_t)(isqrt_u32((uint32_t)(gx * gx + gy * gy)) + 1);
+            }
+        }
     }
-    wimg[i] = (uint16_t)W;
+    *reinterpret_cast<uint2 *>(wimg + fr * ((size_t)qw * qh) + (size_t)iy * qw + ix) =
+        make_uint2((uint32_t)out[0] | ((uint32_t)out[1] << 16), (uint32_t)out[2] | ((uint32_t)out[3] << 16));
 }
 
-// builds the per-size-class work lists from the cluster tables
-__global__ __launch_bounds__(256) void k_classify(ck_stage_ws ws, int n, uint32_t *lists, uint32_t *list_counts, int list_cap) {
-    const int frame = blockIdx.y;
+// builds the per-size-class work lists from the cluster tables: one workgroup per frame counts its clusters per class in
+// LDS, reserves the four list ranges with four global atomics, then writes (the lists' internal order is irrelevant)
+__global__ __launch_bounds__(1024) void k_classify(ck_stage_ws ws, int n, uint32_t *lists, uint32_t *list_counts, int list_cap) {
+    __shared__ uint32_t sCnt[CK_FIT_CLASSES], sBase[CK_FIT_CLASSES];
+    const int frame = blockIdx.x, tid = threadIdx.x;
     const uint32_t *counters = ws.d_counters + (size_t)frame * CK_CNT_STRIDE;
     const uint32_t nc = counters[CK_CNT_CLUSTERS];
     const ck_cluster_t *cls = ws.d_clusters + (size_t)frame * ws.cluster_cap;
-    const int lane = threadIdx.x & 63;
-    for (uint32_t i0 = blockIdx.x * 256; i0 < nc; i0 += gridDim.x * 256) {
-        uint32_t i = i0 + threadIdx.x;
-        int k = -1;
-        if (i < nc) { uint32_t c = cls[i].count; k = c <= 512 ? 0 : (c <= 2048 ? 1 : (c <= 4096 ? 2 : 3)); }
-        for (int kk = 0; kk < CK_FIT_CLASSES; kk++) { // one atomic per wave and class (ballot + prefix popcount)
-            unsigned long long m = __ballot(k == kk);
-            if (!m) continue;
-            uint32_t base = 0;
-            int leader = __builtin_ctzll(m);
-            if (lane == leader) base = atomicAdd(&list_counts[kk], (uint32_t)__popcll(m));
-            base = __shfl(base, leader, 64);
-            if (k == kk) {
-                uint32_t pos = base + (uint32_t)__popcll(m & ((1ull << lane) - 1));
-                if (pos < (uint32_t)list_cap) lists[(size_t)kk * list_cap + pos] = ((uint32_t)frame << 20) | i;
-            }
-        }
+    auto class_of = [](uint32_t c) { return c <= 512 ? 0 : (c <= 2048 ? 1 : (c <= 4096 ? 2 : 3)); };
+    if (tid < CK_FIT_CLASSES) sCnt[tid] = 0;
+    __syncthreads();
+    for (uint32_t i = tid; i < nc; i += 1024) atomicAdd(&sCnt[class_of(cls[i].count)], 1u);
+    __syncthreads();
+    if (tid < CK_FIT_CLASSES) { sBase[tid] = sCnt[tid] ? atomicAdd(&list_counts[tid], sCnt[tid]) : 0u; }
+    __syncthreads();
+    if (tid < CK_FIT_CLASSES) sCnt[tid] = 0;
+    __syncthreads();
+    for (uint32_t i = tid; i < nc; i += 1024) {
+        const int k = class_of(cls[i].count);
+        const uint32_t pos = sBase[k] + atomicAdd(&sCnt[k], 1u);
+        if (pos < (uint32_t)list_cap) lists[(size_t)k * list_cap + pos] = ((uint32_t)frame << 20) | i;
     }
 }
 __global__ void k_clamp_counts(uint32_t *list_counts, int list_cap, ck_stage_ws ws, int n) {
@@ -1397,17 +1408,15 @@ int ck_launch_fit_quads(ck_handle *h, const uint8_t *qframes, int qstride, size_
     uint32_t *list_counts = lists + (size_t)CK_FIT_CLASSES * list_cap;
     uint32_t *heads = list_counts + 8;
     CK_HIP(hipMemsetAsync(list_counts, 0, sizeof(uint32_t) * 16, h->stream));
-    unsigned bx = (unsigned)((ws.cluster_cap + 255) / 256);
-    if (bx > 64) bx = 64;
-    hipLaunchKernelGGL(k_classify, dim3(bx, (unsigned)n), dim3(256), 0, h->stream, ws, n, lists, list_counts, list_cap);
+    hipLaunchKernelGGL(k_classify, dim3((unsigned)n), dim3(1024), 0, h->stream, ws, n, lists, list_counts, list_cap);
     hipLaunchKernelGGL(k_clamp_counts, dim3(1), dim3(64), 0, h->stream, list_counts, list_cap, ws, 0);
     FitArgs a;
     a.qim = qframes; a.qw = h->qw; a.qh = h->qh; a.qstride = qstride; a.qpitch = qpitch;
     a.wimg = ws.d_wimg;
     {
-        size_t total = h->npix * (size_t)n;
-        hipLaunchKernelGGL(k_weight_image, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->stream, qframes, qpitch, qstride, h->qw, h->qh,
-                           ws.d_wimg, total);
+        size_t total4 = h->npix / 4 * (size_t)n;
+        hipLaunchKernelGGL(k_weight_image, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, h->stream, qframes, qpitch, qstride, h->qw, h->qh,
+                           ws.d_wimg, total4);
     }
     a.im = frames; a.w = h->w; a.h = h->h; a.stride = stride; a.pitch = pitch;
     a.decimate = h->cfg.quad_decimate; a.refine = h->cfg.refine_edges; a.max_nmaxima = h->cfg.max_nmaxima;
