@@ -139,6 +139,11 @@ int ck_launch_clusters(ck_handle *h, int n);
 int ck_launch_fit_quads(ck_handle *h, const uint8_t *qframes, int qstride, size_t qpitch, const uint8_t *frames, int stride,
                         size_t pitch, int n);
 int ck_launch_decode(ck_handle *h, const uint8_t *frames, int stride, size_t pitch, int n);
+// whole pipeline on device-resident frames (16-byte aligned rows): detections to the host / pose records
+int ck_detect_frames(ck_handle *h, const uint8_t *frames, int stride, size_t pitch, int n, ck_detection_t *dets, int cap, int32_t *counts,
+                     uint32_t *status);
+int ck_process_frames(ck_handle *h, const uint8_t *frames, int stride, size_t pitch, int n, const ck_process_params_t *pp, const double *gyro,
+                      const uint8_t *has_gyro, ck_vision_measurement_t *out, int32_t *valid);
 // glue + SQPnP + measurement on the detections left on the device by the last pipeline run
 int ck_run_pose(ck_handle *h, int n, const ck_process_params_t *pp, const double *gyro, const uint8_t *has_gyro,
                 ck_vision_measurement_t *out, int32_t *valid);

@@ -167,6 +167,15 @@ extern "C" int ck_detect_batch_device(ck_handle_t *h, const uint8_t *d_frames, i
     return fetch_detections(h, n, dets, cap, counts, status);
 }
 
+int ck_detect_frames(ck_handle *h, const uint8_t *frames, int stride, size_t pitch, int n, ck_detection_t *dets, int cap, int32_t *counts,
+                     uint32_t *status) {
+    if (!h || !dets || !counts || cap < 1 || n < 0 || n > h->cfg.max_batch) return CK_EINVAL;
+    CK_HIP(hipEventRecord(h->ev[0], h->stream));
+    int rc = run_pipeline(h, frames, stride, pitch, n, 3);
+    if (rc != CK_OK) return rc;
+    return fetch_detections(h, n, dets, cap, counts, status);
+}
+
 extern "C" int ck_clusters_batch(ck_handle_t *h, const ck_image_u8_t *imgs, int32_t n, ck_cluster_t *clusters, int32_t cluster_cap,
                                  int32_t *n_clusters, ck_cluster_point_t *points, int32_t point_cap, int32_t *n_points) {
     if (!h || !clusters || !n_clusters || !points || !n_points) return CK_EINVAL;
@@ -224,6 +233,13 @@ static int process_common(ck_handle *h, const uint8_t *frames, int stride, size_
     ms.h2d = el(0, 1); ms.threshold = el(1, 2); ms.segment = 0; ms.clusters = el(2, 3); ms.quads = el(3, 4);
     ms.decode = el(4, 5); ms.d2h = el(5, 6); ms.total = el(0, 6); // d2h slot = glue + SQPnP + 64-byte records back
     return rc;
+}
+
+int ck_process_frames(ck_handle *h, const uint8_t *frames, int stride, size_t pitch, int n, const ck_process_params_t *pp, const double *gyro,
+                      const uint8_t *has_gyro, ck_vision_measurement_t *out, int32_t *valid) {
+    if (!h || n < 0 || n > h->cfg.max_batch) return CK_EINVAL;
+    if (n == 0) return CK_OK;
+    return process_common(h, frames, stride, pitch, n, pp, gyro, has_gyro, out, valid);
 }
 
 extern "C" int ck_process_uploaded(ck_handle_t *h, int32_t n, const ck_process_params_t *pp, const double *gyro, const uint8_t *has_gyro,

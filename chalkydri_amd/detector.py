@@ -50,6 +50,17 @@ def _bind(L):
     L.ck_process_batch_device.argtypes = [vp, vp, i32, i32, C.c_int64, _P(A.ProcessParams), vp, vp,
                                           _P(A.VisionMeasurement), _P(i32)]
     L.ck_unproject_opencv5.argtypes = [_P(A.OpenCV5), vp, i32, vp, vp]
+    L.ck_ingest_create.argtypes = [vp, i32, _P(vp)]
+    L.ck_ingest_destroy.argtypes = [vp]
+    L.ck_ingest_destroy.restype = None
+    L.ck_ingest_stride.argtypes = [vp]
+    L.ck_ingest_stride.restype = i32
+    L.ck_ingest_frame.argtypes = [vp, i32, i32]
+    L.ck_ingest_frame.restype = vp
+    L.ck_ingest_write.argtypes = [vp, i32, i32, _P(A.ImageU8), C.c_uint32]
+    L.ck_ingest_submit.argtypes = [vp, i32, i32]
+    L.ck_detect_ingested.argtypes = [vp, i32, _P(A.Detection), i32, _P(i32), u32p]
+    L.ck_process_ingested.argtypes = [vp, i32, _P(A.ProcessParams), vp, vp, _P(A.VisionMeasurement), _P(i32)]
     L._ck_bound = True
     return L
 
@@ -215,3 +226,58 @@ class AprilTagDetector:
             return None, None, n
         arr, keep = _images(frames)
         return arr, keep, len(arr)
+
+
+def fourcc(code):
+    """'GREY' -> the little-endian u32 the C ABI takes (crates/chalkydri/src/cameras/gst_to_cu.rs:171-179)."""
+    b = code.encode("ascii")
+    if len(b) != 4:
+        raise ValueError("fourcc must be exactly 4 characters")
+    return int.from_bytes(b, "little")
+
+
+class IngestRing:
+    """Pinned host slots + asynchronous upload in front of a detector (the pooled host buffers of the reference's camera
+    layer, gst_to_cu.rs:49-72,131-188).  slot_view(s) is a writable numpy view [max_batch][h][stride] of pinned memory."""
+
+    def __init__(self, detector, n_slots=2):
+        self.det, self._L = detector, detector._L
+        g = C.c_void_p()
+        check(self._L.ck_ingest_create(detector._h, n_slots, C.byref(g)), "ck_ingest_create")
+        self._g, self.n_slots = g, n_slots
+        self.stride = self._L.ck_ingest_stride(g)
+
+    def close(self):
+        if self._g:
+            self._L.ck_ingest_destroy(self._g)
+            self._g = None
+
+    def slot_view(self, slot):
+        cfg = self.det.cfg
+        ptr = self._L.ck_ingest_frame(self._g, slot, 0)
+        pitch = self._L.ck_ingest_frame(self._g, slot, 1) - ptr if cfg.max_batch > 1 else self.stride * cfg.height
+        buf = (C.c_uint8 * (pitch * cfg.max_batch)).from_address(ptr)
+        a = np.frombuffer(buf, np.uint8).reshape(cfg.max_batch, pitch)[:, :self.stride * cfg.height]
+        return a.reshape(cfg.max_batch, cfg.height, self.stride)
+
+    def write(self, slot, index, frame, code="GREY"):
+        arr, keep = _images(frame)
+        check(self._L.ck_ingest_write(self._g, slot, index, arr, fourcc(code)), "ck_ingest_write")
+
+    def submit(self, slot, n):
+        check(self._L.ck_ingest_submit(self._g, slot, n), "ck_ingest_submit")
+
+    def detect(self, slot, n, cap=64):
+        dets = (A.Detection * (cap * n))()
+        counts = (C.c_int32 * n)()
+        status = (C.c_uint32 * n)()
+        check(self._L.ck_detect_ingested(self._g, slot, dets, cap, counts, status), "ck_detect_ingested")
+        return [[Detection(dets[i * cap + k]) for k in range(min(counts[i], cap))] for i in range(n)], np.array(status[:])
+
+    def process(self, slot, n, pp, gyro, has_gyro):
+        out = (A.VisionMeasurement * n)()
+        valid = (C.c_int32 * n)()
+        g = np.ascontiguousarray(gyro, np.float64)
+        hg = np.ascontiguousarray(has_gyro, np.uint8)
+        check(self._L.ck_process_ingested(self._g, slot, C.byref(pp), g.ctypes.data, hg.ctypes.data, out, valid), "ck_process_ingested")
+        return out, np.array(valid[:])

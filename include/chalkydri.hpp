@@ -317,6 +317,27 @@ using VisionMeasurement = ck_vision_measurement_t;
 static_assert(sizeof(VisionMeasurement) == 64, "wire record is 64 bytes (crates/whacknet/src/lib.rs:92-95)");
 } // namespace whacknet
 
+// Pinned host slots + asynchronous upload (the pooled host buffers of the camera layer,
+// crates/chalkydri/src/cameras/gst_to_cu.rs:49-72,131-188): write frames, submit the slot, process it; submitting slot
+// k+1 before processing slot k overlaps its upload with the compute.
+class IngestRing {
+  public:
+    IngestRing(const std::shared_ptr<Handle> &h, int n_slots = 2) : h_(h) { check(ck_ingest_create(h_->get(), n_slots, &g_), "ck_ingest_create"); }
+    ~IngestRing() { ck_ingest_destroy(g_); }
+    IngestRing(const IngestRing &) = delete;
+    IngestRing &operator=(const IngestRing &) = delete;
+    int stride() const { return ck_ingest_stride(g_); }
+    uint8_t *frame(int slot, int index) { return ck_ingest_frame(g_, slot, index); }
+    static uint32_t fourcc(const char (&c)[5]) { return (uint32_t)(uint8_t)c[0] | ((uint32_t)(uint8_t)c[1] << 8) | ((uint32_t)(uint8_t)c[2] << 16) | ((uint32_t)(uint8_t)c[3] << 24); }
+    void write(int slot, int index, const ck_image_u8_t &img, uint32_t code) { check(ck_ingest_write(g_, slot, index, &img, code), "ck_ingest_write"); }
+    void submit(int slot, int n) { check(ck_ingest_submit(g_, slot, n), "ck_ingest_submit"); }
+    ck_ingest_t *get() const { return g_; }
+
+  private:
+    std::shared_ptr<Handle> h_;
+    ck_ingest_t *g_ = nullptr;
+};
+
 // crates/apriltags/src/lib.rs:185-192
 struct RobotToCamOffset { double roll = 0, pitch = 0, yaw = 0, x = 0, y = 0, z = 0; };
 
@@ -373,6 +394,20 @@ class AprilTags {
         return process(std::vector<ck_image_u8_t>{img}, std::vector<std::optional<double>>{gyro})[0];
     }
     const ck_process_params_t &params() const { return pp_; }
+    const std::shared_ptr<Handle> &handle() const { return h_; }
+    // the same for a batch that was written into an IngestRing slot and submitted
+    std::vector<std::pair<whacknet::VisionMeasurement, bool>> process(IngestRing &ring, int slot, const std::vector<std::optional<double>> &gyro) {
+        const int n = (int)gyro.size();
+        std::vector<double> g(n);
+        std::vector<uint8_t> has(n);
+        for (int i = 0; i < n; i++) { has[i] = gyro[i].has_value(); g[i] = gyro[i].value_or(0.0); }
+        std::vector<whacknet::VisionMeasurement> out(n);
+        std::vector<int32_t> valid(n);
+        check(ck_process_ingested(ring.get(), slot, &pp_, g.data(), has.data(), out.data(), valid.data()), "ck_process_ingested");
+        std::vector<std::pair<whacknet::VisionMeasurement, bool>> r;
+        for (int i = 0; i < n; i++) r.emplace_back(out[i], valid[i] != 0);
+        return r;
+    }
 
   private:
     Config cfg_;

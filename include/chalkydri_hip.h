@@ -300,6 +300,25 @@ int ck_process_batch_device(ck_handle_t *h, const uint8_t *d_frames, int32_t n, 
 int ck_process_uploaded(ck_handle_t *h, int32_t n, const ck_process_params_t *pp, const double *gyro,
                         const uint8_t *has_gyro, ck_vision_measurement_t *out, int32_t *valid);
 
+/* ---- ingest ring: pinned host slots + asynchronous upload ---------------------------------------------------------------
+ * What the reference's camera layer hands the detector is a pooled host buffer per frame {buf,width,height,stride} in one
+ * of the 8-bit-luma formats (crates/chalkydri/src/cameras/gst_to_cu.rs:49-72,131-188; fourcc GREY/GRAY/Y800, or the Y
+ * plane that leads NV12/NV21/I420/YV12).  A ring owns `n_slots` pinned host buffers and as many device buffers of
+ * max_batch frames each: the caller writes frames into a slot, submits it (one asynchronous copy on the ring's copy
+ * stream) and processes it; submitting slot k+1 before processing slot k overlaps the upload with the compute. */
+typedef struct ck_ingest ck_ingest_t;
+int ck_ingest_create(ck_handle_t *h, int32_t n_slots, ck_ingest_t **out);
+void ck_ingest_destroy(ck_ingest_t *ing);
+int32_t ck_ingest_stride(const ck_ingest_t *ing);                                  /* row stride of a slot frame, bytes */
+uint8_t *ck_ingest_frame(ck_ingest_t *ing, int32_t slot, int32_t index);           /* pinned host memory of one frame */
+/* stride-aware copy of a caller frame into the slot; fourcc as four ASCII bytes, little-endian ("GREY" = 0x59455247) */
+int ck_ingest_write(ck_ingest_t *ing, int32_t slot, int32_t index, const ck_image_u8_t *img, uint32_t fourcc);
+int ck_ingest_submit(ck_ingest_t *ing, int32_t slot, int32_t n);
+int ck_detect_ingested(ck_ingest_t *ing, int32_t slot, ck_detection_t *dets, int32_t cap_per_frame, int32_t *counts,
+                       uint32_t *status);
+int ck_process_ingested(ck_ingest_t *ing, int32_t slot, const ck_process_params_t *pp, const double *gyro,
+                        const uint8_t *has_gyro, ck_vision_measurement_t *out, int32_t *valid);
+
 /* OpenCVModel5 unprojection of pixel points to bearings (x,y,1)/norm; ok[i]=0 when it does not converge. */
 int ck_unproject_opencv5(const ck_opencv5_t *cam, const double *px, int32_t n, double *bearings,
                          uint8_t *ok);

@@ -114,6 +114,13 @@ int main(int argc, char **argv) {
             std::printf("measurement %d ", r.second ? 1 : 0);
             hex(&r.first, sizeof r.first);
             std::printf("\n");
+            {   // the same frame through the pinned ingest ring must give the same 64 bytes
+                IngestRing ring(task.handle(), 2);
+                ring.write(1, 0, img, IngestRing::fourcc("GREY"));
+                ring.submit(1, 1);
+                auto rr = task.process(ring, 1, {gyro});
+                if (rr[0].second != r.second || std::memcmp(&rr[0].first, &r.first, sizeof r.first) != 0) throw Panic("ingest ring result differs");
+            }
             auto none = task.process(img, std::nullopt); // "no gyro, no solve" (crates/apriltags/src/lib.rs:330)
             std::printf("nogyro %d %u\n", none.second ? 1 : 0, (unsigned)none.first.tag_count);
             return 0;
