@@ -62,3 +62,21 @@ def test_process_frame_and_assert(oracle):
     with pytest.raises(AssertionError):
         det.process_frame(rgb[:, :-1])
     det.close()
+
+
+def test_golden_vectors(built):
+    """The HIP CAT path against the committed vectors directly (no oracle in the loop)."""
+    import golden_util as G
+    from chalkydri_amd.cat import CatDetector
+    for c in G.load("cat_golden.json"):
+        rgb = G.cat_rgb(c)
+        det = CatDetector(c["w"], c["h"])
+        assert G.crc(det.thresh(rgb), np.uint8) == c["thresh_crc32"]
+        assert G.crc(det.calc_otsu(rgb), np.uint8) == c["classes_crc32"]
+        pts = det.detect_corners()
+        assert (len(pts), G.crc(pts, np.uint32)) == (c["n_points"], c["points_crc32"])
+        lines = det.check_edges()
+        assert (len(lines), G.crc(lines, np.uint32)) == (c["n_lines"], c["lines_crc32"])
+        uf = det.connected_components()
+        assert G.crc(uf._roots, np.uint32) == c["roots_crc32"] and G.crc(uf._sizes, np.uint32) == c["sizes_crc32"]
+        det.close()

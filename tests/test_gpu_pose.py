@@ -164,3 +164,25 @@ def test_dense_1080p_full_pipeline(oracle):
         assert abs(r.pose_x - truths[i]["twr"][0]) < 0.03 and abs(r.pose_y - truths[i]["twr"][1]) < 0.03
         assert abs((r.pose_rot - truths[i]["yaw"] + np.pi) % (2 * np.pi) - np.pi) < 0.03
     task.detector.close()
+
+
+def test_sqpnp_golden_vectors(built):
+    """The HIP solver against the committed vectors directly (no oracle in the loop), tolerance 1e-9."""
+    import golden_util as G
+    from chalkydri_amd.detector import AprilTagDetector
+    from chalkydri_amd.sqpnp import SqPnP
+    det = AprilTagDetector(64, 64)
+    solver = SqPnP(det)
+    cases = G.load("sqpnp_golden.json")
+    probs = []
+    for c in cases:
+        tags, b, rtc, gyro = G.sqpnp_problem(c)
+        probs.append(([_iso(R, t) for R, t in tags], b, _iso(*rtc), gyro, 600.0))
+    got = solver.solve_batch(probs)
+    for c, g in zip(cases, got):
+        want = G.sqpnp_result(c)
+        assert (want is None) == (g is None)
+        if want is None:
+            continue
+        assert np.abs(g["rot"] - want["rot"]).max() < TOL and np.abs(g["pos"] - want["pos"]).max() < TOL and abs(g["yaw"] - want["yaw"]) < TOL
+    det.close()

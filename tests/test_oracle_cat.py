@@ -89,3 +89,18 @@ def test_corners_edges_components(oracle):
     assert len(set(zip(rep.tolist(), r.tolist()))) == len(set(rep.tolist())) == len(set(r.tolist()))
     assert (sizes.ravel() == psz[rep]).all()
     assert (roots.ravel()[cls.ravel() == 2] == np.arange(cls.size)[cls.ravel() == 2]).all()
+
+
+def test_golden_vectors(oracle):
+    """oracle/cat.c reproduces the committed CRCs of every CAT output (tests/golden/cat_golden.json) — all integer, exact."""
+    import golden_util as G
+    for c in G.load("cat_golden.json"):
+        rgb = G.cat_rgb(c)
+        cls = oracle.cat_calc_otsu(rgb)
+        pts, npn = oracle.cat_detect_corners(cls)
+        lines, nl = oracle.cat_check_edges(cls, pts)
+        roots, sizes = oracle.cat_connected_components(cls)
+        assert G.crc(oracle.cat_thresh(rgb), np.uint8) == c["thresh_crc32"] and G.crc(cls, np.uint8) == c["classes_crc32"]
+        assert (npn, G.crc(pts, np.uint32)) == (c["n_points"], c["points_crc32"])
+        assert (nl, G.crc(lines, np.uint32)) == (c["n_lines"], c["lines_crc32"])
+        assert G.crc(roots, np.uint32) == c["roots_crc32"] and G.crc(sizes, np.uint32) == c["sizes_crc32"]

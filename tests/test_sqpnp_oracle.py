@@ -121,3 +121,21 @@ def test_axis_aligned_wall_is_solved(oracle, seed):
     assert np.array_equal(got["rot"], again["rot"]) and np.array_equal(got["pos"], again["pos"])
     assert np.abs(got["pos"][:2] - truth["twr"][:2]).max() < 0.03
     assert abs((got["yaw"] - truth["yaw"] + np.pi) % (2 * np.pi) - np.pi) < 0.03
+
+
+def test_golden_vectors(oracle):
+    """oracle/sqpnp.c reproduces the committed vectors (tests/golden/sqpnp_golden.json); 1e-12 leaves room for libm's
+    cos/sin/atan2 differing in the last bit between machines, everything else is +-*/sqrt in a fixed order."""
+    import golden_util as G
+    cases = G.load("sqpnp_golden.json")
+    assert len(cases) >= 12
+    for c in cases:
+        tags, b, rtc, gyro = G.sqpnp_problem(c)
+        want, got = G.sqpnp_result(c), oracle.sqpnp_solve(tags, b, rtc, gyro)
+        assert (want is None) == (got is None)
+        if want is None:
+            continue
+        assert np.abs(got["rot"] - want["rot"]).max() < 1e-12 and np.abs(got["pos"] - want["pos"]).max() < 1e-12
+        assert abs(got["yaw"] - want["yaw"]) < 1e-12 and abs(got["energy"] - want["energy"]) < 1e-12
+        if want["energy"] > 1e-13:
+            assert np.allclose(got["std"], want["std"], rtol=1e-9, atol=0)
