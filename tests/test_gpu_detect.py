@@ -195,3 +195,26 @@ def test_detect_is_deterministic_and_batch_invariant(oracle):
         assert [(d.id(), d.corners().tobytes()) for d in x] == [(d.id(), d.corners().tobytes()) for d in y]
         assert [(d.id(), d.corners().tobytes()) for d in x] == [(d.id(), d.corners().tobytes()) for d in z]
     det.close()
+
+
+def test_detector_golden_vectors(built):
+    """The HIP detector against the committed vectors directly (tests/golden/detector_golden.json; no oracle in the loop):
+    ids, hamming, f32 margin and f64 corners bit for bit, including the decimate-2 and mixed-family cases."""
+    import json
+    import os
+    import zlib
+    from chalkydri_amd.detector import AprilTagDetector
+    golden = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "detector_golden.json")))
+    for g in golden:
+        c = g["case"]
+        frame, _ = synth.render(synth.frame_seed(c["seed_cfg"], c["frame"]), c["w"], c["h"], c["n_tags"], tuple(c["families"]), **c["params"])
+        assert zlib.crc32(frame.tobytes()) == g["frame_crc32"], "renderer output changed"
+        det = AprilTagDetector(c["w"], c["h"], max_batch=1, families=tuple(c["families"]), bits_corrected=c["bits"], quad_decimate=c["decimate"])
+        got, status = det.detect_batch(frame[None], cap=64, return_status=True)
+        det.close()
+        assert int(status[0]) == g["status"] and len(got[0]) == len(g["detections"]), c["name"]
+        for d, e in zip(got[0], g["detections"]):
+            assert (d.family(), d.id(), d.hamming()) == (e["family"], e["id"], e["hamming"])
+            assert np.float32(d.decision_margin()) == np.float32(e["margin"])
+            assert [float.fromhex(v) for v in e["center"]] == list(d.center())
+            assert [[float.fromhex(v) for v in p] for p in e["corners"]] == np.asarray(d.corners()).tolist()
