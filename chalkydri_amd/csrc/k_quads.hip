@@ -644,8 +644,9 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(WPS, 8))) v
     constexpr int SL = CH + 2 * HALO;
     // granularity of the cumulative-moment table: fine for the LDS-resident classes so that a selected maximum needs only
     // a few points beyond its table entry (LPM lanes x 4 points), one entry per chunk for the large class
-    constexpr int G = (CAP <= 4096) ? 32 : CH;
-    constexpr int LPM = (NTH >= MAXSEL * 8) ? 8 : 4; // lanes per selected maximum, G / LPM points each
+    constexpr int G = (CAP <= 4096) ? 32 : 128;
+    constexpr int LPM = (CAP > 4096) ? 32 : (NTH >= MAXSEL * 8) ? 8 : 4; // lanes per selected maximum, G / LPM points each
+    static_assert(MAXSEL * LPM <= NTH && CH % G == 0, "one lane group per selected maximum");
     constexpr int NG = CAP / G;
     constexpr int MAXM = MLDS ? CAP / 2 : 1;
     // sKeys holds the 64-bit sort keys; after duplicate removal its first half is reused for the packed
@@ -1002,7 +1003,7 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(WPS, 8))) v
         PROF(6);
         if (a.stop_after == 5) continue;
         // ---- 5b. moment prefix sums at the selected maxima (chunk totals + partial sums inside the chunk) ------------------
-        if constexpr (G <= 32) {
+        {
             // LPM lanes per selected maximum, G / LPM points each: the at most G points beyond the table entry
             if (tid < MAXSEL * LPM) {
                 const int s = tid / LPM, part = tid % LPM;
@@ -1029,20 +1030,6 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(WPS, 8))) v
                     long long sv[6] = {self.Mx, self.My, self.Mxx, self.Mxy, self.Myy, self.W};
 #pragma unroll
                     for (int q = 0; q < 6; q++) { long long v = sTot[blk][q] + pv[q]; sSelI[s][q] = v; sSelE[s][q] = v - sv[q]; }
-                }
-            }
-        } else {
-            for (int s = 0; s < nsel; s++) {
-                const int gi = sSelIdx[s];
-                const int c = gi / G, cb = c * G;
-                M6 part = m6_zero();
-                for (int i = cb + tid; i <= gi; i += NTH) part = m6_add(part, moments_of(sXY[i], sW[i]));
-                long long pv[6] = {part.Mx, part.My, part.Mxx, part.Mxy, part.Myy, part.W};
-                B::reduce_add6(pv, sScratch);
-                if (tid == 0) {
-                    M6 self = moments_of(sXY[gi], sW[gi]);
-                    long long sv[6] = {self.Mx, self.My, self.Mxx, self.Mxy, self.Myy, self.W};
-                    for (int q = 0; q < 6; q++) { sSelI[s][q] = sTot[c][q] + pv[q]; sSelE[s][q] = sSelI[s][q] - sv[q]; }
                 }
             }
         }
