@@ -218,3 +218,31 @@ def test_detector_golden_vectors(built):
             assert np.float32(d.decision_margin()) == np.float32(e["margin"])
             assert [float.fromhex(v) for v in e["center"]] == list(d.center())
             assert [[float.fromhex(v) for v in p] for p in e["corners"]] == np.asarray(d.corners()).tolist()
+
+
+@pytest.mark.parametrize("w,h", [(16, 16), (32, 20), (68, 52), (132, 68), (260, 72), (516, 36)])
+def test_small_and_ragged_frames(oracle, w, h):
+    """Frames much smaller than a 64x128 tile and not multiples of it: binary noise, blobs and a frame-filling square —
+    labels, clusters, quads and detections still equal the oracle's (nothing reads or writes outside the frame)."""
+    from chalkydri_amd.detector import AprilTagDetector
+    rng = np.random.default_rng(w * 1000 + h)
+    f0 = rng.integers(0, 256, (h, w), dtype=np.uint8)                                   # full-contrast noise
+    f1 = np.full((h, w), 30, np.uint8); f1[2:h - 2, 2:w - 2] = 220; f1[4:h - 4, 4:w - 4] = 25   # nested frame-sized squares
+    f2 = np.clip(128 + 100 * np.sin(np.add.outer(np.arange(h) * 0.9, np.arange(w) * 0.7)) + rng.integers(-2, 3, (h, w)), 0, 255).astype(np.uint8)
+    frames = np.stack([f0, f1, f2])
+    det = AprilTagDetector(w, h, max_batch=3)
+    cfg = default_config(w, h)
+    labels, sizes = det.segment(frames)
+    quads = det.quads(frames)
+    dets, status = det.detect_batch(frames, cap=16, return_status=True)
+    for i in range(3):
+        th = oracle.threshold(frames[i])
+        lab, sz = oracle.segment(th)
+        assert np.array_equal(labels[i], lab) and np.array_equal(sizes[i], sz)
+        ocl, opts, _ = oracle.clusters(th, lab, sz)
+        oq, _ = oracle.fit_quads(frames[i], cfg, ocl, opts)
+        assert np.array_equal(_quads_np(oq), _quads_np(quads[i]))
+        want, st = oracle.detect(frames[i], cfg)
+        assert status[i] == st
+        _same_dets(dets[i], want)
+    det.close()
