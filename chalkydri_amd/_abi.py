@@ -102,3 +102,6 @@ class SynthParams(C.Structure):
 
 
 assert C.sizeof(VisionMeasurement) == 64  # crates/whacknet/src/lib.rs:92-95
+
+# per-frame status bits (include/chalkydri_hip.h)
+CK_FRAME_OK, CK_FRAME_POINTS_OVERFLOW, CK_FRAME_CLUSTERS_OVERFLOW, CK_FRAME_QUADS_OVERFLOW, CK_FRAME_DETS_OVERFLOW = 0, 1, 2, 4, 8

@@ -246,3 +246,33 @@ def test_small_and_ragged_frames(oracle, w, h):
         assert status[i] == st
         _same_dets(dets[i], want)
     det.close()
+
+
+def test_capacity_overflow_is_a_status_bit(oracle):
+    """Undersized workspaces never abort or touch memory they do not own: the frame that overflows is flagged
+    (CK_FRAME_*_OVERFLOW), its batch neighbours still equal the oracle."""
+    from chalkydri_amd.detector import AprilTagDetector
+    w, h = 640, 480
+    rng = np.random.default_rng(4)
+    noise = rng.integers(0, 256, (h, w), dtype=np.uint8)
+    tags, _ = synth.render(synth.frame_seed(21, 0), w, h, 4, noise_amp=1)
+    many, _ = synth.render(synth.frame_seed(21, 1), w, h, 12, noise_amp=0, ramp_amp=0, min_side=40, max_side=70)
+    cfg = default_config(w, h)
+    want_tags, _ = oracle.detect(tags, cfg)
+    # points / clusters: a noise frame needs far more than 20 000 points and 2 048 hash slots
+    det = AprilTagDetector(w, h, max_batch=3, max_points_per_frame=20000, max_clusters_per_frame=1024)
+    dets, status = det.detect_batch(np.stack([tags, noise, tags]), cap=64, return_status=True)
+    assert status[1] & (A.CK_FRAME_POINTS_OVERFLOW | A.CK_FRAME_CLUSTERS_OVERFLOW)
+    assert status[0] == 0 and status[2] == 0
+    _same_dets(dets[0], want_tags); _same_dets(dets[2], want_tags)
+    det.close()
+    # quads: twelve clean tags against room for four candidate quads
+    det = AprilTagDetector(w, h, max_batch=2, max_quads_per_frame=4)
+    dets, status = det.detect_batch(np.stack([many, tags]), cap=64, return_status=True)
+    assert status[0] & A.CK_FRAME_QUADS_OVERFLOW and len(dets[0]) <= 4
+    det.close()
+    # detections: the caller's per-frame capacity
+    det = AprilTagDetector(w, h, max_batch=1)
+    dets, status = det.detect_batch(many[None], cap=2, return_status=True)
+    assert status[0] & A.CK_FRAME_DETS_OVERFLOW and len(dets[0]) == 2
+    det.close()
