@@ -39,13 +39,28 @@ struct ck_dev_family {
 // One boundary point while it waits to be grouped (k_clusters.hip)
 // size classes of the quad fit (k_quads.hip): <= 512, <= 2048, <= 4096, <= 16384 points per cluster
 constexpr int CK_FIT_CLASSES = 4;
+constexpr int CK_LSCRATCH_PER_WG = 16384, CK_LSCRATCH_WGS = 1024; // large class: points per cluster, workgroups in its grid (at most)
 
-// A boundary point on its way from k_emit to k_scatter, packed into 64 bits:
-// [slot:20][rank:15][x:13][y:13][direction:2][sign:1] — slot = hash-table slot of its cluster, rank = position inside the
-// cluster (saturating: clusters that long are dropped anyway), x/y half-pixel coordinates, direction = which of the four
-// forward neighbours (1,0),(0,1),(-1,1),(1,1) the pair spans, sign = 1 when the gradient points along it.
-typedef unsigned long long ck_tmp_point;
-constexpr uint32_t CK_TMP_RANK_MAX = 32767;
+// A boundary point inside the pipeline, packed into 32 bits: [x:13][y:13][direction:2][sign:1] at bits 28..16, 15..3, 2..1, 0.
+// x/y are half-pixel coordinates, direction = which of the four forward neighbours (1,0),(0,1),(-1,1),(1,1) the pair
+// spans, sign = 1 when the gradient points along it.  k_emit writes the points of one (tile, cluster) run next to each
+// other; k_scatter moves whole runs to their place inside the cluster; k_fit unpacks.
+typedef uint32_t ck_packed_point;
+__host__ __device__ inline ck_cluster_point_t ck_unpack_point(ck_packed_point v) {
+    const int k = (int)(v >> 1) & 3, sgn = (v & 1u) ? 1 : -1;
+    const int dx = k == 2 ? -1 : (k == 1 ? 0 : 1), dy = k == 0 ? 0 : 1;
+    ck_cluster_point_t p;
+    p.x = (uint16_t)((v >> 16) & 0x1FFFu); p.y = (uint16_t)((v >> 3) & 0x1FFFu);
+    p.gx = (int8_t)(dx * sgn); p.gy = (int8_t)(dy * sgn); p.pad = 0;
+    return p;
+}
+// One (tile, cluster) run of boundary points in the temp array
+struct ck_run {
+    uint32_t slot;      // hash-table slot of the cluster
+    uint32_t base;      // rank of the run's first point inside the cluster
+    uint32_t tmp_start; // where the run starts in the frame's temp array
+    uint32_t count;
+};
 
 // Workspace of the irregular stages, sized for cfg.max_batch frames
 struct ck_stage_ws {
@@ -55,8 +70,11 @@ struct ck_stage_ws {
     unsigned long long *d_ht_keys; // [n][ht_size]  (rep0<<32 | rep1), 0 = empty
     uint32_t *d_ht_count;      // [n][ht_size]
     uint32_t *d_ht_off;        // [n][ht_size] start of the cluster in d_points, or 0xFFFFFFFF
-    ck_tmp_point *d_tmp;       // [n][point_cap]
-    ck_cluster_point_t *d_points; // [n][point_cap]
+    ck_packed_point *d_tmp;    // [n][point_cap] points in emission order (runs)
+    ck_packed_point *d_points; // [n][point_cap] points grouped by cluster
+    ck_run *d_runs;            // [n][run_cap]
+    int run_cap;
+    unsigned long long *d_lscratch; // [CK_LSCRATCH_WGS][CK_LSCRATCH_PER_WG]: sort scratch / maxima list of the large fit class, per workgroup
     ck_cluster_t *d_clusters;  // [n][cluster_cap]
     uint32_t *d_counters;      // [n][8]: 0 tmp points, 1 clusters, 2 kept points, 3 quads, 4 detections, 5 status
     ck_quad_t *d_quads;        // [n][quad_cap]
@@ -81,6 +99,7 @@ struct ck_stage_ws {
 #define CK_CNT_QUADS 3
 #define CK_CNT_DETS 4
 #define CK_CNT_STATUS 5
+#define CK_CNT_RUNS 6
 #define CK_CNT_STRIDE 8
 
 struct ck_handle {

@@ -15,7 +15,7 @@ int ck_stage_alloc(ck_handle *h) {
     ws.point_cap = cfg.max_points_per_frame > 0 ? cfg.max_points_per_frame : 2 * npix;
     ws.cluster_cap = cfg.max_clusters_per_frame > 0 ? cfg.max_clusters_per_frame : npix / 32;
     if (ws.cluster_cap < 1024) ws.cluster_cap = 1024;
-    if (ws.cluster_cap > (1 << 19)) ws.cluster_cap = 1 << 19; // hash slots (2x) must fit the 20-bit field of ck_tmp_point
+    if (ws.cluster_cap > (1 << 19)) ws.cluster_cap = 1 << 19; // keeps the hash table (2x) at most 2^20 slots per frame
     ws.quad_cap = cfg.max_quads_per_frame > 0 ? cfg.max_quads_per_frame : 1024;
     ws.det_cap = 256;
     ws.ht_size = next_pow2(2 * ws.cluster_cap);
@@ -26,8 +26,11 @@ int ck_stage_alloc(ck_handle *h) {
     CK_HIP(hipMalloc(&ws.d_ht_keys, sizeof(unsigned long long) * (size_t)ws.ht_size * nb));
     CK_HIP(hipMalloc(&ws.d_ht_count, sizeof(uint32_t) * (size_t)ws.ht_size * nb));
     CK_HIP(hipMalloc(&ws.d_ht_off, sizeof(uint32_t) * (size_t)ws.ht_size * nb));
-    CK_HIP(hipMalloc(&ws.d_tmp, sizeof(ck_tmp_point) * (size_t)ws.point_cap * nb));
-    CK_HIP(hipMalloc(&ws.d_points, sizeof(ck_cluster_point_t) * (size_t)ws.point_cap * nb));
+    CK_HIP(hipMalloc(&ws.d_tmp, sizeof(ck_packed_point) * (size_t)ws.point_cap * nb));
+    CK_HIP(hipMalloc(&ws.d_points, sizeof(ck_packed_point) * (size_t)ws.point_cap * nb));
+    ws.run_cap = 4 * ws.cluster_cap;
+    CK_HIP(hipMalloc(&ws.d_runs, sizeof(ck_run) * (size_t)ws.run_cap * nb));
+    CK_HIP(hipMalloc(&ws.d_lscratch, sizeof(unsigned long long) * (size_t)CK_LSCRATCH_PER_WG * CK_LSCRATCH_WGS));
     CK_HIP(hipMalloc(&ws.d_clusters, sizeof(ck_cluster_t) * (size_t)ws.cluster_cap * nb));
     CK_HIP(hipMalloc(&ws.d_counters, sizeof(uint32_t) * CK_CNT_STRIDE * nb));
     CK_HIP(hipMalloc(&ws.d_quads, sizeof(ck_quad_t) * (size_t)ws.quad_cap * nb));
@@ -77,7 +80,7 @@ void ck_stage_free(ck_handle *h) {
         (void)hipFree(h->d_fams);
     }
     (void)hipFree(ws.d_ht_keys); (void)hipFree(ws.d_ht_count); (void)hipFree(ws.d_ht_off); (void)hipFree(ws.d_tmp);
-    (void)hipFree(ws.d_points); (void)hipFree(ws.d_clusters); (void)hipFree(ws.d_counters); (void)hipFree(ws.d_quads);
+    (void)hipFree(ws.d_points); (void)hipFree(ws.d_runs); (void)hipFree(ws.d_lscratch); (void)hipFree(ws.d_clusters); (void)hipFree(ws.d_counters); (void)hipFree(ws.d_quads);
     (void)hipFree(ws.d_dets); (void)hipFree(ws.d_fit_scratch); (void)hipFree(ws.d_wimg);
     (void)hipFree(ws.d_field); (void)hipFree(ws.d_gyro); (void)hipFree(ws.d_has_gyro); (void)hipFree(ws.d_problems);
     (void)hipFree(ws.d_pose_tags); (void)hipFree(ws.d_bearings); (void)hipFree(ws.d_world); (void)hipFree(ws.d_results);
@@ -192,7 +195,9 @@ extern "C" int ck_clusters_batch(ck_handle_t *h, const ck_image_u8_t *imgs, int3
         uint32_t nc = counters[(size_t)i * CK_CNT_STRIDE + CK_CNT_CLUSTERS], np = counters[(size_t)i * CK_CNT_STRIDE + CK_CNT_POINTS];
         if ((int)nc > cluster_cap || (int)np > point_cap) return CK_ECAPACITY;
         CK_HIP(hipMemcpy(clusters + (size_t)i * cluster_cap, ws.d_clusters + (size_t)i * ws.cluster_cap, sizeof(ck_cluster_t) * nc, hipMemcpyDeviceToHost));
-        CK_HIP(hipMemcpy(points + (size_t)i * point_cap, ws.d_points + (size_t)i * ws.point_cap, sizeof(ck_cluster_point_t) * np, hipMemcpyDeviceToHost));
+        std::vector<ck_packed_point> packed(np);
+        CK_HIP(hipMemcpy(packed.data(), ws.d_points + (size_t)i * ws.point_cap, sizeof(ck_packed_point) * np, hipMemcpyDeviceToHost));
+        for (uint32_t k = 0; k < np; k++) points[(size_t)i * point_cap + k] = ck_unpack_point(packed[k]);
         n_clusters[i] = (int32_t)nc; n_points[i] = (int32_t)np;
     }
     return CK_OK;

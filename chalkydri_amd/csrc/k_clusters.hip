@@ -7,11 +7,11 @@
 //
 //   k_emit     one workgroup per 16x64 pixel tile: resolves every pixel's component once into LDS (one extra
 //              hop for ring-touching components, see ck_internal.h), aggregates the tile's points per cluster key
-//              in an LDS hash table, then makes ONE global insert + two global atomics per (tile, key) and writes
-//              its points to the temp array with their final rank inside the cluster.
+//              in an LDS hash table, then makes ONE global insert + one add per (tile, key), writes the tile's points to
+//              the temp array as one contiguous run per key (4-byte packed points) and one run record per key.
 //   k_scan     one workgroup per frame: prefix sums over the frame's hash table -> cluster table + point offsets
 //              (clusters outside [min_cluster_pixels, max_cluster_points] are dropped here).
-//   k_scatter  temp points -> points grouped by cluster.
+//   k_scatter  one wave per run: temp array -> points grouped by cluster.
 #include "ck_internal.h"
 
 namespace {
@@ -54,7 +54,7 @@ __global__ __launch_bounds__(NT) void k_emit(EmitArgs a) {
     __shared__ uint32_t sR[LH][LW];
     __shared__ unsigned long long sKey[LHT];
     __shared__ uint32_t sCnt[LHT], sSlot[LHT], sBase[LHT], sTBase[LHT];
-    __shared__ uint32_t sWave[NT / 64 + 1];
+    __shared__ uint32_t sWave[NT / 64 + 1], sRunW[NT / 64 + 1];
     const int tid = threadIdx.x;
     const int tiles = a.tiles_x * a.tiles_y;
     const int frame = blockIdx.x / tiles, tile = blockIdx.x - frame * tiles;
@@ -69,7 +69,8 @@ __global__ __launch_bounds__(NT) void k_emit(EmitArgs a) {
     unsigned long long *gkeys = ws.d_ht_keys + (size_t)frame * ws.ht_size;
     uint32_t *gcount = ws.d_ht_count + (size_t)frame * ws.ht_size;
     uint32_t *counters = ws.d_counters + (size_t)frame * CK_CNT_STRIDE;
-    ck_tmp_point *tmp = ws.d_tmp + (size_t)frame * ws.point_cap;
+    ck_packed_point *tmp = ws.d_tmp + (size_t)frame * ws.point_cap;
+    ck_run *runs = ws.d_runs + (size_t)frame * ws.run_cap;
 
     for (int i = tid; i < LHT; i += NT) { sKey[i] = 0ull; sCnt[i] = 0; }
     for (int i = tid; i < LH * LW; i += NT) {
@@ -145,6 +146,11 @@ __global__ __launch_bounds__(NT) void k_emit(EmitArgs a) {
         uint32_t before = 0, total = 0;
 #pragma unroll
         for (int wv = 0; wv < NT / 64; wv++) { uint32_t t = sWave[wv]; if (wv < (tid >> 6)) before += t; total += t; }
+        // the tile's keys also get consecutive run records: rank of every used slot among the tile's used slots
+        const unsigned long long b0 = __ballot(k0 != 0ull), b1 = __ballot(k1 != 0ull);
+        const unsigned long long below = (1ull << (tid & 63)) - 1ull;
+        const uint32_t ridx0 = (uint32_t)(__popcll(b0 & below) + __popcll(b1 & below));
+        if ((tid & 63) == 0) sRunW[tid >> 6] = (uint32_t)(__popcll(b0) + __popcll(b1));
         if (tid == 0) sWave[NT / 64] = total ? atomicAdd(&counters[CK_CNT_TMP], total) : 0u;
         const uint32_t excl = before + incl - (c0 + c1);
         sTBase[2 * tid] = excl; sTBase[2 * tid + 1] = excl + c0;
@@ -163,8 +169,27 @@ __global__ __launch_bounds__(NT) void k_emit(EmitArgs a) {
             sSlot[s] = found;
             sBase[s] = atomicAdd(&gcount[found], q ? c1 : c0);
         }
+        __syncthreads(); // sRunW complete
+        uint32_t rbefore = 0, rtotal = 0;
+#pragma unroll
+        for (int wv = 0; wv < NT / 64; wv++) { uint32_t t = sRunW[wv]; if (wv < (tid >> 6)) rbefore += t; rtotal += t; }
+        if (tid == 0) sRunW[NT / 64] = rtotal ? atomicAdd(&counters[CK_CNT_RUNS], rtotal) : 0u;
+        __syncthreads();
+        const uint32_t tile_base2 = sWave[NT / 64], run_base = sRunW[NT / 64];
+        uint32_t ri = run_base + rbefore + ridx0;
+        for (int q = 0; q < 2; q++) {
+            const int s = 2 * tid + q;
+            if ((q ? k1 : k0) == 0ull) continue;
+            if (sSlot[s] != SKIP) {
+                if (ri < (uint32_t)ws.run_cap) {
+                    ck_run r;
+                    r.slot = sSlot[s]; r.base = sBase[s]; r.tmp_start = tile_base2 + sTBase[s]; r.count = q ? c1 : c0;
+                    runs[ri] = r;
+                } else atomicOr(&counters[CK_CNT_STATUS], (uint32_t)CK_FRAME_CLUSTERS_OVERFLOW);
+            }
+            ri++;
+        }
     }
-    __syncthreads();
     if (a.stop_after == 2) return;
 
     // pass 3: write the points
@@ -183,9 +208,7 @@ __global__ __launch_bounds__(NT) void k_emit(EmitArgs a) {
                 uint32_t ti = tile_base + sTBase[s] + lr;
                 if (ti >= (uint32_t)ws.point_cap) { atomicOr(&counters[CK_CNT_STATUS], (uint32_t)CK_FRAME_POINTS_OVERFLOW); continue; }
                 int v0 = sT[ly][lx], v1 = sT[ly + dys[k]][lx + dxs[k]];
-                const uint32_t rank = min(sBase[s] + lr, CK_TMP_RANK_MAX);
-                tmp[ti] = ((unsigned long long)slot << 44) | ((unsigned long long)rank << 29) | ((unsigned long long)(2 * gx + dxs[k]) << 16) |
-                          ((unsigned long long)(2 * gy + dys[k]) << 3) | ((unsigned long long)k << 1) | (v1 > v0 ? 1ull : 0ull);
+                tmp[ti] = ((uint32_t)(2 * gx + dxs[k]) << 16) | ((uint32_t)(2 * gy + dys[k]) << 3) | ((uint32_t)k << 1) | (v1 > v0 ? 1u : 0u);
             }
         }
     }
@@ -243,23 +266,76 @@ __global__ __launch_bounds__(SNT) void k_scan(ck_stage_ws ws, int min_cluster, i
     }
 }
 
+// One wave per run: a (tile, cluster) run of the temp array goes to its place inside the cluster, coalesced on both sides.
 __global__ __launch_bounds__(NT) void k_scatter(ck_stage_ws ws) {
     const int frame = blockIdx.y;
     const uint32_t *counters = ws.d_counters + (size_t)frame * CK_CNT_STRIDE;
-    uint32_t n = min(counters[CK_CNT_TMP], (uint32_t)ws.point_cap);
-    const ck_tmp_point *tmp = ws.d_tmp + (size_t)frame * ws.point_cap;
+    const uint32_t nruns = min(counters[CK_CNT_RUNS], (uint32_t)ws.run_cap);
+    const uint32_t ntmp = min(counters[CK_CNT_TMP], (uint32_t)ws.point_cap);
+    const ck_packed_point *tmp = ws.d_tmp + (size_t)frame * ws.point_cap;
+    const ck_run *runs = ws.d_runs + (size_t)frame * ws.run_cap;
     const uint32_t *goff = ws.d_ht_off + (size_t)frame * ws.ht_size;
-    ck_cluster_point_t *pts = ws.d_points + (size_t)frame * ws.point_cap;
-    for (uint32_t i = blockIdx.x * NT + threadIdx.x; i < n; i += gridDim.x * NT) {
-        const ck_tmp_point tp = tmp[i];
-        uint32_t off = goff[(uint32_t)(tp >> 44)];
-        if (off == SKIP) continue;
-        const int k = (int)(tp >> 1) & 3, sgn = (tp & 1ull) ? 1 : -1;
-        const int dx = k == 2 ? -1 : (k == 1 ? 0 : 1), dy = k == 0 ? 0 : 1;
-        ck_cluster_point_t p;
-        p.x = (uint16_t)((tp >> 16) & 0x1FFF); p.y = (uint16_t)((tp >> 3) & 0x1FFF);
-        p.gx = (int8_t)(dx * sgn); p.gy = (int8_t)(dy * sgn); p.pad = 0;
-        pts[off + (uint32_t)((tp >> 29) & 0x7FFF)] = p;
+    ck_packed_point *pts = ws.d_points + (size_t)frame * ws.point_cap;
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave = blockIdx.x * (NT / 64) + (threadIdx.x >> 6), nwaves = gridDim.x * (NT / 64);
+    // 64 runs per wave and round: every lane fetches one run record and its cluster offset (two dependent loads paid once
+    // for 64 runs), then the wave copies the runs one after the other (runs of up to 64 points: 16 lanes each, four runs at a time)
+    for (uint32_t r0 = wave * 64; r0 < nruns; r0 += nwaves * 64) {
+        ck_run mine = {0, 0, 0, 0};
+        uint32_t moff = SKIP;
+        if (r0 + lane < nruns) { mine = runs[r0 + lane]; moff = goff[mine.slot]; }
+        if (moff == SKIP) mine.count = 0; // cluster dropped by k_scan (too small / too large / no room)
+        const uint32_t dst0 = moff + mine.base;
+        // short runs first, four per step
+        const unsigned long long small = __ballot(mine.count > 0 && mine.count <= 64);
+        unsigned long long todo = small;
+        const int sub = lane >> 4, sl = lane & 15;
+        while (todo) {
+            // pick up to four set bits of `todo`; sub-group `sub` takes the sub-th of them
+            unsigned long long t = todo;
+            int pick = -1;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int bit = t ? __builtin_ctzll(t) : -1;
+                if (q == sub) pick = bit;
+                if (t) t &= t - 1;
+            }
+            todo = t;
+            const int srcl = pick < 0 ? 0 : pick;
+            const uint32_t cnt = (uint32_t)__shfl((int)mine.count, srcl, 64), ts = (uint32_t)__shfl((int)mine.tmp_start, srcl, 64),
+                           ds = (uint32_t)__shfl((int)dst0, srcl, 64);
+            ck_packed_point v[4];
+            bool ok[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) { // all loads of the step are in flight before the first store
+                const uint32_t j = (uint32_t)sl + 16u * q;
+                ok[q] = pick >= 0 && j < cnt && ts + j < ntmp;
+                v[q] = ok[q] ? tmp[ts + j] : 0u;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                if (ok[q]) pts[ds + (uint32_t)sl + 16u * q] = v[q];
+        }
+        unsigned long long big = __ballot(mine.count > 64);
+        while (big) {
+            const int srcl = __builtin_ctzll(big);
+            big &= big - 1;
+            const uint32_t cnt = (uint32_t)__builtin_amdgcn_readlane((int)mine.count, srcl), ts = (uint32_t)__builtin_amdgcn_readlane((int)mine.tmp_start, srcl),
+                           ds = (uint32_t)__builtin_amdgcn_readlane((int)dst0, srcl);
+            for (uint32_t j0 = 0; j0 < cnt; j0 += 256) {
+                ck_packed_point v[4];
+                bool ok[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const uint32_t j = j0 + (uint32_t)lane + 64u * q;
+                    ok[q] = j < cnt && ts + j < ntmp;
+                    v[q] = ok[q] ? tmp[ts + j] : 0u;
+                }
+#pragma unroll
+                for (int q = 0; q < 4; q++)
+                    if (ok[q]) pts[ds + j0 + (uint32_t)lane + 64u * q] = v[q];
+            }
+        }
     }
 }
 
@@ -278,9 +354,7 @@ int ck_launch_clusters(ck_handle *h, int n) {
     hipLaunchKernelGGL(k_emit, dim3((unsigned)(a.tiles_x * a.tiles_y * n)), dim3(NT), 0, h->stream, a);
     int min_cluster = h->cfg.min_cluster_pixels < 24 ? 24 : h->cfg.min_cluster_pixels;
     hipLaunchKernelGGL(k_scan, dim3((unsigned)n), dim3(SNT), 0, h->stream, ws, min_cluster, ws.max_cluster_points);
-    unsigned bx = (unsigned)((ws.point_cap + NT * 4 - 1) / (NT * 4));
-    if (bx > 2048) bx = 2048;
-    hipLaunchKernelGGL(k_scatter, dim3(bx, (unsigned)n), dim3(NT), 0, h->stream, ws);
+    hipLaunchKernelGGL(k_scatter, dim3(32u, (unsigned)n), dim3(NT), 0, h->stream, ws);
     CK_HIP(hipGetLastError());
     return CK_OK;
 }

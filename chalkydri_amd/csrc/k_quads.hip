@@ -571,7 +571,7 @@ __device__ __forceinline__ long long keys_bucket_sort(unsigned long long *sKeys,
 }
 
 // The same sort for the large class, whose keys do not fit in registers: the counting pass only counts, the scatter goes
-// to the cluster's own slice of the global point array (dead once staged; 8 bytes per point like the keys), and the rank
+// to the cluster's slice of an 8-byte-per-point global scratch (ck_stage_ws::d_lscratch), and the rank
 // pass walks that slice and writes the sorted keys to LDS.  The staged points stay intact until the bucket sizes are known,
 // so the bitonic fallback can still start from them.
 constexpr int BUCKET_LIMIT_L = 96;
@@ -701,7 +701,10 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(WPS, 8))) v
         const uint32_t item = a.list[work];
         const int frame = (int)(item >> 20), ci = (int)(item & 0xFFFFFu);
         const ck_cluster_t cl = ws.d_clusters[(size_t)frame * ws.cluster_cap + ci];
-        ck_cluster_point_t *pts = ws.d_points + (size_t)frame * ws.point_cap + cl.start;
+        const ck_packed_point *pts = ws.d_points + (size_t)frame * ws.point_cap + cl.start;
+        // 8 bytes per point for the large class (sort scratch, then the maxima list): one fixed region per workgroup, so
+        // the same few hundred KB are reused cluster after cluster and stay in L2
+        unsigned long long *scratch8 = ws.d_lscratch + (size_t)blockIdx.x * CK_LSCRATCH_PER_WG;
         const int sz0 = (int)cl.count;
         const uint16_t *wq = a.wimg + (size_t)frame * a.qw * a.qh;
         const uint8_t *im = a.im + (size_t)frame * a.pitch;
@@ -714,24 +717,31 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(WPS, 8))) v
         int xmin = 1 << 30, xmax = -(1 << 30), ymin = 1 << 30, ymax = -(1 << 30);
         {   // one coalesced pass; all of a lane's loads are issued before the first use (one memory round trip, not EPL)
             constexpr int EPL = CAP / NTH;
-            const unsigned long long *praw = reinterpret_cast<const unsigned long long *>(pts);
+            // packed point -> the staged form the sort reads: x | y << 16 | (u8)gx << 32 | (u8)gy << 40
+            auto stage = [](ck_packed_point v) -> unsigned long long {
+                const int k = (int)(v >> 1) & 3, sgn = (v & 1u) ? 1 : -1;
+                const int dx = k == 2 ? -1 : (k == 1 ? 0 : 1), dy = k == 0 ? 0 : 1;
+                return (unsigned long long)((v >> 16) & 0x1FFFu) | ((unsigned long long)((v >> 3) & 0x1FFFu) << 16) |
+                       ((unsigned long long)(uint8_t)(int8_t)(dx * sgn) << 32) | ((unsigned long long)(uint8_t)(int8_t)(dy * sgn) << 40);
+            };
             if constexpr (EPL <= 16) {
-                unsigned long long raw[EPL];
+                ck_packed_point rawp[EPL];
 #pragma unroll
-                for (int e = 0; e < EPL; e++) { int i = tid + e * NTH; raw[e] = (i < sz0) ? praw[i] : 0ull; }
+                for (int e = 0; e < EPL; e++) { int i = tid + e * NTH; rawp[e] = (i < sz0) ? pts[i] : 0u; }
 #pragma unroll
                 for (int e = 0; e < EPL; e++) {
                     int i = tid + e * NTH;
                     if (i < sz0) {
-                        sKeys[i] = raw[e];
-                        int px = (int)(raw[e] & 0xFFFF), py = (int)((raw[e] >> 16) & 0xFFFF);
+                        const unsigned long long raw = stage(rawp[e]);
+                        sKeys[i] = raw;
+                        int px = (int)(raw & 0xFFFF), py = (int)((raw >> 16) & 0xFFFF);
                         xmin = min(xmin, px); xmax = max(xmax, px);
                         ymin = min(ymin, py); ymax = max(ymax, py);
                     }
                 }
             } else {
                 for (int i = tid; i < sz0; i += NTH) {
-                    unsigned long long raw = praw[i];
+                    const unsigned long long raw = stage(pts[i]);
                     sKeys[i] = raw;
                     int px = (int)(raw & 0xFFFF), py = (int)((raw >> 16) & 0xFFFF);
                     xmin = min(xmin, px); xmax = max(xmax, px);
@@ -760,7 +770,7 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(WPS, 8))) v
                                                   a.normal_ok, a.reversed_ok, a.stop_after != 11, &sorted);
             else
                 dot = keys_bucket_sort_global<NTH>(sKeys, reinterpret_cast<uint32_t *>(sPraw), sScratch,
-                                                   reinterpret_cast<unsigned long long *>(pts), sz0, xmin, xmax, ymin, ymax,
+                                                   scratch8, sz0, xmin, xmax, ymin, ymax,
                                                    a.normal_ok, a.reversed_ok, a.stop_after != 11, &sorted);
             if (sorted) {}
             else if (EPLS >= 32 && epl == 32) dot = keys_sort<NTH, (EPLS >= 32 ? 32 : 1)>(sKeys, sScratch, sz0, xmin, xmax, ymin, ymax, a.normal_ok, a.reversed_ok, a.stop_after != 11);
@@ -830,8 +840,8 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(WPS, 8))) v
                 }
             }
         }
-        // the cluster's slice of the point array is dead from here on; the large class keeps its maxima there
-        double *gval = reinterpret_cast<double *>(pts);
+        // the cluster's slice of the 8-byte scratch is free again (the sort is done); the large class keeps its maxima there
+        double *gval = reinterpret_cast<double *>(scratch8);
         uint32_t *gidx = reinterpret_cast<uint32_t *>(gval + (sz0 + 1) / 2);
         if (tid == 0) { sNmax = 0; sFlag = 0; }
         if (tid < 6) sTot[0][tid] = 0;
