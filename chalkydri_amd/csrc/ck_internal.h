@@ -57,7 +57,7 @@ __host__ __device__ inline ck_cluster_point_t ck_unpack_point(ck_packed_point v)
 // One (tile, cluster) run of boundary points in the temp array
 struct ck_run {
     uint32_t slot;      // hash-table slot of the cluster
-    uint32_t base;      // rank of the run's first point inside the cluster
+    uint32_t base;      // unused (the run's place inside the cluster is handed out by k_scatter)
     uint32_t tmp_start; // where the run starts in the frame's temp array
     uint32_t count;
 };
@@ -69,7 +69,7 @@ struct ck_stage_ws {
     int max_cluster_points;
     unsigned long long *d_ht_keys; // [n][ht_size]  (rep0<<32 | rep1), 0 = empty
     uint32_t *d_ht_count;      // [n][ht_size]
-    uint32_t *d_ht_off;        // [n][ht_size] start of the cluster in d_points, or 0xFFFFFFFF
+    uint32_t *d_ht_off;        // [n][ht_size] start of the cluster in d_points (k_scatter advances it as it fills), or 0xFFFFFFFF
     ck_packed_point *d_tmp;    // [n][point_cap] points in emission order (runs)
     ck_packed_point *d_points; // [n][point_cap] points grouped by cluster
     ck_run *d_runs;            // [n][run_cap]

@@ -53,7 +53,7 @@ __global__ __launch_bounds__(NT) void k_emit(EmitArgs a) {
     __shared__ uint8_t sT[LH][LW + 2];
     __shared__ uint32_t sR[LH][LW];
     __shared__ unsigned long long sKey[LHT];
-    __shared__ uint32_t sCnt[LHT], sSlot[LHT], sBase[LHT], sTBase[LHT];
+    __shared__ uint32_t sCnt[LHT], sSlot[LHT], sTBase[LHT];
     __shared__ uint32_t sWave[NT / 64 + 1], sRunW[NT / 64 + 1];
     const int tid = threadIdx.x;
     const int tiles = a.tiles_x * a.tiles_y;
@@ -130,30 +130,36 @@ __global__ __launch_bounds__(NT) void k_emit(EmitArgs a) {
     __syncthreads();
     if (a.stop_after == 1) return;
 
-    // pass 2: one reservation of temp space per tile (exclusive scan of the per-key counts), and per (tile, key) one
-    // global insert + one add that hands out the points' ranks inside the cluster
+    // pass 2: one reservation of temp space and of run records per tile (exclusive scans of the per-key counts / used
+    // slots), and per (tile, key) one global insert (waited for: it yields the slot) + one add to the cluster's point
+    // count that nobody waits for.
+    const unsigned long long k0 = sKey[2 * tid], k1 = sKey[2 * tid + 1];
+    const uint32_t c0 = k0 ? sCnt[2 * tid] : 0u, c1 = k1 ? sCnt[2 * tid + 1] : 0u;
+    uint32_t found0 = SKIP, found1 = SKIP, ridx0;
     {
-        const unsigned long long k0 = sKey[2 * tid], k1 = sKey[2 * tid + 1];
-        const uint32_t c0 = k0 ? sCnt[2 * tid] : 0u, c1 = k1 ? sCnt[2 * tid + 1] : 0u;
-        uint32_t incl = c0 + c1;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            uint32_t o = __shfl_up(incl, d, 64);
-            if ((tid & 63) >= d) incl += o;
-        }
-        if ((tid & 63) == 63) sWave[tid >> 6] = incl;
-        __syncthreads();
-        uint32_t before = 0, total = 0;
-#pragma unroll
-        for (int wv = 0; wv < NT / 64; wv++) { uint32_t t = sWave[wv]; if (wv < (tid >> 6)) before += t; total += t; }
-        // the tile's keys also get consecutive run records: rank of every used slot among the tile's used slots
+        const uint32_t incl = wave_scan_u32(c0 + c1);
         const unsigned long long b0 = __ballot(k0 != 0ull), b1 = __ballot(k1 != 0ull);
         const unsigned long long below = (1ull << (tid & 63)) - 1ull;
-        const uint32_t ridx0 = (uint32_t)(__popcll(b0 & below) + __popcll(b1 & below));
+        ridx0 = (uint32_t)(__popcll(b0 & below) + __popcll(b1 & below)); // rank of this thread's first used slot in its wave
+        if ((tid & 63) == 63) sWave[tid >> 6] = incl;
         if ((tid & 63) == 0) sRunW[tid >> 6] = (uint32_t)(__popcll(b0) + __popcll(b1));
-        if (tid == 0) sWave[NT / 64] = total ? atomicAdd(&counters[CK_CNT_TMP], total) : 0u;
+        __syncthreads();
+        uint32_t before = 0, total = 0, rbefore = 0, rtotal = 0;
+#pragma unroll
+        for (int wv = 0; wv < NT / 64; wv++) {
+            uint32_t t = sWave[wv], r = sRunW[wv];
+            if (wv < (tid >> 6)) { before += t; rbefore += r; }
+            total += t; rtotal += r;
+        }
+        ridx0 += rbefore;
+        __syncthreads(); // every thread has read the per-wave totals before thread 0 reuses the arrays' last entries
+        if (tid == 0) {
+            sWave[NT / 64] = total ? atomicAdd(&counters[CK_CNT_TMP], total) : 0u;
+            sRunW[NT / 64] = rtotal ? atomicAdd(&counters[CK_CNT_RUNS], rtotal) : 0u;
+        }
         const uint32_t excl = before + incl - (c0 + c1);
         sTBase[2 * tid] = excl; sTBase[2 * tid + 1] = excl + c0;
+#pragma unroll
         for (int q = 0; q < 2; q++) {
             const unsigned long long key = q ? k1 : k0;
             const int s = 2 * tid + q;
@@ -165,31 +171,14 @@ __global__ __launch_bounds__(NT) void k_emit(EmitArgs a) {
                 if (prev == 0ull || prev == key) { found = g; break; }
                 g = (g + 1) & (uint32_t)(ws.ht_size - 1);
             }
-            if (found == SKIP) { atomicOr(&counters[CK_CNT_STATUS], (uint32_t)CK_FRAME_CLUSTERS_OVERFLOW); sSlot[s] = SKIP; continue; }
+            if (found == SKIP) atomicOr(&counters[CK_CNT_STATUS], (uint32_t)CK_FRAME_CLUSTERS_OVERFLOW);
             sSlot[s] = found;
-            sBase[s] = atomicAdd(&gcount[found], q ? c1 : c0);
+            if (q) found1 = found; else found0 = found;
         }
-        __syncthreads(); // sRunW complete
-        uint32_t rbefore = 0, rtotal = 0;
-#pragma unroll
-        for (int wv = 0; wv < NT / 64; wv++) { uint32_t t = sRunW[wv]; if (wv < (tid >> 6)) rbefore += t; rtotal += t; }
-        if (tid == 0) sRunW[NT / 64] = rtotal ? atomicAdd(&counters[CK_CNT_RUNS], rtotal) : 0u;
-        __syncthreads();
-        const uint32_t tile_base2 = sWave[NT / 64], run_base = sRunW[NT / 64];
-        uint32_t ri = run_base + rbefore + ridx0;
-        for (int q = 0; q < 2; q++) {
-            const int s = 2 * tid + q;
-            if ((q ? k1 : k0) == 0ull) continue;
-            if (sSlot[s] != SKIP) {
-                if (ri < (uint32_t)ws.run_cap) {
-                    ck_run r;
-                    r.slot = sSlot[s]; r.base = sBase[s]; r.tmp_start = tile_base2 + sTBase[s]; r.count = q ? c1 : c0;
-                    runs[ri] = r;
-                } else atomicOr(&counters[CK_CNT_STATUS], (uint32_t)CK_FRAME_CLUSTERS_OVERFLOW);
-            }
-            ri++;
-        }
+        if (found0 != SKIP) atomicAdd(&gcount[found0], c0); // result unused: nothing waits for these
+        if (found1 != SKIP) atomicAdd(&gcount[found1], c1);
     }
+    __syncthreads();
     if (a.stop_after == 2) return;
 
     // pass 3: write the points
@@ -210,6 +199,23 @@ __global__ __launch_bounds__(NT) void k_emit(EmitArgs a) {
                 int v0 = sT[ly][lx], v1 = sT[ly + dys[k]][lx + dxs[k]];
                 tmp[ti] = ((uint32_t)(2 * gx + dxs[k]) << 16) | ((uint32_t)(2 * gy + dys[k]) << 3) | ((uint32_t)k << 1) | (v1 > v0 ? 1u : 0u);
             }
+        }
+    }
+    // run records (their place inside the cluster is decided by k_scatter)
+    {
+        uint32_t ri = sRunW[NT / 64] + ridx0;
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            if ((q ? k1 : k0) == 0ull) continue;
+            const uint32_t found = q ? found1 : found0;
+            if (found != SKIP) {
+                if (ri < (uint32_t)ws.run_cap) {
+                    ck_run r;
+                    r.slot = found; r.base = 0; r.tmp_start = tile_base + sTBase[2 * tid + q]; r.count = q ? c1 : c0;
+                    runs[ri] = r;
+                } else atomicOr(&counters[CK_CNT_STATUS], (uint32_t)CK_FRAME_CLUSTERS_OVERFLOW);
+            }
+            ri++;
         }
     }
 }
@@ -274,7 +280,7 @@ __global__ __launch_bounds__(NT) void k_scatter(ck_stage_ws ws) {
     const uint32_t ntmp = min(counters[CK_CNT_TMP], (uint32_t)ws.point_cap);
     const ck_packed_point *tmp = ws.d_tmp + (size_t)frame * ws.point_cap;
     const ck_run *runs = ws.d_runs + (size_t)frame * ws.run_cap;
-    const uint32_t *goff = ws.d_ht_off + (size_t)frame * ws.ht_size;
+    uint32_t *goff = ws.d_ht_off + (size_t)frame * ws.ht_size;
     ck_packed_point *pts = ws.d_points + (size_t)frame * ws.point_cap;
     const int lane = threadIdx.x & 63;
     const uint32_t wave = blockIdx.x * (NT / 64) + (threadIdx.x >> 6), nwaves = gridDim.x * (NT / 64);
@@ -285,7 +291,8 @@ __global__ __launch_bounds__(NT) void k_scatter(ck_stage_ws ws) {
         uint32_t moff = SKIP;
         if (r0 + lane < nruns) { mine = runs[r0 + lane]; moff = goff[mine.slot]; }
         if (moff == SKIP) mine.count = 0; // cluster dropped by k_scan (too small / too large / no room)
-        const uint32_t dst0 = moff + mine.base;
+        // goff[slot] starts as the cluster's offset and serves as its fill cursor: the add returns where this run goes
+        const uint32_t dst0 = mine.count ? atomicAdd(&goff[mine.slot], mine.count) : 0u;
         // short runs first, four per step
         const unsigned long long small = __ballot(mine.count > 0 && mine.count <= 64);
         unsigned long long todo = small;
