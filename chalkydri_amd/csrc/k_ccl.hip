@@ -13,7 +13,7 @@
 //            masks), labels written once (64 B/lane).  HBM traffic 1.2 R + 1 W + 4 W bytes per pixel.
 //   k_merge  one thread per tile-ring pixel: joins components across tile boundaries with atomicMin on the
 //            label words of the (few) roots involved.
-//   k_roots_a/b  flatten the entries of ring-touching roots and accumulate their sizes into csize[].
+//   k_roots  flattens the entries of ring-touching roots and accumulates their sizes into csize[].
 // No full-frame relabel pass exists: interior components are final when k_tile writes them; ring-touching
 // ones are resolved by consumers with one extra hop (label word format in ck_internal.h).
 #include <stdlib.h>
@@ -139,7 +139,7 @@ __global__ __launch_bounds__(KNT) void k_tile(const uint8_t *__restrict__ frames
                                              int w, int h, int tiles_x, int tiles_y, int min_diff, int min_comp,
                                              uint8_t *__restrict__ thresh, uint32_t *__restrict__ labels,
                                              ck_border_root *__restrict__ broots,
-                                             uint32_t *__restrict__ broot_count, int broot_cap, int stop_after) {
+                                             uint32_t *__restrict__ broot_count, int broot_cap, uint32_t *__restrict__ csize, int stop_after) {
     __shared__ __attribute__((aligned(16))) uint8_t lds[LDS_BYTES];
     const int tid = threadIdx.x;
     const int tiles = tiles_x * tiles_y;
@@ -474,6 +474,7 @@ __global__ __launch_bounds__(KNT) void k_tile(const uint8_t *__restrict__ frames
                     br.root = (uint32_t)gy * (uint32_t)w + (uint32_t)(tx0 + 64 * seg + 16 * piece + k);
                     br.size = size8[node] & 0x7Fu;
                     broots[(size_t)frame * broot_cap + pos] = br;
+                    csize[fbase + br.root] = 0; // k_roots accumulates the parts of a component at its global root
                 }
                 pos++;
             }
@@ -590,10 +591,13 @@ __global__ __launch_bounds__(NT) void k_merge(const uint8_t *__restrict__ thresh
     }
 }
 
-// ---- ring-touching roots: flatten their entries, then accumulate sizes at the global roots ------------------------------------
-__global__ __launch_bounds__(NT) void k_roots_a(uint32_t *__restrict__ labels, uint32_t *__restrict__ csize,
-                                                const ck_border_root *__restrict__ broots,
-                                                const uint32_t *__restrict__ broot_count, int broot_cap, size_t npix) {
+// ---- ring-touching roots: flatten their entries and accumulate sizes at the global roots ---------------------------------------
+// csize[] was zeroed at every ring-touching root by k_tile, so all parts of a component (the global root's own included)
+// simply add up there.  csize[] is only ever compared with min_component_px: a part that is large enough on its own settles
+// the answer with a plain store (thousands of parts of one frame-spanning component would otherwise queue on one address).
+__global__ __launch_bounds__(NT) void k_roots(uint32_t *__restrict__ labels, uint32_t *__restrict__ csize,
+                                              const ck_border_root *__restrict__ broots,
+                                              const uint32_t *__restrict__ broot_count, int broot_cap, size_t npix, int min_comp) {
     const int frame = blockIdx.y;
     uint32_t n = min(broot_count[frame], (uint32_t)broot_cap);
     uint32_t *L = labels + (size_t)frame * npix;
@@ -601,24 +605,7 @@ __global__ __launch_bounds__(NT) void k_roots_a(uint32_t *__restrict__ labels, u
     for (uint32_t k = blockIdx.x * NT + threadIdx.x; k < n; k += gridDim.x * NT) {
         ck_border_root br = broots[(size_t)frame * broot_cap + k];
         uint32_t g = g_find_ro(L, br.root);
-        C[br.root] = br.size;
         if (g != br.root) L[br.root] = g | CK_LBL_BORDER; // still a valid ancestor for concurrent finds
-    }
-}
-__global__ __launch_bounds__(NT) void k_roots_b(const uint32_t *__restrict__ labels, uint32_t *__restrict__ csize,
-                                                const ck_border_root *__restrict__ broots,
-                                                const uint32_t *__restrict__ broot_count, int broot_cap, size_t npix, int min_comp) {
-    const int frame = blockIdx.y;
-    uint32_t n = min(broot_count[frame], (uint32_t)broot_cap);
-    const uint32_t *L = labels + (size_t)frame * npix;
-    uint32_t *C = csize + (size_t)frame * npix;
-    for (uint32_t k = blockIdx.x * NT + threadIdx.x; k < n; k += gridDim.x * NT) {
-        ck_border_root br = broots[(size_t)frame * broot_cap + k];
-        uint32_t g = L[br.root] & CK_LBL_IDX_MASK;
-        if (g == br.root) continue;
-        // csize[] is only ever compared with min_component_px: a part that is large enough on its own settles the answer
-        // with a plain store (thousands of parts of one frame-spanning component would otherwise queue on one address);
-        // small parts still add up exactly
         if ((int)br.size >= min_comp) __hip_atomic_store(&C[g], SIZE_SAT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         else atomicAdd(&C[g], br.size);
     }
@@ -669,19 +656,17 @@ int ck_launch_threshold_segment(ck_handle *h, const uint8_t *frames, int stride,
     if (precomputed)
         hipLaunchKernelGGL(k_tile<true>, dim3((unsigned)(tiles * n)), dim3(KNT), 0, h->stream, frames, frame_pitch, stride, h->qw, h->qh,
                            h->tiles_x, h->tiles_y, h->cfg.min_white_black_diff, h->cfg.min_component_px, h->d_thresh, h->d_labels,
-                           h->d_broots, h->d_broot_count, h->broot_cap, stop_after);
+                           h->d_broots, h->d_broot_count, h->broot_cap, h->d_csize, stop_after);
     else
         hipLaunchKernelGGL(k_tile<false>, dim3((unsigned)(tiles * n)), dim3(KNT), 0, h->stream, frames, frame_pitch, stride, h->qw, h->qh,
                            h->tiles_x, h->tiles_y, h->cfg.min_white_black_diff, h->cfg.min_component_px, h->d_thresh, h->d_labels,
-                           h->d_broots, h->d_broot_count, h->broot_cap, stop_after);
+                           h->d_broots, h->d_broot_count, h->broot_cap, h->d_csize, stop_after);
     hipLaunchKernelGGL(k_merge, dim3((unsigned)(tiles * n)), dim3(NT), 0, h->stream, h->d_thresh, h->d_labels, h->qw, h->qh,
                        h->tiles_x, h->tiles_y);
     int bx = (h->broot_cap + NT * 8 - 1) / (NT * 8);
     if (bx < 1) bx = 1;
     if (bx > 64) bx = 64;
-    hipLaunchKernelGGL(k_roots_a, dim3((unsigned)bx, (unsigned)n), dim3(NT), 0, h->stream, h->d_labels, h->d_csize, h->d_broots,
-                       h->d_broot_count, h->broot_cap, h->npix);
-    hipLaunchKernelGGL(k_roots_b, dim3((unsigned)bx, (unsigned)n), dim3(NT), 0, h->stream, h->d_labels, h->d_csize, h->d_broots,
+    hipLaunchKernelGGL(k_roots, dim3((unsigned)bx, (unsigned)n), dim3(NT), 0, h->stream, h->d_labels, h->d_csize, h->d_broots,
                        h->d_broot_count, h->broot_cap, h->npix, h->cfg.min_component_px);
     CK_HIP(hipGetLastError());
     return CK_OK;

@@ -7,7 +7,7 @@ Bytes are summed over the threshold+segment kernels and divided by the number of
 usage: traffic_from_pmc.py <fetch_dir> <write_dir> [out.json]"""
 import csv, glob, json, os, re, sys
 
-KERNELS = ("k_tile", "k_merge", "k_roots_a", "k_roots_b")
+KERNELS = ("k_tile", "k_merge", "k_roots", "k_roots_a", "k_roots_b")
 
 
 def per_launch(d, counter):
@@ -35,7 +35,7 @@ def main():
     rec = {"hbm_bytes_per_launch": 2.0 * f + w, "fetch_bytes_corrected": 2.0 * f, "write_bytes": w,
            "launches": [nf, nw],
            "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), FETCH_SIZE doubled per MI355X_MICROARCH.md; "
-                     "kernels k_tile+k_merge+k_roots_a+k_roots_b; bench.py --steps 2 --warmup 1 --no-cpu-baseline",
+                     "kernels k_tile+k_merge+k_roots; bench.py --steps 2 --warmup 1 --no-cpu-baseline",
            "round": 1}
     json.dump(rec, open(out, "w"), indent=1)
     print(json.dumps(rec))
