@@ -106,7 +106,9 @@ struct ck_handle {
     ck_config_t cfg;
     int device;
     hipStream_t stream;
+    hipStream_t stream2;  // the second half of a batch runs its irregular stages here (ck_stages.hip: split_batch)
     hipEvent_t ev[16];
+    hipEvent_t ev_fork, ev_join;
     int w, h;            // full-resolution frame
     int qw, qh;          // geometry of the image the quad stages run on (w/decimate)
     int tiles_x, tiles_y;
@@ -165,7 +167,7 @@ int ck_process_frames(ck_handle *h, const uint8_t *frames, int stride, size_t pi
                       const uint8_t *has_gyro, ck_vision_measurement_t *out, int32_t *valid);
 // glue + SQPnP + measurement on the detections left on the device by the last pipeline run
 int ck_run_pose(ck_handle *h, int n, const ck_process_params_t *pp, const double *gyro, const uint8_t *has_gyro,
-                ck_vision_measurement_t *out, int32_t *valid);
+                ck_vision_measurement_t *out, int32_t *valid, bool upload_field = true, bool sync = true);
 
 #ifdef __HIPCC__
 // Wave-wide inclusive sums on the DPP path (no LDS crossbar, no lane-index arithmetic): four row_shr steps inside each

@@ -30,7 +30,7 @@ int ck_stage_alloc(ck_handle *h) {
     CK_HIP(hipMalloc(&ws.d_points, sizeof(ck_packed_point) * (size_t)ws.point_cap * nb));
     ws.run_cap = 4 * ws.cluster_cap;
     CK_HIP(hipMalloc(&ws.d_runs, sizeof(ck_run) * (size_t)ws.run_cap * nb));
-    CK_HIP(hipMalloc(&ws.d_lscratch, sizeof(unsigned long long) * (size_t)CK_LSCRATCH_PER_WG * CK_LSCRATCH_WGS));
+    CK_HIP(hipMalloc(&ws.d_lscratch, 2 * sizeof(unsigned long long) * (size_t)CK_LSCRATCH_PER_WG * CK_LSCRATCH_WGS));
     CK_HIP(hipMalloc(&ws.d_clusters, sizeof(ck_cluster_t) * (size_t)ws.cluster_cap * nb));
     CK_HIP(hipMalloc(&ws.d_counters, sizeof(uint32_t) * CK_CNT_STRIDE * nb));
     CK_HIP(hipMalloc(&ws.d_quads, sizeof(ck_quad_t) * (size_t)ws.quad_cap * nb));
@@ -39,7 +39,7 @@ int ck_stage_alloc(ck_handle *h) {
     size_t list_bytes = ((size_t)CK_FIT_CLASSES * ws.cluster_cap * nb + 16) * sizeof(uint32_t);
     size_t cand_bytes = 256 + ((nb * 4 + 255) / 256) * 256 + sizeof(ck_detection_t) * (size_t)ws.quad_cap * cfg.n_families * nb;
     ws.fit_scratch_bytes = ((list_bytes + 255) / 256) * 256 + cand_bytes;
-    CK_HIP(hipMalloc(&ws.d_fit_scratch, ws.fit_scratch_bytes));
+    CK_HIP(hipMalloc(&ws.d_fit_scratch, 2 * ws.fit_scratch_bytes)); // second copy: the half-batch that runs on stream2
     CK_HIP(hipMalloc(&ws.d_wimg, sizeof(uint16_t) * h->npix * nb));
     ws.field_cap = 1024;
     CK_HIP(hipMalloc(&ws.d_field, sizeof(ck_field_tag_t) * (size_t)ws.field_cap));
@@ -88,27 +88,100 @@ void ck_stage_free(ck_handle *h) {
 }
 
 // the whole detector on n frames resident on the device
-static int run_pipeline(ck_handle *h, const uint8_t *frames, int stride, size_t pitch, int n, int upto /*1 clusters, 2 quads, 3 all*/) {
+// The stages after segmentation are irregular (persistent grids with tails, one-workgroup-per-frame kernels, latency
+// chains): two half-batches on two streams fill each other's gaps.  Threshold + segmentation always run for the whole batch
+// on the handle's stream (that is the stage the HBM roofline is quoted on); then the second half of the frames continues
+// on stream2 through a VIEW of the handle — a copy whose per-frame pointers are advanced by n0 frames and whose scratch
+// regions are the second copies allocated for it.  Frames are independent, so the results do not depend on the split.
+static int streams_wanted() {
+    static const int v = getenv("CK_STREAMS") ? atoi(getenv("CK_STREAMS")) : 2;
+    return v;
+}
+static ck_handle make_view(const ck_handle *h, int f0, bool second_stream = true) {
+    ck_handle v = *h;
+    ck_stage_ws &w = v.ws;
+    const size_t f = (size_t)f0, npix = h->npix;
+    if (second_stream) v.stream = h->stream2;
+    v.d_frames += f * h->frame_pitch;
+    if (h->cfg.quad_decimate > 1) v.d_qframes += f * (size_t)((h->qw + 15) / 16 * 16) * h->qh;
+    else v.d_qframes = v.d_frames;
+    v.d_thresh += f * npix; v.d_labels += f * npix; v.d_csize += f * npix;
+    v.d_broots += f * h->broot_cap; v.d_broot_count += f;
+    w.d_ht_keys += f * w.ht_size; w.d_ht_count += f * w.ht_size; w.d_ht_off += f * w.ht_size;
+    w.d_tmp += f * w.point_cap; w.d_points += f * w.point_cap; w.d_runs += f * w.run_cap;
+    if (second_stream) w.d_lscratch += (size_t)CK_LSCRATCH_PER_WG * CK_LSCRATCH_WGS;
+    w.d_clusters += f * w.cluster_cap; w.d_counters += f * CK_CNT_STRIDE; w.d_quads += f * w.quad_cap; w.d_dets += f * w.det_cap;
+    w.d_wimg += f * npix;
+    if (second_stream) w.d_fit_scratch = static_cast<uint8_t *>(w.d_fit_scratch) + w.fit_scratch_bytes;
+    w.d_gyro += f; w.d_has_gyro += f; w.d_problems += f; w.d_pose_tags += f * w.det_cap; w.d_bearings += f * w.det_cap * 12;
+    w.d_world += f * w.det_cap * 12; w.d_results += f; w.d_meas += f; w.d_valid += f;
+    return v;
+}
+
+// clusters -> quad fit -> decode of n frames on h->stream
+static int run_tail(ck_handle *h, const uint8_t *frames, int stride, size_t pitch, int n, int upto, bool events) {
     hipEvent_t *ev = h->ev;
-    CK_HIP(hipEventRecord(ev[1], h->stream));
-    int rc = ck_run_threshold_segment(h, frames, stride, pitch, n);
+    int rc = ck_launch_clusters(h, n);
     if (rc != CK_OK) return rc;
-    CK_HIP(hipEventRecord(ev[2], h->stream));
-    rc = ck_launch_clusters(h, n);
-    if (rc != CK_OK) return rc;
-    CK_HIP(hipEventRecord(ev[3], h->stream));
+    if (events) CK_HIP(hipEventRecord(ev[3], h->stream));
     if (upto >= 2) {
         const uint8_t *q = frames; int qs = stride; size_t qp = pitch;
         if (h->cfg.quad_decimate > 1) { q = h->d_qframes; qs = (h->qw + 15) / 16 * 16; qp = (size_t)qs * h->qh; }
         rc = ck_launch_fit_quads(h, q, qs, qp, frames, stride, pitch, n);
         if (rc != CK_OK) return rc;
     }
-    CK_HIP(hipEventRecord(ev[4], h->stream));
+    if (events) CK_HIP(hipEventRecord(ev[4], h->stream));
     if (upto >= 3) {
         rc = ck_launch_decode(h, frames, stride, pitch, n);
         if (rc != CK_OK) return rc;
     }
-    CK_HIP(hipEventRecord(ev[5], h->stream));
+    if (events) CK_HIP(hipEventRecord(ev[5], h->stream));
+    return CK_OK;
+}
+
+struct ck_split {
+    int parts = 1;     // the batch is cut into `parts` consecutive pieces; piece p runs on stream (p & 1)
+    int first[9] = {0}; // piece p = frames [first[p], first[p + 1])
+    ck_handle view[8]; // view[p] for p >= 1 (piece 0 uses the handle itself)
+    bool split() const { return parts > 1; }
+};
+static int parts_wanted() {
+    static const int v = getenv("CK_PARTS") ? atoi(getenv("CK_PARTS")) : 2;
+    return v < 1 ? 1 : (v > 8 ? 8 : v);
+}
+
+static int run_pipeline(ck_handle *h, const uint8_t *frames, int stride, size_t pitch, int n, int upto /*1 clusters, 2 quads, 3 all*/,
+                        ck_split *split = nullptr) {
+    hipEvent_t *ev = h->ev;
+    CK_HIP(hipEventRecord(ev[1], h->stream));
+    int rc = ck_run_threshold_segment(h, frames, stride, pitch, n);
+    if (rc != CK_OK) return rc;
+    CK_HIP(hipEventRecord(ev[2], h->stream));
+    int parts = parts_wanted();
+    if (parts > n) parts = n;
+    if (!split || parts < 2 || streams_wanted() < 2) {
+        if (split) { split->parts = 1; split->first[0] = 0; split->first[1] = n; }
+        return run_tail(h, frames, stride, pitch, n, upto, true);
+    }
+    split->parts = parts;
+    for (int p = 0; p <= parts; p++) split->first[p] = (int)((long long)n * p / parts);
+    CK_HIP(hipEventRecord(h->ev_fork, h->stream));
+    CK_HIP(hipStreamWaitEvent(h->stream2, h->ev_fork, 0));
+    for (int p = 0; p < parts; p++) {
+        const int f0 = split->first[p], cnt = split->first[p + 1] - f0;
+        ck_handle *hp = h;
+        if (p > 0) { split->view[p] = make_view(h, f0, (p & 1) != 0); hp = &split->view[p]; }
+        rc = run_tail(hp, frames + (size_t)f0 * pitch, stride, pitch, cnt, upto, p == 0);
+        if (rc != CK_OK) return rc;
+    }
+    return CK_OK;
+}
+// the handle's stream continues only after stream2 has finished its half
+static int join_split(ck_handle *h, const ck_split &sp, int n) {
+    (void)n;
+    if (!sp.split()) return CK_OK;
+    CK_HIP(hipEventRecord(h->ev_join, h->stream2));
+    CK_HIP(hipStreamWaitEvent(h->stream, h->ev_join, 0));
     return CK_OK;
 }
 
@@ -140,7 +213,9 @@ extern "C" int ck_detect_uploaded(ck_handle_t *h, int32_t n, ck_detection_t *det
     if (!h || !dets || !counts || cap < 1 || n < 0 || n > h->n_staged) return CK_EINVAL;
     CK_HIP(hipSetDevice(h->device));
     CK_HIP(hipEventRecord(h->ev[0], h->stream));
-    int rc = run_pipeline(h, h->d_frames, h->frame_stride, h->frame_pitch, n, 3);
+    ck_split sp;
+    int rc = run_pipeline(h, h->d_frames, h->frame_stride, h->frame_pitch, n, 3, &sp);
+    if (rc == CK_OK) rc = join_split(h, sp, n);
     if (rc != CK_OK) return rc;
     return fetch_detections(h, n, dets, cap, counts, status);
 }
@@ -152,7 +227,9 @@ extern "C" int ck_detect_batch(ck_handle_t *h, const ck_image_u8_t *imgs, int32_
     CK_HIP(hipEventRecord(h->ev[0], h->stream));
     int rc = ck_upload_frames(h, imgs, n);
     if (rc != CK_OK) return rc;
-    rc = run_pipeline(h, h->d_frames, h->frame_stride, h->frame_pitch, n, 3);
+    ck_split sp;
+    rc = run_pipeline(h, h->d_frames, h->frame_stride, h->frame_pitch, n, 3, &sp);
+    if (rc == CK_OK) rc = join_split(h, sp, n);
     if (rc != CK_OK) return rc;
     return fetch_detections(h, n, dets, cap, counts, status);
 }
@@ -165,7 +242,9 @@ extern "C" int ck_detect_batch_device(ck_handle_t *h, const uint8_t *d_frames, i
     const uint8_t *use; int us; size_t up;
     int rc = ck_stage_device_frames(h, d_frames, n, stride, frame_pitch, &use, &us, &up);
     if (rc != CK_OK) return rc;
-    rc = run_pipeline(h, use, us, up, n, 3);
+    ck_split sp;
+    rc = run_pipeline(h, use, us, up, n, 3, &sp);
+    if (rc == CK_OK) rc = join_split(h, sp, n);
     if (rc != CK_OK) return rc;
     return fetch_detections(h, n, dets, cap, counts, status);
 }
@@ -174,7 +253,9 @@ int ck_detect_frames(ck_handle *h, const uint8_t *frames, int stride, size_t pit
                      uint32_t *status) {
     if (!h || !dets || !counts || cap < 1 || n < 0 || n > h->cfg.max_batch) return CK_EINVAL;
     CK_HIP(hipEventRecord(h->ev[0], h->stream));
-    int rc = run_pipeline(h, frames, stride, pitch, n, 3);
+    ck_split sp;
+    int rc = run_pipeline(h, frames, stride, pitch, n, 3, &sp);
+    if (rc == CK_OK) rc = join_split(h, sp, n);
     if (rc != CK_OK) return rc;
     return fetch_detections(h, n, dets, cap, counts, status);
 }
@@ -227,9 +308,17 @@ static int process_common(ck_handle *h, const uint8_t *frames, int stride, size_
                           const double *gyro, const uint8_t *has_gyro, ck_vision_measurement_t *out, int32_t *valid) {
     if (!pp || !gyro || !has_gyro || !out || !valid || (pp->n_field > 0 && !pp->field) || pp->n_field < 0) return CK_EINVAL;
     CK_HIP(hipEventRecord(h->ev[0], h->stream));
-    int rc = run_pipeline(h, frames, stride, pitch, n, 3);
+    if (pp->n_field > h->ws.field_cap) return CK_ECAPACITY;
+    // the field layout is shared by both halves: upload it once, ahead of the fork
+    if (pp->n_field) CK_HIP(hipMemcpyAsync(h->ws.d_field, pp->field, sizeof(ck_field_tag_t) * (size_t)pp->n_field, hipMemcpyDefault, h->stream));
+    ck_split sp;
+    int rc = run_pipeline(h, frames, stride, pitch, n, 3, &sp);
     if (rc != CK_OK) return rc;
-    rc = ck_run_pose(h, n, pp, gyro, has_gyro, out, valid);
+    for (int p = 0; p < sp.parts && rc == CK_OK; p++) {
+        const int f0 = sp.first[p], cnt = sp.first[p + 1] - f0;
+        rc = ck_run_pose(p ? &sp.view[p] : h, cnt, pp, gyro + f0, has_gyro + f0, out + f0, valid + f0, false, false);
+    }
+    if (rc == CK_OK) rc = join_split(h, sp, n);
     CK_HIP(hipEventRecord(h->ev[6], h->stream));
     CK_HIP(hipStreamSynchronize(h->stream));
     ck_stage_ms_t &ms = h->last_ms;

@@ -644,11 +644,11 @@ extern "C" int ck_unproject_opencv5(const ck_opencv5_t *cam, const double *px, i
 
 // detect (already run) -> glue -> solve -> measurement, all on the device; only 64-byte records come back
 int ck_run_pose(ck_handle *h, int n, const ck_process_params_t *pp, const double *gyro, const uint8_t *has_gyro,
-                ck_vision_measurement_t *out, int32_t *valid) {
+                ck_vision_measurement_t *out, int32_t *valid, bool upload_field, bool sync) {
     ck_stage_ws &ws = h->ws;
     if (pp->n_field > ws.field_cap) return CK_ECAPACITY;
     // gyro / has_gyro / out / valid may be host or device pointers (hipMemcpyDefault resolves them)
-    if (pp->n_field) CK_HIP(hipMemcpyAsync(ws.d_field, pp->field, sizeof(ck_field_tag_t) * (size_t)pp->n_field, hipMemcpyDefault, h->stream));
+    if (pp->n_field && upload_field) CK_HIP(hipMemcpyAsync(ws.d_field, pp->field, sizeof(ck_field_tag_t) * (size_t)pp->n_field, hipMemcpyDefault, h->stream));
     CK_HIP(hipMemcpyAsync(ws.d_gyro, gyro, sizeof(double) * (size_t)n, hipMemcpyDefault, h->stream));
     CK_HIP(hipMemcpyAsync(ws.d_has_gyro, has_gyro, (size_t)n, hipMemcpyDefault, h->stream));
     GlueArgs g;
@@ -664,6 +664,6 @@ int ck_run_pose(ck_handle *h, int n, const ck_process_params_t *pp, const double
     CK_HIP(hipGetLastError());
     CK_HIP(hipMemcpyAsync(out, ws.d_meas, sizeof(ck_vision_measurement_t) * (size_t)n, hipMemcpyDefault, h->stream));
     CK_HIP(hipMemcpyAsync(valid, ws.d_valid, sizeof(int32_t) * (size_t)n, hipMemcpyDefault, h->stream));
-    CK_HIP(hipStreamSynchronize(h->stream));
+    if (sync) CK_HIP(hipStreamSynchronize(h->stream));
     return CK_OK;
 }

@@ -1,0 +1,54 @@
+"""The post-segmentation stages run as consecutive pieces of the batch on two streams (ck_stages.hip: run_pipeline).  Frames
+are independent, so every split — none, the default two halves, three uneven pieces — must give the same bytes."""
+import hashlib
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+SCRIPT = r"""
+import sys, hashlib
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import numpy as np
+import scenes
+from chalkydri_amd.apriltags import AprilTags
+w, h, f, n = 640, 480, 600.0, 7
+layout = scenes.wall_layout(6, cols=3)
+r2c = {"roll": 0.0, "pitch": 0.0, "yaw": 0.0, "x": 0.2, "y": 0.0, "z": 0.6}
+calib = scenes.pinhole_calib(f, w / 2.0, h / 2.0)
+rng = np.random.default_rng(5)
+frames, gyros = [], []
+for i in range(n):
+    pose = (rng.uniform(1.8, 2.4), rng.uniform(-0.2, 0.2), rng.uniform(-0.1, 0.1))
+    frames.append(scenes.render_view(900 + i, w, h, f, layout, pose, r2c, noise_amp=3)[0]); gyros.append(pose[2])
+gyros[4] = None
+task = AprilTags(w, h, layout, calib, r2c, cam_id=1, max_batch=n)
+recs, valid = task.process_batch(np.stack(frames), gyros)
+dets, status = task.detector.detect_batch(np.stack(frames), cap=32, return_status=True)
+hh = hashlib.sha256()
+for r in recs: hh.update(bytes(r))
+hh.update(np.asarray(valid, np.int32).tobytes()); hh.update(np.asarray(status, np.uint32).tobytes())
+for fr in dets:
+    for d in fr:
+        hh.update(np.asarray([d.id(), d.hamming()], np.int64).tobytes()); hh.update(np.asarray(d.corners(), np.float64).tobytes())
+print("HASH", hh.hexdigest(), int(np.sum(valid)))
+"""
+
+
+def _run(env_extra):
+    env = dict(os.environ, **env_extra)
+    r = subprocess.run([sys.executable, "-c", SCRIPT % (ROOT, os.path.join(ROOT, "tests"))], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("HASH")][0].split()
+    return line[1], int(line[2])
+
+
+def test_results_do_not_depend_on_the_split(built):
+    single, nvalid = _run({"CK_STREAMS": "1"})
+    assert nvalid == 6                       # 7 frames, one without gyro
+    assert _run({}) [0] == single            # default: two halves on two streams
+    assert _run({"CK_PARTS": "3"})[0] == single
