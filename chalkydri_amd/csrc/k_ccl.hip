@@ -48,6 +48,7 @@ static_assert(OFF_THR + 1024 <= OFF_SIZE, "threshold scratch must fit in the par
 static_assert(LDS_BYTES + 64 <= 27136, "keep six workgroups per CU");
 static_assert(TH * NSEG * 2 == KNT, "k_tile thread mapping: colour x row x segment");
 static_assert(TH * TW <= 65536, "node indices are u16");
+static_assert(TW == 128, "label pass splits a node index with >> 7 / & 127");
 
 // find with path halving.  Plain stores race with the min-hooks of lds_union, but every value ever written to p[a]
 // is an ancestor of a, so the forest stays valid (a lost hook is re-issued by its own union).
@@ -434,19 +435,31 @@ __global__ __launch_bounds__(KNT) void k_tile(const uint8_t *__restrict__ frames
             uint64_t Wm = masks[(rr * NSEG + seg) * 2], Bm = masks[(rr * NSEG + seg) * 2 + 1];
             uint64_t Oo = origin_mask(tx0 + 64 * seg, w);
             uint64_t SW = Wm & ~((Wm << 1) & Oo), SB = Bm & ~((Bm << 1) & Oo);
+            // everything below works on the 16 bits of this chunk with compile-time shifts (the kernel is bound by
+            // instruction issue): colour bits, run-start bits, and for each colour the node of the run that is already
+            // open when the chunk begins
+            const int sh = 16 * piece;
+            const uint32_t w16 = (uint32_t)(Wm >> sh) & 0xFFFFu, b16 = (uint32_t)(Bm >> sh) & 0xFFFFu;
+            const uint32_t sw16 = (uint32_t)(SW >> sh) & 0xFFFFu, sb16 = (uint32_t)(SB >> sh) & 0xFFFFu;
+            const uint64_t lowmask = (1ull << sh) - 1ull; // sh <= 48
+            const uint64_t lw = SW & lowmask, lb = SB & lowmask;
+            const uint32_t carryW = sbase + (lw ? (uint32_t)(63 - __builtin_clzll(lw)) : 0u);
+            const uint32_t carryB = sbase + (lb ? (uint32_t)(63 - __builtin_clzll(lb)) : 0u);
+            const uint32_t cbase = sbase + (uint32_t)sh;
+            const uint32_t gbase = (uint32_t)ty0 * (uint32_t)w + (uint32_t)tx0;
 #pragma unroll
             for (int k = 0; k < 16; k++) {
-                int bit = 16 * piece + k;
+                const bool isw = (w16 >> k) & 1u, isb = (b16 >> k) & 1u;
+                const uint32_t m = (isw ? sw16 : sb16) & ((2u << k) - 1u);
+                const uint32_t node = m ? cbase + (uint32_t)(31 - __builtin_clz(m)) : (isw ? carryW : carryB);
                 uint32_t word = CK_LBL_INVALID;
-                bool isw = (Wm >> bit) & 1ull, isb = (Bm >> bit) & 1ull;
                 if (isw || isb) {
-                    uint32_t node = sbase + run_start(isw ? SW : SB, bit);
-                    uint32_t root = parent[node];
-                    uint32_t sw = size8[root];
-                    uint32_t gidx = (uint32_t)(ty0 + (int)(root / TW)) * (uint32_t)w + (uint32_t)(tx0 + (int)(root % TW));
+                    const uint32_t root = parent[node];
+                    const uint32_t sw = size8[root];
+                    const uint32_t gidx = gbase + (root >> 7) * (uint32_t)w + (root & (TW - 1));
                     word = gidx | ((sw & 0x80u) ? CK_LBL_BORDER : ((int)(sw & 0x7Fu) < min_comp ? CK_LBL_SMALL : 0u));
                     // a ring-touching root: a run start whose label word points at itself
-                    if ((sw & 0x80u) && root == sbase + (uint32_t)bit) roots_mask |= 1u << k;
+                    if ((sw & 0x80u) && root == cbase + (uint32_t)k) roots_mask |= 1u << k;
                 }
                 outw[k] = word;
             }
