@@ -23,11 +23,18 @@
 namespace {
 
 constexpr int TW = CK_TW, TH = CK_TH, NT = 256; // NT: merge / utility kernels
-constexpr int KNT = 256;                             // k_tile: one lane per (row segment, colour)
+constexpr int SEGW = 64;                             // pixels per row segment = width of a lane's bit masks
+using mask_t = uint64_t;                             // (32-bit segments with twice the lanes were measured: slightly slower)
+constexpr int KNT = TH * (TW / SEGW) * 2;            // k_tile: one lane per (row segment, colour)
 constexpr int IMG_PITCH = 160;          // 12 pad | 4 halo | 128 tile | 4 halo | 12 pad
 constexpr int IMG_ROWS = TH + 8;
 constexpr int T4X = TW / 4 + 2, T4Y = TH / 4 + 2;
-constexpr int NSEG = TW / 64;
+constexpr int NSEG = TW / SEGW;
+constexpr int MPIECES = SEGW / 16;                   // 16-pixel chunks per mask
+constexpr mask_t MALL = ~mask_t(0), MONE = 1;
+__device__ __forceinline__ int mctz(mask_t v) { return sizeof(mask_t) == 8 ? __builtin_ctzll(v) : __builtin_ctz((uint32_t)v); }
+__device__ __forceinline__ int mclz(mask_t v) { return sizeof(mask_t) == 8 ? __builtin_clzll(v) : __builtin_clz((uint32_t)v); }
+__device__ __forceinline__ int mpopc(mask_t v) { return sizeof(mask_t) == 8 ? __popcll(v) : __popc((uint32_t)v); }
 
 // LDS of k_tile, 26 KB, so that six workgroups (24 waves) share a CU — the union-find is bound by LDS round-trip
 // latency, and resident waves are what hides it:
@@ -35,14 +42,14 @@ constexpr int NSEG = TW / 64;
 //                       the same bytes hold the staged image, the 4x4 min/max and the per-4x4 threshold words
 //   size    u8[TH*TW]   at the roots: pixel count saturating at 127 (only "< min_component_px" is ever asked, and
 //                       ck_create refuses min_component_px > 127) | bit 7 = component touches the tile ring
-//   masks   u64[TH][NSEG][2]
+//   masks   mask_t[TH][NSEG][2]
 constexpr int OFF_PARENT = 0;                              // u16[TH*TW] = 16384
 constexpr int OFF_IMG = 0;                                 // IMG_ROWS*IMG_PITCH = 11520
 constexpr int OFF_MINMAX = OFF_IMG + IMG_ROWS * IMG_PITCH; // u16[T4Y*T4X] (1224 -> 1280)
 constexpr int OFF_THR = OFF_MINMAX + 1280;                 // u16[(TH/4)*(TW/4)] = 1024
 constexpr int OFF_SIZE = TH * TW * 2;                      // u8[TH*TW] = 8192
-constexpr int OFF_MASK = OFF_SIZE + TH * TW;               // u64[TH][NSEG][2]
-constexpr int LDS_BYTES = OFF_MASK + TH * NSEG * 2 * 8;
+constexpr int OFF_MASK = OFF_SIZE + TH * TW;               // mask_t[TH][NSEG][2]
+constexpr int LDS_BYTES = OFF_MASK + TH * NSEG * 2 * (int)sizeof(mask_t);
 constexpr uint32_t SIZE_SAT = 127;
 static_assert(OFF_THR + 1024 <= OFF_SIZE, "threshold scratch must fit in the parent array");
 static_assert(LDS_BYTES + 64 <= 27136, "keep six workgroups per CU");
@@ -107,14 +114,14 @@ __device__ __forceinline__ void lds_size_add(uint8_t *sz, uint32_t root, uint32_
     }
 }
 // start bit of the run that contains bit i, given the run-start mask S (bit i's run start is <= i)
-__device__ __forceinline__ int run_start(uint64_t S, int i) {
-    return 63 - __builtin_clzll(S & (~0ull >> (63 - i)));
+__device__ __forceinline__ int run_start(mask_t S, int i) {
+    return SEGW - 1 - mclz(S & (MALL >> (SEGW - 1 - i)));
 }
-__device__ __forceinline__ uint64_t origin_mask(int x0, int w) {
-    uint64_t O = ~0ull;
-    if (x0 == 0) O &= ~1ull;
+__device__ __forceinline__ mask_t origin_mask(int x0, int w) {
+    mask_t O = MALL;
+    if (x0 == 0) O &= ~MONE;
     int last = (w - 1) - x0;
-    if (last >= 0 && last < 64) O &= ~(1ull << last);
+    if (last >= 0 && last < SEGW) O &= ~(MONE << last);
     return O;
 }
 // gathers bit 7 of each byte of v into a nibble (bit k = byte k)
@@ -257,9 +264,9 @@ __global__ __launch_bounds__(KNT) void k_tile(const uint8_t *__restrict__ frames
                 for (int k = 0; k < 4; k++)
                     if (gx + 4 * k < w) *reinterpret_cast<uint32_t *>(dst + 4 * k) = out[k];
         }
-        int seg = c >> 2, piece = c & 3;
-        mask16[((r * NSEG + seg) * 2 + 0) * 4 + piece] = (uint16_t)wbits;
-        mask16[((r * NSEG + seg) * 2 + 1) * 4 + piece] = (uint16_t)bbits;
+        int seg = c / MPIECES, piece = c % MPIECES;
+        mask16[((r * NSEG + seg) * 2 + 0) * MPIECES + piece] = (uint16_t)wbits;
+        mask16[((r * NSEG + seg) * 2 + 1) * MPIECES + piece] = (uint16_t)bbits;
     }
     __syncthreads();
     TPROF(2);
@@ -273,56 +280,56 @@ __global__ __launch_bounds__(KNT) void k_tile(const uint8_t *__restrict__ frames
     for (int i = tid * 16; i < TH * TW; i += KNT * 16) *reinterpret_cast<uint4 *>(size8 + i) = make_uint4(0, 0, 0, 0);
 
     // ---- P5: unions.  thread = (colour, row, segment) --------------------------------------------------------------
-    const uint64_t *masks = reinterpret_cast<const uint64_t *>(lds + OFF_MASK);
-    const int color = tid >> 7, sitem = tid & 127;
+    const mask_t *masks = reinterpret_cast<const mask_t *>(lds + OFF_MASK);
+    const int color = tid / (KNT / 2), sitem = tid % (KNT / 2);
     const int r = sitem / NSEG, s = sitem - r * NSEG;
-    const int x0 = tx0 + 64 * s;
-    const uint64_t M = masks[(r * NSEG + s) * 2 + color];
-    const uint64_t O = origin_mask(x0, w);
-    const uint64_t S = M & ~((M << 1) & O); // segment-local run starts
-    const uint32_t base = (uint32_t)(r * TW + 64 * s);
+    const int x0 = tx0 + SEGW * s;
+    const mask_t M = masks[(r * NSEG + s) * 2 + color];
+    const mask_t O = origin_mask(x0, w);
+    const mask_t S = M & ~((M << 1) & O); // segment-local run starts
+    const uint32_t base = (uint32_t)(r * TW + SEGW * s);
     // Events of this segment: every link from one of its runs to a run that comes earlier in scan order
     //   hleft : bit 0 continues the run that ends the segment on the left
     //   Ev    : vertical links (first column of every stretch where this row and the row above overlap)
     //   DL/DR : white only, diagonal links not already implied by a vertical one
-    uint64_t Ev = 0, DL = 0, DR = 0, U = 0, Su = 0, Ul = 0;
+    mask_t Ev = 0, DL = 0, DR = 0, U = 0, Su = 0, Ul = 0;
     uint32_t left_node = 0;
     bool hleft = false;
     if (M) {
-        if (s > 0 && (M & O & 1ull)) {
-            uint64_t Ml = masks[(r * NSEG + s - 1) * 2 + color];
-            if (Ml >> 63) {
-                uint64_t Ol = origin_mask(x0 - 64, w);
-                uint64_t Sl = Ml & ~((Ml << 1) & Ol);
-                left_node = base - 64 + (uint32_t)(63 - __builtin_clzll(Sl));
+        if (s > 0 && (M & O & MONE)) {
+            mask_t Ml = masks[(r * NSEG + s - 1) * 2 + color];
+            if (Ml >> (SEGW - 1)) {
+                mask_t Ol = origin_mask(x0 - SEGW, w);
+                mask_t Sl = Ml & ~((Ml << 1) & Ol);
+                left_node = base - SEGW + (uint32_t)(SEGW - 1 - mclz(Sl));
                 hleft = true;
             }
         }
         if (r > 0) {
             U = masks[((r - 1) * NSEG + s) * 2 + color];
             Su = U & ~((U << 1) & O);
-            uint64_t V = M & U & O;
+            mask_t V = M & U & O;
             Ev = V & ~(V << 1);
             if (color == 0) {
-                uint64_t Ur = 0;
+                mask_t Ur = 0;
                 if (s > 0) Ul = masks[((r - 1) * NSEG + s - 1) * 2];
                 if (s < NSEG - 1) Ur = masks[((r - 1) * NSEG + s + 1) * 2];
-                int xn = x0 + 64; // origin flag of the column right of this segment
-                uint64_t On = (xn >= 1 && xn <= w - 2) ? 1ull : 0ull;
-                uint64_t MO = M & O;
-                DL = MO & ((U << 1) | (Ul >> 63)) & ~U & ~(MO << 1);
-                DR = MO & ((U >> 1) | (Ur << 63)) & ~(U & ((O >> 1) | (On << 63))) & ~(MO >> 1);
+                int xn = x0 + SEGW; // origin flag of the column right of this segment
+                mask_t On = (xn >= 1 && xn <= w - 2) ? MONE : (mask_t)0;
+                mask_t MO = M & O;
+                DL = MO & ((U << 1) | (Ul >> (SEGW - 1))) & ~U & ~(MO << 1);
+                DR = MO & ((U >> 1) | (Ur << (SEGW - 1))) & ~(U & ((O >> 1) | (On << (SEGW - 1)))) & ~(MO >> 1);
             }
         }
     }
     auto up_left_node = [&](int i) -> uint32_t { // run of the pixel up-left of bit i
         if (i > 0) return base - TW + (uint32_t)run_start(Su, i - 1);
-        uint64_t Ol = origin_mask(x0 - 64, w);
-        uint64_t Sl = Ul & ~((Ul << 1) & Ol);
-        return base - TW - 64 + (uint32_t)(63 - __builtin_clzll(Sl));
+        mask_t Ol = origin_mask(x0 - SEGW, w);
+        mask_t Sl = Ul & ~((Ul << 1) & Ol);
+        return base - TW - SEGW + (uint32_t)(SEGW - 1 - mclz(Sl));
     };
     auto up_right_node = [&](int i) -> uint32_t { // bit 0 of the segment on the right always starts a run
-        return (i < 63) ? base - TW + (uint32_t)run_start(Su, i + 1) : base - TW + 64;
+        return (i < SEGW - 1) ? base - TW + (uint32_t)run_start(Su, i + 1) : base - TW + SEGW;
     };
     __syncthreads(); // parent[] initialised everywhere before the first adoption lands
     if (stop_after == 3) return; // diagnostics (CK_TILE_STOP_AFTER)
@@ -330,17 +337,17 @@ __global__ __launch_bounds__(KNT) void k_tile(const uint8_t *__restrict__ frames
     // and nothing reads parent[] in this phase, so no find and no atomic is needed for these links; the target always
     // has a smaller index, which keeps the forest invariant (parent <= self) the atomic phase relies on.
     {
-        uint64_t St = S;
+        mask_t St = S;
         while (St) {
-            int i = __builtin_ctzll(St);
+            int i = mctz(St);
             St &= St - 1;
-            uint64_t rest = S & ~((2ull << i) - 1);
-            uint64_t above = rest ? (rest & (0ull - rest)) : 0ull;
-            uint64_t span = above ? (above - (1ull << i)) : (~0ull << i);
-            uint64_t e;
-            if ((e = Ev & span)) { int j = __builtin_ctzll(e); Ev &= ~(1ull << j); parent[base + i] = (uint16_t)(base - TW + (uint32_t)run_start(Su, j)); }
-            else if ((e = DL & span)) { int j = __builtin_ctzll(e); DL &= ~(1ull << j); parent[base + i] = (uint16_t)up_left_node(j); }
-            else if ((e = DR & span)) { int j = __builtin_ctzll(e); DR &= ~(1ull << j); parent[base + i] = (uint16_t)up_right_node(j); }
+            mask_t rest = S & ~((((mask_t)2) << i) - 1);
+            mask_t above = rest ? (rest & ((mask_t)0 - rest)) : (mask_t)0;
+            mask_t span = above ? (above - (MONE << i)) : (MALL << i);
+            mask_t e;
+            if ((e = Ev & span)) { int j = mctz(e); Ev &= ~(MONE << j); parent[base + i] = (uint16_t)(base - TW + (uint32_t)run_start(Su, j)); }
+            else if ((e = DL & span)) { int j = mctz(e); DL &= ~(MONE << j); parent[base + i] = (uint16_t)up_left_node(j); }
+            else if ((e = DR & span)) { int j = mctz(e); DR &= ~(MONE << j); parent[base + i] = (uint16_t)up_right_node(j); }
             else if (i == 0 && hleft) { hleft = false; parent[base] = (uint16_t)left_node; }
         }
     }
@@ -349,17 +356,17 @@ __global__ __launch_bounds__(KNT) void k_tile(const uint8_t *__restrict__ frames
     // ---- P5b: the remaining links (a run touching a second, third ... earlier run) go through the atomic union
     if (hleft) lds_union(parent, base, left_node);
     while (Ev) {
-        int i = __builtin_ctzll(Ev);
+        int i = mctz(Ev);
         Ev &= Ev - 1;
         lds_union(parent, base + run_start(S, i), base - TW + run_start(Su, i));
     }
     while (DL) {
-        int i = __builtin_ctzll(DL);
+        int i = mctz(DL);
         DL &= DL - 1;
         lds_union(parent, base + run_start(S, i), up_left_node(i));
     }
     while (DR) {
-        int i = __builtin_ctzll(DR);
+        int i = mctz(DR);
         DR &= DR - 1;
         lds_union(parent, base + run_start(S, i), up_right_node(i));
     }
@@ -371,7 +378,7 @@ __global__ __launch_bounds__(KNT) void k_tile(const uint8_t *__restrict__ frames
     // ---- P6: flatten run starts, accumulate sizes and ring flags at the roots ---------------------------------------
     {
         const bool ring_row = (r == 0 && ty0 > 0) || (r == TH - 1 && ty0 + TH < h);
-        uint64_t St = S;
+        mask_t St = S;
         // consecutive runs of a segment usually end at the same root (in a noisy tile nearly every white run belongs to
         // the one spanning component): their pixels are summed in registers and flushed once per change of root
         uint32_t acc_root = 0xFFFFFFFFu, acc_add = 0;
@@ -384,15 +391,15 @@ __global__ __launch_bounds__(KNT) void k_tile(const uint8_t *__restrict__ frames
                 live[q] = St != 0;
                 node[q] = base; add[q] = 0; ring[q] = false;
                 if (live[q]) {
-                    int i = __builtin_ctzll(St);
+                    int i = mctz(St);
                     St &= St - 1;
-                    uint64_t rest = S & ~((2ull << i) - 1);          // starts above i in the whole segment
-                    uint64_t above = rest ? (rest & (0ull - rest)) : 0ull; // lowest of them
-                    uint64_t span = above ? (above - (1ull << i)) : (~0ull << i);
-                    uint64_t run = M & span;
+                    mask_t rest = S & ~((((mask_t)2) << i) - 1);          // starts above i in the whole segment
+                    mask_t above = rest ? (rest & ((mask_t)0 - rest)) : (mask_t)0; // lowest of them
+                    mask_t span = above ? (above - (MONE << i)) : (MALL << i);
+                    mask_t run = M & span;
                     node[q] = base + i;
-                    add[q] = (uint32_t)__popcll(run);
-                    ring[q] = ring_row || (s == 0 && tx0 > 0 && (run & 1ull)) || (s == NSEG - 1 && tx0 + TW < w && (run >> 63));
+                    add[q] = (uint32_t)mpopc(run);
+                    ring[q] = ring_row || (s == 0 && tx0 > 0 && (run & MONE)) || (s == NSEG - 1 && tx0 + TW < w && (run >> (SEGW - 1)));
                 }
                 root[q] = node[q];
             }
@@ -429,22 +436,22 @@ __global__ __launch_bounds__(KNT) void k_tile(const uint8_t *__restrict__ frames
         uint32_t roots_mask = 0;
         uint32_t outw[16];
         const bool inside = gy < h && gx < w;
-        int seg = c >> 2, piece = c & 3;
-        uint32_t sbase = (uint32_t)(rr * TW + 64 * seg);
+        int seg = c / MPIECES, piece = c % MPIECES;
+        uint32_t sbase = (uint32_t)(rr * TW + SEGW * seg);
         if (inside) {
-            uint64_t Wm = masks[(rr * NSEG + seg) * 2], Bm = masks[(rr * NSEG + seg) * 2 + 1];
-            uint64_t Oo = origin_mask(tx0 + 64 * seg, w);
-            uint64_t SW = Wm & ~((Wm << 1) & Oo), SB = Bm & ~((Bm << 1) & Oo);
+            mask_t Wm = masks[(rr * NSEG + seg) * 2], Bm = masks[(rr * NSEG + seg) * 2 + 1];
+            mask_t Oo = origin_mask(tx0 + SEGW * seg, w);
+            mask_t SW = Wm & ~((Wm << 1) & Oo), SB = Bm & ~((Bm << 1) & Oo);
             // everything below works on the 16 bits of this chunk with compile-time shifts (the kernel is bound by
             // instruction issue): colour bits, run-start bits, and for each colour the node of the run that is already
             // open when the chunk begins
             const int sh = 16 * piece;
             const uint32_t w16 = (uint32_t)(Wm >> sh) & 0xFFFFu, b16 = (uint32_t)(Bm >> sh) & 0xFFFFu;
             const uint32_t sw16 = (uint32_t)(SW >> sh) & 0xFFFFu, sb16 = (uint32_t)(SB >> sh) & 0xFFFFu;
-            const uint64_t lowmask = (1ull << sh) - 1ull; // sh <= 48
-            const uint64_t lw = SW & lowmask, lb = SB & lowmask;
-            const uint32_t carryW = sbase + (lw ? (uint32_t)(63 - __builtin_clzll(lw)) : 0u);
-            const uint32_t carryB = sbase + (lb ? (uint32_t)(63 - __builtin_clzll(lb)) : 0u);
+            const mask_t lowmask = (MONE << sh) - MONE; // sh <= SEGW - 16
+            const mask_t lw = SW & lowmask, lb = SB & lowmask;
+            const uint32_t carryW = sbase + (lw ? (uint32_t)(SEGW - 1 - mclz(lw)) : 0u);
+            const uint32_t carryB = sbase + (lb ? (uint32_t)(SEGW - 1 - mclz(lb)) : 0u);
             const uint32_t cbase = sbase + (uint32_t)sh;
             const uint32_t gbase = (uint32_t)ty0 * (uint32_t)w + (uint32_t)tx0;
 #pragma unroll
@@ -484,7 +491,7 @@ __global__ __launch_bounds__(KNT) void k_tile(const uint8_t *__restrict__ frames
                 if (pos < (uint32_t)broot_cap) {
                     uint32_t node = sbase + (uint32_t)(16 * piece + k);
                     ck_border_root br;
-                    br.root = (uint32_t)gy * (uint32_t)w + (uint32_t)(tx0 + 64 * seg + 16 * piece + k);
+                    br.root = (uint32_t)gy * (uint32_t)w + (uint32_t)(tx0 + SEGW * seg + 16 * piece + k);
                     br.size = size8[node] & 0x7Fu;
                     broots[(size_t)frame * broot_cap + pos] = br;
                     csize[fbase + br.root] = 0; // k_roots accumulates the parts of a component at its global root
