@@ -339,11 +339,10 @@ __global__ __launch_bounds__(KNT) void k_tile(const uint8_t *__restrict__ frames
     {
         mask_t St = S;
         while (St) {
-            int i = mctz(St);
-            St &= St - 1;
-            mask_t rest = S & ~((((mask_t)2) << i) - 1);
-            mask_t above = rest ? (rest & ((mask_t)0 - rest)) : (mask_t)0;
-            mask_t span = above ? (above - (MONE << i)) : (MALL << i);
+            const mask_t low = St & ((mask_t)0 - St); // this run's start bit
+            const int i = mctz(low);
+            St ^= low;
+            const mask_t span = (St & ((mask_t)0 - St)) - low; // bits from this start up to the next one (or to the top: 0 - low)
             mask_t e;
             if ((e = Ev & span)) { int j = mctz(e); Ev &= ~(MONE << j); parent[base + i] = (uint16_t)(base - TW + (uint32_t)run_start(Su, j)); }
             else if ((e = DL & span)) { int j = mctz(e); DL &= ~(MONE << j); parent[base + i] = (uint16_t)up_left_node(j); }
@@ -391,11 +390,10 @@ __global__ __launch_bounds__(KNT) void k_tile(const uint8_t *__restrict__ frames
                 live[q] = St != 0;
                 node[q] = base; add[q] = 0; ring[q] = false;
                 if (live[q]) {
-                    int i = mctz(St);
-                    St &= St - 1;
-                    mask_t rest = S & ~((((mask_t)2) << i) - 1);          // starts above i in the whole segment
-                    mask_t above = rest ? (rest & ((mask_t)0 - rest)) : (mask_t)0; // lowest of them
-                    mask_t span = above ? (above - (MONE << i)) : (MALL << i);
+                    const mask_t low = St & ((mask_t)0 - St); // this run's start bit
+                    const int i = mctz(low);
+                    St ^= low;
+                    const mask_t span = (St & ((mask_t)0 - St)) - low; // up to the next start (or to the top: 0 - low)
                     mask_t run = M & span;
                     node[q] = base + i;
                     add[q] = (uint32_t)mpopc(run);
