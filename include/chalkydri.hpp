@@ -16,6 +16,11 @@
 #ifndef CHALKYDRI_HPP
 #define CHALKYDRI_HPP
 
+#include <arpa/inet.h>
+#include <netinet/in.h>
+#include <sys/socket.h>
+#include <unistd.h>
+
 #include <array>
 #include <cmath>
 #include <cstdint>
@@ -315,6 +320,43 @@ namespace whacknet {
 // crates/whacknet/src/lib.rs:19-66 — the 64-byte record sent as one datagram
 using VisionMeasurement = ck_vision_measurement_t;
 static_assert(sizeof(VisionMeasurement) == 64, "wire record is 64 bytes (crates/whacknet/src/lib.rs:92-95)");
+
+// WhacknetClient (lib.rs:68-89): a UDP socket bound to 0.0.0.0:0 and connected to the roboRIO; send() puts the 64 raw
+// bytes of one measurement on the wire as one datagram, so a consumer cannot tell which backend produced it.
+class WhacknetClient {
+  public:
+    explicit WhacknetClient(const std::string &remote_ip = "10.45.33.2", uint16_t remote_port = 7001) { // REMOTE_ADDR, lib.rs:14
+        fd_ = ::socket(AF_INET, SOCK_DGRAM, 0);
+        if (fd_ < 0) throw Panic("whacknet: socket() failed");
+        sockaddr_in local{};
+        local.sin_family = AF_INET; local.sin_addr.s_addr = htonl(INADDR_ANY); local.sin_port = 0;            // BIND_ADDR, lib.rs:13
+        sockaddr_in remote{};
+        remote.sin_family = AF_INET; remote.sin_port = htons(remote_port);
+        if (::bind(fd_, reinterpret_cast<sockaddr *>(&local), sizeof local) != 0 || ::inet_pton(AF_INET, remote_ip.c_str(), &remote.sin_addr) != 1 ||
+            ::connect(fd_, reinterpret_cast<sockaddr *>(&remote), sizeof remote) != 0) {
+            ::close(fd_);
+            throw Panic("whacknet: bind/connect failed");
+        }
+    }
+    ~WhacknetClient() { if (fd_ >= 0) ::close(fd_); }
+    WhacknetClient(const WhacknetClient &) = delete;
+    WhacknetClient &operator=(const WhacknetClient &) = delete;
+    // lib.rs:83-89; false where the reference returns the io::Error
+    bool send(const VisionMeasurement &m) const { return ::send(fd_, &m, sizeof m, 0) == (ssize_t)sizeof m; }
+
+  private:
+    int fd_ = -1;
+};
+
+// The gyro heading arrives as one little-endian f64 per datagram on port 7002 (lib.rs:112-130)
+inline std::optional<double> decode_gyro(const uint8_t *buf, size_t len) {
+    if (len < 8) return std::nullopt;
+    uint64_t bits = 0;
+    for (int i = 7; i >= 0; i--) bits = (bits << 8) | buf[i];
+    double v;
+    std::memcpy(&v, &bits, sizeof v);
+    return v;
+}
 } // namespace whacknet
 
 // Pinned host slots + asynchronous upload (the pooled host buffers of the camera layer,

@@ -43,6 +43,29 @@ static int selfcheck() {
     apriltags::UnionFind uf(8);
     uf.union_(1, 2); uf.union_(2, 5);
     if (uf.find(5) != uf.find(1) || uf.get_size(uf.find(1)) != 3 || uf.find(7) != 7) { std::puts("FAIL union-find"); return 1; }
+    {   // whacknet: one measurement = one 64-byte datagram with exactly the struct's bytes; the gyro is a little-endian f64
+        int rx = ::socket(AF_INET, SOCK_DGRAM, 0);
+        sockaddr_in a{};
+        a.sin_family = AF_INET; a.sin_addr.s_addr = htonl(INADDR_LOOPBACK); a.sin_port = 0;
+        socklen_t al = sizeof a;
+        if (rx < 0 || ::bind(rx, reinterpret_cast<sockaddr *>(&a), sizeof a) != 0 || ::getsockname(rx, reinterpret_cast<sockaddr *>(&a), &al) != 0) {
+            std::puts("FAIL loopback socket"); return 1;
+        }
+        timeval tv{2, 0};
+        ::setsockopt(rx, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof tv);
+        whacknet::WhacknetClient tx("127.0.0.1", ntohs(a.sin_port));
+        whacknet::VisionMeasurement m{};
+        m.pose_x = 1.25; m.pose_y = -3.5; m.pose_rot = 0.125; m.std_x = 0.01; m.std_y = 0.02; m.std_rot = 0.05; m.ts = 0x1122334455667788ull;
+        m.camera_id = 3; m.tag_count = 6;
+        unsigned char buf[128];
+        if (!tx.send(m) || ::recv(rx, buf, sizeof buf, 0) != 64 || std::memcmp(buf, &m, 64) != 0) { std::puts("FAIL whacknet datagram"); return 1; }
+        ::close(rx);
+        const double g = -1.5707963267948966;
+        unsigned char gb[8];
+        std::memcpy(gb, &g, 8);
+        auto back = whacknet::decode_gyro(gb, 8);
+        if (!back || *back != g || whacknet::decode_gyro(gb, 4)) { std::puts("FAIL gyro decode"); return 1; }
+    }
     int devs = ck_device_count();
     if (devs <= 0) {
         try {
