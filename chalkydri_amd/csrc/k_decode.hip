@@ -18,8 +18,9 @@ struct DecodeArgs {
     ck_detection_t *cands; int cand_cap; uint32_t *cand_count; // [n][cand_cap], [n]
 };
 
-__device__ int homography_compute(const double corr[4][4], double *H) {
-    double A[8 * 9];
+// A: 72 doubles of workspace.  The elimination indexes it with run-time rows, so a private array would live in scratch
+// memory; the caller passes LDS.
+__device__ int homography_compute(const double corr[4][4], double *H, double *A) {
     for (int i = 0; i < 4; i++) {
         double x = corr[i][0], y = corr[i][1], u = corr[i][2], v = corr[i][3];
         double *r0 = &A[(2 * i) * 9], *r1 = &A[(2 * i + 1) * 9];
@@ -76,7 +77,7 @@ __device__ __forceinline__ unsigned long long code_rotate90(unsigned long long w
 
 // one wave per (frame, quad); loops over families
 __global__ __launch_bounds__(64) void k_decode(DecodeArgs a) {
-    __shared__ double sH[9];
+    __shared__ double sH[9], sA[72], sSamp[128][3];
     __shared__ double sC[2][3];      // gray models: [0] white, [1] black
     __shared__ double sVal[256], sSharp[256];
     __shared__ int sOk;
@@ -97,7 +98,7 @@ __global__ __launch_bounds__(64) void k_decode(DecodeArgs a) {
             corr[i][2] = q.p[i][0]; corr[i][3] = q.p[i][1];
         }
         double H[9];
-        int ok = homography_compute(corr, H);
+        int ok = homography_compute(corr, H, sA);
         for (int i = 0; i < 9; i++) sH[i] = H[i];
         sOk = ok;
     }
@@ -109,42 +110,53 @@ __global__ __launch_bounds__(64) void k_decode(DecodeArgs a) {
         const double wb = (double)fam.width_at_border;
         const int tw = fam.total_width;
         __syncthreads();
-        // gray models: lane 0 accumulates the white border samples, lane 1 the black ones, each in the oracle's order
-        if (lane < 2) {
+        // gray models.  The 8 * width_at_border border samples are independent (one image read each): every lane takes
+        // samples, then lane 0 adds up the white ones and lane 1 the black ones from LDS in the oracle's order.
+        {
             const double patterns[8][5] = {
                 {-0.5, 0.5, 0, 1, 1}, {0.5, 0.5, 0, 1, 0}, {wb + 0.5, 0.5, 0, 1, 1}, {wb - 0.5, 0.5, 0, 1, 0},
                 {0.5, -0.5, 1, 0, 1}, {0.5, 0.5, 1, 0, 0}, {0.5, wb + 0.5, 1, 0, 1}, {0.5, wb - 0.5, 1, 0, 0}};
-            const int want_white = (lane == 0);
-            double A00 = 0, A01 = 0, A02 = 0, A11 = 0, A12 = 0, A22 = 0, B0 = 0, B1 = 0, B2 = 0;
-            for (int pi = 0; pi < 8; pi++) {
-                int is_white = patterns[pi][4] != 0;
-                if (is_white != want_white) continue;
-                for (int i = 0; i < fam.width_at_border; i++) {
-                    double tagx01 = (patterns[pi][0] + (double)i * patterns[pi][2]) / wb;
-                    double tagy01 = (patterns[pi][1] + (double)i * patterns[pi][3]) / wb;
-                    double tagx = 2.0 * (tagx01 - 0.5), tagy = 2.0 * (tagy01 - 0.5);
-                    double px, py;
-                    hproject(sH, tagx, tagy, &px, &py);
-                    int ix = (int)px, iy = (int)py;
-                    if (px < 0 || py < 0 || ix < 0 || iy < 0 || ix >= w || iy >= h) continue;
-                    double gray = (double)im[(size_t)iy * stride + ix];
-                    A00 += tagx * tagx; A01 += tagx * tagy; A02 += tagx;
-                    A11 += tagy * tagy; A12 += tagy; A22 += 1;
-                    B0 += tagx * gray; B1 += tagy * gray; B2 += gray;
-                }
+            const int wab = fam.width_at_border, nsamp = 8 * wab; // <= 128: total_width <= 16
+            for (int j = lane; j < nsamp; j += 64) {
+                const int pi = j / wab, i = j - pi * wab;
+                double tagx01 = (patterns[pi][0] + (double)i * patterns[pi][2]) / wb;
+                double tagy01 = (patterns[pi][1] + (double)i * patterns[pi][3]) / wb;
+                double tagx = 2.0 * (tagx01 - 0.5), tagy = 2.0 * (tagy01 - 0.5);
+                double px, py;
+                hproject(sH, tagx, tagy, &px, &py);
+                int ix = (int)px, iy = (int)py;
+                double gray = -1.0; // outside the image: the sample is skipped
+                if (!(px < 0 || py < 0 || ix < 0 || iy < 0 || ix >= w || iy >= h)) gray = (double)im[(size_t)iy * stride + ix];
+                sSamp[j][0] = tagx; sSamp[j][1] = tagy; sSamp[j][2] = gray;
             }
-            double l00 = sqrt(A00);
-            double l10 = A01 / l00, l20 = A02 / l00;
-            double l11 = sqrt(A11 - l10 * l10);
-            double l21 = (A12 - l10 * l20) / l11;
-            double l22 = sqrt(A22 - l20 * l20 - l21 * l21);
-            double y0 = B0 / l00;
-            double y1 = (B1 - l10 * y0) / l11;
-            double y2 = (B2 - l20 * y0 - l21 * y1) / l22;
-            double c2 = y2 / l22;
-            double c1 = (y1 - l21 * c2) / l11;
-            double c0 = (y0 - l10 * c1 - l20 * c2) / l00;
-            sC[1 - want_white][0] = c0; sC[1 - want_white][1] = c1; sC[1 - want_white][2] = c2;
+            __syncthreads();
+            if (lane < 2) {
+                const int want_white = (lane == 0);
+                double A00 = 0, A01 = 0, A02 = 0, A11 = 0, A12 = 0, A22 = 0, B0 = 0, B1 = 0, B2 = 0;
+                for (int pi = 0; pi < 8; pi++) {
+                    int is_white = patterns[pi][4] != 0;
+                    if (is_white != want_white) continue;
+                    for (int i = 0; i < wab; i++) {
+                        const double tagx = sSamp[pi * wab + i][0], tagy = sSamp[pi * wab + i][1], gray = sSamp[pi * wab + i][2];
+                        if (gray < 0) continue;
+                        A00 += tagx * tagx; A01 += tagx * tagy; A02 += tagx;
+                        A11 += tagy * tagy; A12 += tagy; A22 += 1;
+                        B0 += tagx * gray; B1 += tagy * gray; B2 += gray;
+                    }
+                }
+                double l00 = sqrt(A00);
+                double l10 = A01 / l00, l20 = A02 / l00;
+                double l11 = sqrt(A11 - l10 * l10);
+                double l21 = (A12 - l10 * l20) / l11;
+                double l22 = sqrt(A22 - l20 * l20 - l21 * l21);
+                double y0 = B0 / l00;
+                double y1 = (B1 - l10 * y0) / l11;
+                double y2 = (B2 - l20 * y0 - l21 * y1) / l22;
+                double c2 = y2 / l22;
+                double c1 = (y1 - l21 * c2) / l11;
+                double c0 = (y0 - l10 * c1 - l20 * c2) / l00;
+                sC[1 - want_white][0] = c0; sC[1 - want_white][1] = c1; sC[1 - want_white][2] = c2;
+            }
         }
         for (int i = lane; i < tw * tw; i += 64) sVal[i] = 0.0;
         __syncthreads();
