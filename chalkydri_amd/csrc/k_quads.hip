@@ -148,33 +148,6 @@ struct Block {
         }
         return v;
     }
-    // inclusive scan of six values per thread with ONE barrier pair; v[] is replaced by the inclusive sums
-    __device__ static void scan_incl6(long long v[6], long long *scratch /* [6*NW] */) {
-        const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-#pragma unroll
-        for (int q = 0; q < 6; q++) {
-            long long x = v[q];
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                long long o = __shfl_up(x, d, 64);
-                if (lane >= d) x += o;
-            }
-            v[q] = x;
-        }
-        if (NW > 1) {
-            if (lane == 63)
-#pragma unroll
-                for (int q = 0; q < 6; q++) scratch[q * NW + wv] = v[q];
-            __syncthreads();
-#pragma unroll
-            for (int q = 0; q < 6; q++) {
-                long long base = 0;
-                for (int k = 0; k < wv; k++) base += scratch[q * NW + k];
-                v[q] += base;
-            }
-            __syncthreads();
-        }
-    }
     // inclusive scan of three 64-bit and three 32-bit values per thread, one barrier pair; both arrays are replaced.
     // scratch: 5 * NW long long (the 32-bit values travel as a second array inside it)
     __device__ static void scan_incl_3x64_3x32(unsigned long long a[3], uint32_t b[3], long long *scratch) {
@@ -235,102 +208,7 @@ struct Block {
         *total = tot;
         return incl;
     }
-    // sums of six values per thread over the workgroup (every thread gets them), one barrier pair
-    __device__ static void reduce_add6(long long v[6], long long *scratch /* [6*NW] */) {
-        const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-#pragma unroll
-        for (int q = 0; q < 6; q++)
-#pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) v[q] += __shfl_xor(v[q], d, 64);
-        if (NW > 1) {
-            if (lane == 0)
-#pragma unroll
-                for (int q = 0; q < 6; q++) scratch[q * NW + wv] = v[q];
-            __syncthreads();
-#pragma unroll
-            for (int q = 0; q < 6; q++) {
-                long long r = 0;
-                for (int k = 0; k < NW; k++) r += scratch[q * NW + k];
-                v[q] = r;
-            }
-            __syncthreads();
-        }
-    }
 };
-
-__device__ __forceinline__ void key_xy(unsigned long long k, int *x, int *y) { *x = (int)((k >> 13) & 0x1FFF); *y = (int)(k & 0x1FFF); }
-
-// moment contribution of one sorted point
-__device__ __forceinline__ M6 point_moments(const FitArgs &a, const uint8_t *qim, unsigned long long key) {
-    int x, y;
-    key_xy(key, &x, &y);
-    int ix = (x + 1) >> 1, iy = (y + 1) >> 1;
-    long long W = 1;
-    if (ix > 0 && ix + 1 < a.qw && iy > 0 && iy + 1 < a.qh) {
-        int gx = (int)qim[(size_t)iy * a.qstride + ix + 1] - (int)qim[(size_t)iy * a.qstride + ix - 1];
-        int gy = (int)qim[(size_t)(iy + 1) * a.qstride + ix] - (int)qim[(size_t)(iy - 1) * a.qstride + ix];
-        W = (long long)isqrt_u32((uint32_t)(gx * gx + gy * gy)) + 1;
-    }
-    long long X = x + 1, Y = y + 1;
-    M6 m;
-    m.Mx = W * X; m.My = W * Y; m.Mxx = W * X * X; m.Mxy = W * X * Y; m.Myy = W * Y * Y; m.W = W;
-    return m;
-}
-
-// edge refinement of one quad edge: returns the refitted line {Ex,Ey,nx,ny} (oracle refine_edges, per edge)
-__device__ void refine_edge(const FitArgs &a, const uint8_t *im, const double p[4][2], int reversed, int edge, double line[4]) {
-    int ea = edge, eb = (edge + 1) & 3;
-    double nx = p[eb][1] - p[ea][1];
-    double ny = -p[eb][0] + p[ea][0];
-    double mag = sqrt(nx * nx + ny * ny);
-    nx = nx / mag; ny = ny / mag;
-    if (reversed) { nx = -nx; ny = -ny; }
-    int nsamples = (int)(mag / 8.0);
-    if (nsamples < 16) nsamples = 16;
-    double Mx = 0, My = 0, Mxx = 0, Mxy = 0, Myy = 0, N = 0;
-    const int w = a.w, h = a.h;
-    for (int s = 0; s < nsamples; s++) {
-        double alpha = (1.0 + (double)s) / ((double)nsamples + 1.0);
-        double x0 = alpha * p[ea][0] + (1.0 - alpha) * p[eb][0];
-        double y0 = alpha * p[ea][1] + (1.0 - alpha) * p[eb][1];
-        double Mn = 0, Mcount = 0;
-        int range = a.decimate + 1;
-        for (int n = -range; n <= range; n++) {
-            double grange = 1.0;
-            int x1 = (int)(x0 + ((double)n + grange) * nx), y1 = (int)(y0 + ((double)n + grange) * ny);
-            if (x1 < 0 || x1 >= w || y1 < 0 || y1 >= h) continue;
-            int x2 = (int)(x0 + ((double)n - grange) * nx), y2 = (int)(y0 + ((double)n - grange) * ny);
-            if (x2 < 0 || x2 >= w || y2 < 0 || y2 >= h) continue;
-            int g1 = im[(size_t)y1 * a.stride + x1], g2 = im[(size_t)y2 * a.stride + x2];
-            if (g1 < g2) continue;
-            double weight = (double)((g2 - g1) * (g2 - g1));
-            Mn += weight * (double)n;
-            Mcount += weight;
-        }
-        if (Mcount == 0) continue;
-        double n0 = Mn / Mcount;
-        double bx = x0 + n0 * nx, by = y0 + n0 * ny;
-        Mx += bx; My += by; Mxx += bx * bx; Mxy += bx * by; Myy += by * by; N += 1.0;
-    }
-    if (N < 2.0) {
-        line[0] = 0.5 * (p[ea][0] + p[eb][0]); line[1] = 0.5 * (p[ea][1] + p[eb][1]);
-        line[2] = nx; line[3] = ny;
-        return;
-    }
-    double Ex = Mx / N, Ey = My / N;
-    double Cxx = Mxx / N - Ex * Ex, Cxy = Mxy / N - Ex * Ey, Cyy = Myy / N - Ey * Ey;
-    double d = Cxx - Cyy, q = 4.0 * Cxy;
-    double disc = sqrt(d * d + q * Cxy);
-    double eig = 0.5 * (Cxx + Cyy + disc);
-    double nx1 = Cxx - eig, ny1 = Cxy, M1 = nx1 * nx1 + ny1 * ny1;
-    double nx2 = Cxy, ny2 = Cyy - eig, M2 = nx2 * nx2 + ny2 * ny2;
-    double fx, fy, M;
-    if (M1 > M2) { fx = nx1; fy = ny1; M = M1; } else { fx = nx2; fy = ny2; M = M2; }
-    double len = sqrt(M);
-    line[0] = Ex; line[1] = Ey;
-    if (len < 1e-12) { line[2] = nx; line[3] = ny; }
-    else { line[2] = fx / len; line[3] = fy / len; }
-}
 
 // Diagnostic build only (-DCK_FIT_PROFILE): per-phase cycle totals of k_fit, written to a buffer of their own.
 #ifdef CK_FIT_PROFILE
@@ -354,19 +232,6 @@ __device__ __forceinline__ int wrap_index(int i, int sz) { // i in [-HALO, sz + 
     if (i < 0) i += sz;   // one step each way is enough: i >= -HALO >= -sz, and a span ends before sz + HALO <= 2 * sz
     if (i >= sz) i -= sz;
     return i;
-}
-// gradient-magnitude weight of a sorted point (x,y in half pixels)
-__device__ __forceinline__ uint32_t point_weight(const FitArgs &a, const uint8_t *qim, uint32_t xy) {
-    int x = (int)(xy >> 13), y = (int)(xy & 0x1FFF);
-    int ix = (x + 1) >> 1, iy = (y + 1) >> 1;
-    uint32_t W = 1;
-    if (ix > 0 && ix + 1 < a.qw && iy > 0 && iy + 1 < a.qh) {
-        const uint8_t *row = qim + (size_t)iy * a.qstride + ix;
-        int gx = (int)row[1] - (int)row[-1];
-        int gy = (int)row[a.qstride] - (int)row[-a.qstride];
-        W = isqrt_u32((uint32_t)(gx * gx + gy * gy)) + 1;
-    }
-    return W;
 }
 __device__ __forceinline__ M6 moments_of(uint32_t xy, uint32_t Wt) {
     long long X = (long long)(xy >> 13) + 1, Y = (long long)(xy & 0x1FFF) + 1, W = Wt;
