@@ -5,15 +5,19 @@
 // are made on int64 moments or on doubles evaluated in the oracle's order with -ffp-contract=off.
 //
 // Per cluster (template: NTH threads, up to CAP points, chunks of CH points):
-//   1. bounding box and border direction (integer reductions over the raw points);
-//   2. exact 60-bit angular keys -> bitonic sort in LDS -> drop duplicate coordinates;
-//   3. chunk loop: gradient weights (image gather), int64 moment prefix sums over the chunk + halo (block scan),
-//      windowed line-fit error, 7-tap smoothing, local maxima appended to a per-cluster list that reuses the
-//      cluster's own (now dead) slice of the point array;
-//   4. keep the max_nmaxima strongest maxima, evaluate every 4-subset in parallel (argmin with the oracle's
-//      lexicographic tie-break), intersect the four lines, area/angle/winding checks, optional edge refinement.
-// Clusters are dispatched through per-size-class work lists built by k_classify (S <= 512, M <= 4096,
-// L <= 16384 points); each variant is a persistent grid that pulls cluster indices until the list is drained.
+//   1. points arrive packed (4 bytes, ck_internal.h); bounding box and border direction are integer reductions (DPP);
+//   2. exact 60-bit angular keys -> bucketed rank sort (counting pass over angle buckets + ranks inside a bucket; LDS
+//      for the classes whose keys fit in registers, a per-workgroup L2-resident scratch for the large one; the bitonic
+//      network remains as the fallback for clusters whose angles pile up) -> duplicate coordinates dropped (ballot scan);
+//   3. gradient weights: one u16 gather per point from the weight image k_weight_image wrote;
+//   4. chunk loop: moment prefix sums over the chunk + halo (DPP wave scans; first-order sums in 32 bit), windowed
+//      line-fit error, 7-tap smoothing fused with the maxima test, maxima appended to a per-cluster list;
+//   5. the max_nmaxima strongest maxima (rank-based selection), moment sums at them from a 32/128-point table, one line
+//      fit per ordered pair, every 4-subset evaluated in parallel (argmin with the oracle's lexicographic tie-break);
+//   6. lines, corners, area/angle/winding checks on four lanes, wave-parallel edge refinement.
+// Clusters are dispatched through per-size-class work lists built by k_classify (<= 512, <= 2048, <= 4096, <= 16384
+// points); each variant is a persistent grid: static striding for the two small classes, a dequeue counter for the two
+// large ones.  The phases can be cut short for measurements with CK_FIT_STOP_AFTER (tools/ablate_fit.sh).
 #include <stdlib.h>
 
 #include "ck_internal.h"
