@@ -10,9 +10,10 @@
 //   k_tile   one workgroup per 64x128 tile: coalesced 16-byte loads of the tile + 4-px halo into LDS, 4x4
 //            tile min/max, 3x3 dilation, tri-state threshold (written once, 16 B/lane), bit-parallel
 //            union-find in LDS (one lane per 64-pixel row segment and colour, runs found with clz/ctz on u64
-//            masks), labels written once (64 B/lane).  HBM traffic 1.2 R + 1 W + 4 W bytes per pixel.
-//   k_merge  one thread per tile-ring pixel: joins components across tile boundaries with atomicMin on the
-//            label words of the (few) roots involved.
+//            masks, u16 parents, saturating u8 sizes: 26 KB of LDS, six workgroups per CU), labels written once
+//            (64 B/lane), ring-touching roots appended per wave.  HBM traffic 1.2 R + 1 W + 4 W bytes per pixel.
+//   k_merge  one thread per tile-ring pixel: links reduced to pairs of tile-local roots, de-duplicated per tile in an
+//            LDS hash set, joined with atomicMin on the label words of the roots involved.
 //   k_roots  flattens the entries of ring-touching roots and accumulates their sizes into csize[].
 // No full-frame relabel pass exists: interior components are final when k_tile writes them; ring-touching
 // ones are resolved by consumers with one extra hop (label word format in ck_internal.h).

@@ -4,7 +4,7 @@
 // (crates/apriltags/src/lib.rs:301); the outputs are exactly what the reference consumes: id() (:306),
 // corners() (:310-314) and the number of detections (:302,354).  Bit-exact with oracle/detector.c
 // (homography_compute, quad_decode, ora_decode_quads): every accumulation that the oracle does sequentially is
-// done by one lane in the same order; only order-free work (bit sampling, sharpening cells, codebook search)
+// done by one lane in the same order; order-free work (border and bit sampling, sharpening cells, codebook search)
 // is spread over the wave.
 #include "ck_internal.h"
 

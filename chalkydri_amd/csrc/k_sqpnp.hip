@@ -4,11 +4,12 @@
 // build_linear_system :124-180, solve_rotation_candidates :396-428, optimization :463-480, nearest_so3 :42-59) and
 // the per-frame glue of crates/apriltags/src/lib.rs:293-379.  All arithmetic is f64.
 //
-// One 64-lane wave per problem.  The work is ~0.3 MFLOP and latency-bound, so the mapping favours determinism over
-// peak rate: every entry of Q_rr/Q_rt/Q_tt is accumulated by ONE lane over the points in index order (same sums as
-// the scalar code, no atomics, no reduction tree); the 9x9 Jacobi eigen-decomposition runs its rotations with 9 lanes
-// updating one row/column element each; the six SQP refinements (15x15 KKT systems, LU with partial pivoting) run on
-// six lanes in parallel with their matrices in LDS.  MFMA is deliberately not used: the only contraction,
+// Two waves per problem.  The work is ~0.3 MFLOP and latency-bound, so the mapping favours determinism over peak rate:
+// every entry of Q_rr/Q_rt/Q_tt is accumulated by ONE lane over the points in index order (same sums as the scalar code,
+// no atomics, no reduction tree); the 9x9 Jacobi eigen-decomposition runs its rotations with 9 lanes updating one
+// row/column element each; the six SQP refinements run as six groups of 16 lanes, each lane holding one row of the 15x15
+// KKT system in registers (LU with partial pivoting: pivot rows travel by shuffle, rows are never moved); the cheirality
+// test of the winner selection is spread over a wave.  MFMA is deliberately not used: the only contraction,
 // (9 x 3N)(3N x 9) with N <= 120, is 0.2 MFLOP — see DESIGN.md.
 #include <math.h>
 #include <string.h>
