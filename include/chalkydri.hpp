@@ -432,6 +432,11 @@ class AprilTags {
         for (int i = 0; i < n; i++) r.emplace_back(out[i], valid[i] != 0);
         return r;
     }
+    // `ts` of a record is the processing latency in microseconds, clock.now() - tov (lib.rs:351,366): the device leaves it
+    // zero, the host stamps it when the batch comes back.  tov_us[i] = time of validity of frame i on the same clock.
+    static void stamp(std::vector<std::pair<whacknet::VisionMeasurement, bool>> &recs, const std::vector<uint64_t> &tov_us, uint64_t now_us) {
+        for (size_t i = 0; i < recs.size() && i < tov_us.size(); i++) recs[i].first.ts = now_us - tov_us[i];
+    }
     std::pair<whacknet::VisionMeasurement, bool> process(const ck_image_u8_t &img, std::optional<double> gyro) {
         return process(std::vector<ck_image_u8_t>{img}, std::vector<std::optional<double>>{gyro})[0];
     }
