@@ -27,12 +27,36 @@ def check(code, where=""):
         raise ChalkydriError(code, where)
 
 
+def _share_torch_hip_runtime():
+    """One HIP runtime per process.  PyTorch-ROCm ships its own libamdhip64; if it and the system one (which our library
+    is linked against) both get loaded — which happens when this library is loaded before torch — the second one finds no
+    GPU.  When torch is installed, its runtime is therefore put in place first, exactly as when torch is imported first
+    (bench.py's order).  Without torch the system runtime is used."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def lib():
     global _lib
     if _lib is not None:
         return _lib
     if not os.path.exists(LIB_PATH):
         raise ImportError(f"{LIB_PATH} is missing: build the HIP extension first (no CPU fallback exists)")
+    _share_torch_hip_runtime()
     L = C.CDLL(LIB_PATH)
     P = C.POINTER
     L.ck_strerror.restype = C.c_char_p

@@ -37,11 +37,12 @@ def init(backend=None):
     return rank, local_rank, world
 
 
-def gather_records(records, world):
-    """records: uint8 torch tensor [n, 64] (device tensor with nccl, CPU tensor with gloo).  Returns [world*n, 64] on every rank."""
+def gather_records(records, world, force=False):
+    """records: uint8 torch tensor [n, 64] (device tensor with nccl, CPU tensor with gloo).  Returns [world*n, 64] on every rank.
+    A single rank skips the collective unless `force` (used by the one-rank RCCL rehearsal in tests/test_gpu_pose.py)."""
     import torch
     import torch.distributed as dist
-    if world == 1:
+    if world == 1 and not force:
         return records
     out = torch.empty((world * records.shape[0], RECORD_BYTES), dtype=torch.uint8, device=records.device)
     dist.all_gather_into_tensor(out, records.contiguous())

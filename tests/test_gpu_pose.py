@@ -186,3 +186,47 @@ def test_sqpnp_golden_vectors(built):
             continue
         assert np.abs(g["rot"] - want["rot"]).max() < TOL and np.abs(g["pos"] - want["pos"]).max() < TOL and abs(g["yaw"] - want["yaw"]) < TOL
     det.close()
+
+
+def test_rccl_gather_one_rank(built):
+    """The multi-GPU exchange is one all_gather of 64-byte records from the device buffer the pose stage fills.  With one GPU
+    the collective can still be rehearsed on a one-rank RCCL group: same call, same tensor, same layout.  Runs in a fresh
+    process that initialises torch first, like bench.py (torch ships its own HIP runtime and wants to be the first user)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = r"""
+import os, sys
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import numpy as np, torch, torch.distributed as tdist
+torch.cuda.set_device(0)
+import scenes
+from chalkydri_amd import dist
+from chalkydri_amd.apriltags import AprilTags
+w, h, f, n = 640, 480, 600.0, 3
+layout = scenes.wall_layout(6, cols=3)
+r2c = {"roll": 0.0, "pitch": 0.0, "yaw": 0.0, "x": 0.2, "y": 0.0, "z": 0.6}
+calib = scenes.pinhole_calib(f, w / 2.0, h / 2.0)
+frames = np.stack([scenes.render_view(40 + i, w, h, f, layout, (2.0, 0.05 * i, 0.0), r2c, noise_amp=1)[0] for i in range(n)])
+task = AprilTags(w, h, layout, calib, r2c, cam_id=9, max_batch=n)
+want, valid = task.process_batch(frames, [0.0] * n)
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29541")
+tdist.init_process_group(backend="nccl", rank=0, world_size=1)
+dev = torch.device("cuda", 0)
+d_gyro = torch.zeros(n, dtype=torch.float64, device=dev); d_has = torch.ones(n, dtype=torch.uint8, device=dev)
+d_rec = torch.zeros((n, 64), dtype=torch.uint8, device=dev); d_valid = torch.zeros(n, dtype=torch.int32, device=dev)
+task.detector.upload(frames)
+task.process_uploaded_into(n, d_gyro.data_ptr(), d_has.data_ptr(), d_rec.data_ptr(), d_valid.data_ptr())
+out = dist.gather_records(d_rec, 1, force=True)
+torch.cuda.synchronize()
+got = dist.records_to_numpy(out)
+assert out.shape == (n, 64) and d_valid.cpu().numpy().tolist() == [int(v) for v in valid]
+for i in range(n):
+    assert bytes(out[i].cpu().numpy()) == bytes(want[i])
+    assert got["camera_id"][i] == 9 and got["tag_count"][i] == 6
+tdist.destroy_process_group()
+print("GATHER OK")
+"""
+    r = subprocess.run([sys.executable, "-c", script % (root, os.path.join(root, "tests"))], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "GATHER OK" in r.stdout, r.stdout[-1000:] + r.stderr[-3000:]
