@@ -230,3 +230,39 @@ print("GATHER OK")
 """
     r = subprocess.run([sys.executable, "-c", script % (root, os.path.join(root, "tests"))], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "GATHER OK" in r.stdout, r.stdout[-1000:] + r.stderr[-3000:]
+
+
+def test_full_size_batch_properties(oracle):
+    """BASELINE config 2 at full size (1280x800 x 256 frames, the bench workload): the oracle cannot run 256 frames in seconds,
+    so the batch is 8 distinct frames repeated 32 times in shuffled positions.  Properties: a frame's record does not depend
+    on where it sits in the batch or on which stream processed it (idempotence over copies), a second run returns the same
+    bytes, and the 8 distinct records equal the oracle's."""
+    from chalkydri_amd.apriltags import AprilTags
+    w, h, n, uniq = 1280, 800, 256, 8
+    frames8, gyro8, layout, calib, r2c = scenes.bench_stream(2, uniq, w, h, 6, stream=0, unique=uniq, noise_amp=3)
+    rng = np.random.default_rng(0)
+    which = rng.permutation(np.repeat(np.arange(uniq), n // uniq))
+    frames = frames8[which]
+    gyro = [float(gyro8[k]) for k in which]
+    task = AprilTags(w, h, layout, calib, r2c, cam_id=0, max_batch=n)
+    recs, valid = task.process_batch(frames, gyro)
+    again, valid2 = task.process_batch(frames, gyro)
+    assert valid.all() and np.array_equal(valid, valid2)
+    first = {}
+    for i in range(n):
+        assert bytes(recs[i]) == bytes(again[i])
+        k = int(which[i])
+        if k in first:
+            assert bytes(recs[i]) == first[k], f"frame copy {i} of {k} differs"
+        else:
+            first[k] = bytes(recs[i])
+    cfg = default_config(w, h)
+    for k in range(uniq):
+        out = A.VisionMeasurement()
+        v = C.c_int(0)
+        oracle.lib().ora_process_frame(C.c_void_p(frames8[k].ctypes.data), w, h, w, C.byref(cfg), C.byref(task._pp),
+                                       C.c_double(float(gyro8[k])), 1, C.byref(out), C.byref(v))
+        r = A.VisionMeasurement.from_buffer_copy(first[k])
+        assert v.value == 1 and r.tag_count == out.tag_count
+        assert abs(r.pose_x - out.pose_x) < 1e-6 and abs(r.pose_y - out.pose_y) < 1e-6 and abs(r.pose_rot - out.pose_rot) < 1e-7
+    task.detector.close()
