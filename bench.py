@@ -70,7 +70,7 @@ def main():
     ap.add_argument("--tags", type=int, default=6)
     ap.add_argument("--noise", type=int, default=3)
     ap.add_argument("--decimate", type=int, default=1)
-    ap.add_argument("--unique", type=int, default=32, help="distinct frames rendered per stream, repeated to fill the batch")
+    ap.add_argument("--unique", type=int, default=0, help="distinct frames rendered per stream (0 = every frame of the batch is distinct)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -89,6 +89,8 @@ def main():
     dist.init("nccl")
 
     w, h, n = args.width, args.height, args.batch
+    if args.unique <= 0 or args.unique > n:
+        args.unique = n
     frames, gyro, layout, calib, r2c = scenes.bench_stream(2, n, w, h, args.tags, stream=rank, unique=args.unique, noise_amp=args.noise)
     task = AprilTags(w, h, layout, calib, r2c, cam_id=rank, max_batch=n, device=local_rank, quad_decimate=args.decimate)
     task.detector.upload(frames)                      # inputs resident in HBM before the timed region
