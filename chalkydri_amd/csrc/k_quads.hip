@@ -229,8 +229,18 @@ constexpr int MAXSEL = 12; // largest max_nmaxima supported
 
 struct PairFit { double err, mse, nx, ny; };
 
-// all 4-subsets of {0..MAXSEL-1}, packed m0<<12|m1<<8|m2<<4|m3 (filled once per handle by ck_launch_fit_quads)
-__device__ uint16_t g_combos[495];
+// all 4-subsets of {0..MAXSEL-1}, packed m0<<12|m1<<8|m2<<4|m3
+struct ComboTable {
+    uint16_t v[495];
+    constexpr ComboTable() : v() {
+        int k = 0;
+        for (int m0 = 0; m0 < MAXSEL - 3; m0++)
+            for (int m1 = m0 + 1; m1 < MAXSEL - 2; m1++)
+                for (int m2 = m1 + 1; m2 < MAXSEL - 1; m2++)
+                    for (int m3 = m2 + 1; m3 < MAXSEL; m3++) v[k++] = (uint16_t)((m0 << 12) | (m1 << 8) | (m2 << 4) | m3);
+    }
+};
+__device__ const ComboTable g_combo_table{}; // built at compile time: nothing to upload, valid on every device of the process
 
 __device__ __forceinline__ int wrap_index(int i, int sz) { // i in [-HALO, sz + CH + HALO): bring into [0, sz)
     if (i < 0) i += sz;   // one step each way is enough: i >= -HALO >= -sz, and a span ends before sz + HALO <= 2 * sz
@@ -961,7 +971,7 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(WPS, 8))) v
         int bestc = 1 << 30;
         {
             for (int cb = tid; cb < 495; cb += NTH) { // every lane walks its own subsets; ties resolved by the packed index
-                const int pk = g_combos[cb];
+                const int pk = g_combo_table.v[cb];
                 const int m0 = pk >> 12, m1 = (pk >> 8) & 15, m2 = (pk >> 4) & 15, m3 = pk & 15;
                 if (m3 >= nsel) continue;
                 {
@@ -1297,19 +1307,6 @@ int ck_launch_fit_quads(ck_handle *h, const uint8_t *qframes, int qstride, size_
     if (a.min_tag_width < 3) a.min_tag_width = 3;
     a.ws = ws;
     { const char *e = getenv("CK_FIT_STOP_AFTER"); a.stop_after = e ? atoi(e) : 99; }
-    {
-        static bool combos_ready = false; // process-wide table, written once
-        if (!combos_ready) {
-            uint16_t tab[495];
-            int k = 0;
-            for (int m0 = 0; m0 < MAXSEL - 3; m0++)
-                for (int m1 = m0 + 1; m1 < MAXSEL - 2; m1++)
-                    for (int m2 = m1 + 1; m2 < MAXSEL - 1; m2++)
-                        for (int m3 = m2 + 1; m3 < MAXSEL; m3++) tab[k++] = (uint16_t)((m0 << 12) | (m1 << 8) | (m2 << 4) | m3);
-            CK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_combos), tab, sizeof tab));
-            combos_ready = true;
-        }
-    }
     int cus = 256;
     a.list = lists; a.list_count = list_counts; a.head = heads;
     hipLaunchKernelGGL((k_fit<64, 512, 64, true, 3>), dim3((unsigned)(cus * 12)), dim3(64), 0, h->stream, a);
