@@ -43,23 +43,24 @@ __device__ __forceinline__ M6 m6_sub(M6 a, M6 b) { a.Mx -= b.Mx; a.My -= b.My; a
 __device__ __forceinline__ M6 m6_zero() { M6 z = {0, 0, 0, 0, 0, 0}; return z; }
 
 __device__ __forceinline__ unsigned long long angle_key(int x, int y, int xmin, int xmax, int ymin, int ymax) {
-    long long dx = 4ll * x - 2ll * (xmin + xmax) - 1;
-    long long dy = 4ll * y - 2ll * (ymin + ymax) + 1;
-    long long ax = dx < 0 ? -dx : dx, ay = dy < 0 ? -dy : dy;
-    int oct, inv;
-    long long num, den;
-    if (dy < 0) {
-        if (dx < 0) { if (ay <= ax) { oct = 0; inv = 0; num = ay; den = ax; } else { oct = 1; inv = 1; num = ax; den = ay; } }
-        else        { if (ay > ax)  { oct = 2; inv = 0; num = ax; den = ay; } else { oct = 3; inv = 1; num = ay; den = ax; } }
-    } else {
-        if (dx > 0) { if (ay <= ax) { oct = 4; inv = 0; num = ay; den = ax; } else { oct = 5; inv = 1; num = ax; den = ay; } }
-        else        { if (ay > ax)  { oct = 6; inv = 0; num = ax; den = ay; } else { oct = 7; inv = 1; num = ay; den = ax; } }
-    }
-    // floor(num * 2^30 / den) by two 15-bit long-division steps (num <= den < 2^15): exact, 32-bit only
-    uint32_t n32 = (uint32_t)num, d32 = (uint32_t)den;
-    uint32_t q1 = (n32 << 15) / d32, r1 = (n32 << 15) - q1 * d32;
-    uint32_t q2 = (r1 << 15) / d32;
-    unsigned long long frac = ((unsigned long long)q1 << 15) + q2;
+    // everything fits 32 bits (|dx|, |dy| < 2^15) and the octant is picked without branches:
+    //   quadrant q: 0 (dy<0,dx<0)  1 (dy<0,dx>=0)  2 (dy>=0,dx>0)  3 (dy>=0,dx<=0);  inside a quadrant the second octant
+    //   (fraction counted downwards, inv) starts where |dy| exceeds |dx| for even q, where it stops exceeding it for odd q;
+    //   the fraction is always min/max of the two magnitudes
+    const int dx = 4 * x - 2 * (xmin + xmax) - 1;
+    const int dy = 4 * y - 2 * (ymin + ymax) + 1;
+    const int ax = dx < 0 ? -dx : dx, ay = dy < 0 ? -dy : dy;
+    const int q = dy < 0 ? (dx < 0 ? 0 : 1) : (dx > 0 ? 2 : 3);
+    const int steep = ay > ax ? 1 : 0;
+    const int inv = (q & 1) ? 1 - steep : steep;
+    const int oct = 2 * q + inv;
+    const int num = ax < ay ? ax : ay, den = ax < ay ? ay : ax;
+    // floor(num * 2^30 / den), num <= den < 2^15 (the oracle does two 15-bit long-division steps).  Here: one IEEE f64
+    // division.  num * 2^30 < 2^45 and den are exact doubles; a quotient that is not an integer lies at least 1/den > 2^-15
+    // away from one while the rounding error is below 2^-22, so truncating the correctly rounded quotient gives the exact
+    // floor — and two integer divisions (~100 instructions on this hardware) become ~20.  den >= 1: dx is odd.
+    const double qd = ((double)(uint32_t)num * 1073741824.0) / (double)(uint32_t)den;
+    unsigned long long frac = (unsigned long long)(uint32_t)qd;
     if (inv) frac = (1ull << 30) - frac;
     return ((unsigned long long)oct << 57) | (frac << 26) | ((unsigned long long)x << 13) | (unsigned long long)y;
 }
