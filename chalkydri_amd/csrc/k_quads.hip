@@ -339,9 +339,8 @@ __device__ __forceinline__ long long keys_sort(unsigned long long *sKeys, long l
             unsigned long long raw = sKeys[i];
             int px = (int)(raw & 0xFFFF), py = (int)((raw >> 16) & 0xFFFF);
             int pgx = (int)(signed char)((raw >> 32) & 0xFF), pgy = (int)(signed char)((raw >> 40) & 0xFF);
-            long long dx = 4ll * px - 2ll * (xmin + xmax) - 1;
-            long long dy = 4ll * py - 2ll * (ymin + ymax) + 1;
-            dot += dx * pgx + dy * pgy;
+            const int dx = 4 * px - 2 * (xmin + xmax) - 1, dy = 4 * py - 2 * (ymin + ymax) + 1; // |.| < 2^15
+            dot += (long long)(dx * pgx + dy * pgy);
             key = angle_key(px, py, xmin, xmax, ymin, ymax);
         }
         kreg[e] = key;
@@ -384,9 +383,8 @@ __device__ __forceinline__ long long keys_bucket_sort(unsigned long long *sKeys,
             unsigned long long raw = sKeys[i];
             int px = (int)(raw & 0xFFFF), py = (int)((raw >> 16) & 0xFFFF);
             int pgx = (int)(signed char)((raw >> 32) & 0xFF), pgy = (int)(signed char)((raw >> 40) & 0xFF);
-            long long dx = 4ll * px - 2ll * (xmin + xmax) - 1;
-            long long dy = 4ll * py - 2ll * (ymin + ymax) + 1;
-            dot += dx * pgx + dy * pgy;
+            const int dx = 4 * px - 2 * (xmin + xmax) - 1, dy = 4 * py - 2 * (ymin + ymax) + 1; // |.| < 2^15
+            dot += (long long)(dx * pgx + dy * pgy);
             kreg[e] = angle_key(px, py, xmin, xmax, ymin, ymax);
         }
     }
@@ -476,9 +474,8 @@ __device__ __forceinline__ long long keys_bucket_sort_global(unsigned long long 
         unsigned long long raw = sKeys[i];
         int px = (int)(raw & 0xFFFF), py = (int)((raw >> 16) & 0xFFFF);
         int pgx = (int)(signed char)((raw >> 32) & 0xFF), pgy = (int)(signed char)((raw >> 40) & 0xFF);
-        long long dx = 4ll * px - 2ll * (xmin + xmax) - 1;
-        long long dy = 4ll * py - 2ll * (ymin + ymax) + 1;
-        dot += dx * pgx + dy * pgy;
+        const int dx = 4 * px - 2 * (xmin + xmax) - 1, dy = 4 * py - 2 * (ymin + ymax) + 1; // |.| < 2^15
+        dot += (long long)(dx * pgx + dy * pgy);
         atomicAdd(&hist[bucket_of(angle_key(px, py, xmin, xmax, ymin, ymax))], 1u);
     }
     dot = B::reduce_add(dot, sScratch);
