@@ -249,9 +249,13 @@ __device__ __forceinline__ int wrap_index(int i, int sz) { // i in [-HALO, sz + 
     return i;
 }
 __device__ __forceinline__ M6 moments_of(uint32_t xy, uint32_t Wt) {
-    long long X = (long long)(xy >> 13) + 1, Y = (long long)(xy & 0x1FFF) + 1, W = Wt;
+    // W <= 362, X, Y <= 8192: the first-order products fit 32 bits, the second-order ones are one 32x32->64 multiply each
+    const uint32_t X = (xy >> 13) + 1, Y = (xy & 0x1FFF) + 1;
+    const uint32_t wx = Wt * X, wy = Wt * Y;
     M6 m;
-    m.Mx = W * X; m.My = W * Y; m.Mxx = W * X * X; m.Mxy = W * X * Y; m.Myy = W * Y * Y; m.W = W;
+    m.Mx = (long long)wx; m.My = (long long)wy;
+    m.Mxx = (long long)((unsigned long long)wx * X); m.Mxy = (long long)((unsigned long long)wx * Y); m.Myy = (long long)((unsigned long long)wy * Y);
+    m.W = (long long)Wt;
     return m;
 }
 
@@ -783,9 +787,17 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(WPS, 8))) v
                     mx -= sP32[0][lo]; my -= sP32[1][lo]; mw -= sP32[2][lo];
                     m.Mxx -= sP64[0][lo]; m.Mxy -= sP64[1][lo]; m.Myy -= sP64[2][lo];
                 }
-                m.Mx = (long long)mx; m.My = (long long)my; m.W = (long long)mw;
                 double e;
-                fit_line_m(m, 2 * ksz + 1, nullptr, &e, nullptr);
+                {   // fit_line_m's error for this window, with the three first-order sums converted straight from 32 bits
+                    const double inv = 1.0 / (double)mw;
+                    const double Ex = (0.5 * (double)mx) * inv, Ey = (0.5 * (double)my) * inv;
+                    const double Cxx = (0.25 * (double)m.Mxx) * inv - Ex * Ex;
+                    const double Cxy = (0.25 * (double)m.Mxy) * inv - Ex * Ey;
+                    const double Cyy = (0.25 * (double)m.Myy) * inv - Ey * Ey;
+                    const double d = Cxx - Cyy, q4 = 4.0 * Cxy;
+                    const double disc = sqrt(d * d + q4 * Cxy);
+                    e = (double)(2 * ksz + 1) * (0.5 * ((Cxx + Cyy) - disc));
+                }
                 sErr[j] = e;
             }
             __syncthreads();
