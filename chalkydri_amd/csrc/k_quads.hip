@@ -231,6 +231,17 @@ constexpr int MAXSEL = 12; // largest max_nmaxima supported
 struct PairFit { double err, mse, nx, ny; };
 
 // all 4-subsets of {0..MAXSEL-1}, packed m0<<12|m1<<8|m2<<4|m3
+// all pairs a < b of {0..MAXSEL-1}, ordered by b then a and packed a << 4 | b: for nsel selected maxima the first
+// nsel*(nsel-1)/2 entries are exactly the pairs below nsel
+struct PairTable {
+    uint8_t v[MAXSEL * (MAXSEL - 1) / 2];
+    constexpr PairTable() : v() {
+        int k = 0;
+        for (int b = 1; b < MAXSEL; b++)
+            for (int a = 0; a < b; a++) v[k++] = (uint8_t)((a << 4) | b);
+    }
+};
+__device__ const PairTable g_pair_table{};
 struct ComboTable {
     uint16_t v[495];
     constexpr ComboTable() : v() {
@@ -948,32 +959,36 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(WPS, 8))) v
         if (a.stop_after == 6) continue;
         // ---- 5c. one line fit per ordered pair of maxima; the 4-subset search is then table lookups ------------------------
         PairFit *sF = reinterpret_cast<PairFit *>(sPraw);
-        {   // a one-wave workgroup needs two rounds for its up to 132 pairs: both fits of a lane are issued together so
-            // that their long f64 dependency chains overlap (an unused slot fits pair (0,1) and stores nothing)
-            constexpr int PU = (NTH == 64) ? 2 : 1;
-            const int npairs = nsel * nsel;
-            for (int pr0 = tid; pr0 < npairs; pr0 += PU * NTH) {
-                int sa[PU], sb[PU], Np[PU];
-                bool valid[PU];
-                M6 mm[PU];
-#pragma unroll
-                for (int u = 0; u < PU; u++) {
-                    const int pr = pr0 + u * NTH;
-                    sa[u] = pr / nsel; sb[u] = pr - sa[u] * nsel;
-                    valid[u] = pr < npairs && sa[u] != sb[u];
-                    if (!valid[u]) { sa[u] = 0; sb[u] = 1; }
-                    mm[u] = rangeM(sa[u], sb[u], &Np[u]);
-                }
-                PairFit f[PU];
-#pragma unroll
-                for (int u = 0; u < PU; u++) {
+        {   // lane k takes the pair a < b from the table and fits both directions in one go: a -> b with the line normal
+            // (the subset search reads normals of forward spans only), b -> a around the end without it; the two f64
+            // dependency chains overlap
+            const int npf = nsel * (nsel - 1) / 2;
+            if constexpr (NTH > 64) { // enough lanes for one fit each
+                const int npairs = nsel * nsel;
+                for (int pr = tid; pr < npairs; pr += NTH) {
+                    const int sa = pr / nsel, sb = pr - sa * nsel;
+                    if (sa == sb) continue;
+                    int N;
                     double lp[4], e, ms;
-                    fit_line_m(mm[u], Np[u], lp, &e, &ms);
-                    f[u].err = e; f[u].mse = ms; f[u].nx = lp[2]; f[u].ny = lp[3];
+                    const M6 m = rangeM(sa, sb, &N);
+                    fit_line_m(m, N, lp, &e, &ms);
+                    PairFit f;
+                    f.err = e; f.mse = ms; f.nx = lp[2]; f.ny = lp[3];
+                    sF[sa * MAXSEL + sb] = f;
                 }
-#pragma unroll
-                for (int u = 0; u < PU; u++)
-                    if (valid[u]) sF[sa[u] * MAXSEL + sb[u]] = f[u];
+            } else
+            for (int k = tid; k < npf; k += NTH) {
+                const int pk = g_pair_table.v[k], sa = pk >> 4, sb = pk & 15;
+                int Nf, Nw;
+                const M6 mf = rangeM(sa, sb, &Nf), mw = rangeM(sb, sa, &Nw);
+                double lp[4], ef, msf, ew, msw;
+                fit_line_m(mf, Nf, lp, &ef, &msf);
+                fit_line_m(mw, Nw, nullptr, &ew, &msw);
+                PairFit f;
+                f.err = ef; f.mse = msf; f.nx = lp[2]; f.ny = lp[3];
+                sF[sa * MAXSEL + sb] = f;
+                f.err = ew; f.mse = msw; f.nx = 0.0; f.ny = 0.0;
+                sF[sb * MAXSEL + sa] = f;
             }
         }
         __syncthreads();
