@@ -54,3 +54,42 @@ def test_ring_matches_upload_path(built):
     assert task.detector._L.ck_ingest_write(ring._g, 0, 0, arr, fourcc("YUYV")) != 0
     ring.close()
     task.detector.close()
+
+
+def test_strided_host_and_device_frames(built, oracle):
+    """image_u8_t {buf,width,height,stride} with stride > width (crates/apriltags/src/lib.rs:197-213; gst_to_cu.rs:60-63):
+    host frames through ck_detect_batch, and device-resident frames whose rows are not 16-byte aligned through
+    ck_detect_batch_device (the library restages them), give the detections of the tightly packed frames."""
+    import torch
+    from chalkydri_amd import default_config, synth
+    from chalkydri_amd.detector import AprilTagDetector
+    w, h, n, pad = 640, 480, 2, 11                      # stride 651: neither a multiple of 16 nor of 4
+    frames, _ = synth.render_batch(31, n, w, h, 4, noise_amp=2)
+    padded = np.full((n, h, w + pad), 0x5A, np.uint8)
+    padded[:, :, :w] = frames
+    det = AprilTagDetector(w, h, max_batch=n)
+    want = det.detect_batch(frames)
+    # host path: hand-built image_u8_t views into the padded buffer
+    imgs = (A.ImageU8 * n)()
+    for i in range(n):
+        imgs[i].buf, imgs[i].width, imgs[i].height, imgs[i].stride = padded[i].ctypes.data, w, h, w + pad
+    cap = 64
+    dets = (A.Detection * (cap * n))()
+    counts = (C.c_int32 * n)()
+    status = (C.c_uint32 * n)()
+    assert det._L.ck_detect_batch(det._h, imgs, n, dets, cap, counts, status) == 0
+    # device path: the same padded frames resident on the GPU
+    d = torch.from_numpy(padded).cuda()
+    dets2 = (A.Detection * (cap * n))()
+    counts2 = (C.c_int32 * n)()
+    status2 = (C.c_uint32 * n)()
+    assert det._L.ck_detect_batch_device(det._h, C.c_void_p(d.data_ptr()), n, w + pad, (w + pad) * h, dets2, cap, counts2, status2) == 0
+    cfg = default_config(w, h)
+    for i in range(n):
+        ref, _ = oracle.detect(frames[i], cfg)
+        assert counts[i] == counts2[i] == len(want[i]) == len(ref) and status[i] == status2[i] == 0
+        for k in range(counts[i]):
+            for got in (dets[i * cap + k], dets2[i * cap + k]):
+                assert got.id == want[i][k].id() and got.hamming == want[i][k].hamming()
+                assert [list(p) for p in got.p] == np.asarray(want[i][k].corners()).tolist()
+    det.close()
