@@ -266,3 +266,42 @@ def test_full_size_batch_properties(oracle):
         assert v.value == 1 and r.tag_count == out.tag_count
         assert abs(r.pose_x - out.pose_x) < 1e-6 and abs(r.pose_y - out.pose_y) < 1e-6 and abs(r.pose_rot - out.pose_rot) < 1e-7
     task.detector.close()
+
+
+def test_glue_filters(oracle):
+    """AprilTags::process filters (crates/apriltags/src/lib.rs:306-330): tags missing from the field layout do not enter the
+    solve but still count in tag_count; a frame whose tags are all unknown, a frame without tags, and a frame without gyro
+    publish the empty record.  Device == oracle in every case."""
+    from chalkydri_amd.apriltags import AprilTags
+    w, h, f = 640, 480, 600.0
+    full = scenes.wall_layout(6, cols=3)
+    r2c = {"roll": 0.0, "pitch": 0.0, "yaw": 0.0, "x": 0.2, "y": 0.0, "z": 0.6}
+    calib = scenes.pinhole_calib(f, w / 2.0, h / 2.0)
+    pose = (2.1, 0.05, 0.02)
+    seen, _ = scenes.render_view(61, w, h, f, full, pose, r2c, noise_amp=1)      # six tags, ids 1..6
+    blank = np.full((h, w), 128, np.uint8)
+    known3 = {"tags": full["tags"][:3], "field": full["field"]}                   # the layout knows ids 1..3 only
+    other = scenes.wall_layout(6, cols=3, first_id=101)                           # a layout that knows none of them
+    cfg = default_config(w, h)
+
+    def both(layout, frames, gyros):
+        task = AprilTags(w, h, layout, calib, r2c, cam_id=4, max_batch=len(frames))
+        recs, valid = task.process_batch(np.stack(frames), gyros)
+        outs = []
+        for fr, g in zip(frames, gyros):
+            out = A.VisionMeasurement()
+            v = C.c_int(0)
+            oracle.lib().ora_process_frame(C.c_void_p(fr.ctypes.data), w, h, w, C.byref(cfg), C.byref(task._pp),
+                                           C.c_double(g or 0.0), 0 if g is None else 1, C.byref(out), C.byref(v))
+            outs.append((out, v.value))
+        task.detector.close()
+        return recs, valid, outs
+
+    recs, valid, outs = both(known3, [seen, blank, seen], [pose[2], pose[2], None])
+    assert list(valid) == [1, 0, 0] == [o[1] for o in outs]
+    assert recs[0].tag_count == outs[0][0].tag_count == 6                      # ALL detections are counted (lib.rs:354)
+    assert abs(recs[0].pose_x - outs[0][0].pose_x) < 1e-6 and abs(recs[0].pose_rot - outs[0][0].pose_rot) < 1e-7
+    assert abs(recs[0].pose_x - pose[0]) < 0.05                                # three known tags still locate the robot
+    assert bytes(recs[1]) == bytes(outs[1][0]) and bytes(recs[2]) == bytes(outs[2][0]) and recs[1].tag_count == 0
+    recs, valid, outs = both(other, [seen], [pose[2]])
+    assert list(valid) == [0] == [outs[0][1]] and bytes(recs[0]) == bytes(outs[0][0])
