@@ -74,3 +74,25 @@ def test_product_package_never_touches_the_oracle():
                 text = open(path, errors="ignore").read()
                 assert "pyoracle" not in text and "libck_oracle" not in text and "ck_oracle" not in text, path
                 assert not re.search(r"^\s*(from|import)\s+oracle", text, flags=re.M), path
+
+
+def test_create_validates_before_touching_a_device(built):
+    """Argument errors are reported without a GPU: the order in ck_create is validation first, device second."""
+    import ctypes as C
+    from chalkydri_amd import _abi as A, default_config
+    from chalkydri_amd.detector import _bind
+    from chalkydri_amd._lib import lib
+    L = _bind(lib())
+    h = C.c_void_p()
+
+    def rc(**kw):
+        size = kw.pop("size", (640, 480))
+        cfg = default_config(size[0], size[1], **kw)
+        return L.ck_create(C.byref(cfg), C.byref(h))
+    assert rc(size=(8, 8)) == A.CK_EINVAL                       # smaller than the 16-pixel minimum
+    assert rc(size=(642, 480)) == A.CK_EUNSUPPORTED             # sides must be multiples of 4
+    assert rc(quad_decimate=3) == A.CK_EUNSUPPORTED
+    assert rc(min_component_px=200) == A.CK_EUNSUPPORTED        # tile-local sizes saturate at 127
+    assert rc() in (A.CK_OK, A.CK_ENODEVICE)                    # a valid config fails only for lack of a device
+    if h.value:
+        L.ck_destroy(h)
