@@ -276,3 +276,26 @@ def test_capacity_overflow_is_a_status_bit(oracle):
     dets, status = det.detect_batch(many[None], cap=2, return_status=True)
     assert status[0] & A.CK_FRAME_DETS_OVERFLOW and len(dets[0]) == 2
     det.close()
+
+
+@pytest.mark.parametrize("kw", [{"max_nmaxima": 12}, {"max_nmaxima": 4}, {"refine_edges": 0}, {"max_line_fit_mse": 4.0, "cos_critical_rad": 0.9}])
+def test_quads_match_oracle_under_other_settings(oracle, kw):
+    """Quad-fit parameters away from their defaults (12 maxima = 66 forward pairs, more than a wave; 4 = a single subset;
+    no edge refinement; tighter thresholds): quads and detections still equal the oracle's."""
+    from chalkydri_amd.detector import AprilTagDetector
+    w, h, n = 640, 480, 2
+    frames, _ = _synth(15, w, h, n, 4, noise_amp=3)
+    det = AprilTagDetector(w, h, max_batch=n, **kw)
+    got = det.quads(frames)
+    dets, status = det.detect_batch(frames, cap=64, return_status=True)
+    cfg = default_config(w, h, **kw)
+    for i in range(n):
+        th = oracle.threshold(frames[i])
+        lab, sz = oracle.segment(th)
+        ocl, opts, _ = oracle.clusters(th, lab, sz)
+        oq, _ = oracle.fit_quads(frames[i], cfg, ocl, opts)
+        assert np.array_equal(_quads_np(oq), _quads_np(got[i]))
+        want, st = oracle.detect(frames[i], cfg)
+        assert status[i] == st
+        _same_dets(dets[i], want)
+    det.close()
