@@ -299,3 +299,25 @@ def test_quads_match_oracle_under_other_settings(oracle, kw):
         assert status[i] == st
         _same_dets(dets[i], want)
     det.close()
+
+
+@pytest.mark.parametrize("kw", [{"min_white_black_diff": 20}, {"min_component_px": 60, "min_cluster_pixels": 80}, {"decode_sharpening": 0.0}])
+def test_detect_matches_oracle_under_other_front_end_settings(oracle, kw):
+    """Threshold contrast gate, component / cluster size gates and decode sharpening away from their defaults."""
+    from chalkydri_amd.detector import AprilTagDetector
+    w, h, n = 640, 480, 2
+    frames, _ = _synth(16, w, h, n, 4, noise_amp=3)
+    det = AprilTagDetector(w, h, max_batch=n, **kw)
+    cfg = default_config(w, h, **kw)
+    thr = det.threshold(frames)
+    labels, sizes = det.segment(frames)
+    dets, status = det.detect_batch(frames, cap=64, return_status=True)
+    for i in range(n):
+        oth = oracle.threshold(frames[i], cfg.min_white_black_diff)
+        assert np.array_equal(thr[i], oth)
+        lab, sz = oracle.segment(oth)
+        assert np.array_equal(labels[i], lab) and np.array_equal(sizes[i], sz)
+        want, st = oracle.detect(frames[i], cfg)
+        assert status[i] == st
+        _same_dets(dets[i], want)
+    det.close()
