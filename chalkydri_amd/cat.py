@@ -14,6 +14,54 @@ from .detector import AprilTagDetector, _bind
 BLACK, WHITE, OTHER = 0, 1, 2  # utils.rs:2-6
 
 
+# ---- src/utils.rs helpers.  None of them is on the device path (the reference never calls the last three either);
+# ---- they are kept so that code written against the crate's `utils` module finds the same names and results.
+def grayscale(r, g, b):
+    """utils.rs:33-46: trunc(fma(r, 0.33f, fma(g, 0.33f, b * 0.33f))) in f32, saturating cast to u8."""
+    k = np.float32(0.33)
+    inner = np.float32(np.float64(np.float32(g)) * np.float64(k) + np.float64(np.float32(b) * k))   # single rounding = fmaf
+    outer = np.float32(np.float64(np.float32(r)) * np.float64(k) + np.float64(inner))
+    return int(min(255.0, max(0.0, np.trunc(outer))))
+
+
+def fast_angle(p):
+    """utils.rs:51-72: FAST ring position 1..16 -> degrees in steps of 22.5."""
+    if not 1 <= p <= 16:
+        raise ValueError("invalid FAST point")
+    return (p - 1) * 22.5
+
+
+COLLINEAR, CLOCKWISE, COUNTERCLOCKWISE = 0, 1, 2  # utils.rs:74-79 (derive order)
+
+
+def orientation(p, q, r):
+    """utils.rs:82-101: sign of (qy-py)(rx-qx) - (qx-px)(ry-qy) in i32."""
+    v = (int(q[1]) - int(p[1])) * (int(r[0]) - int(q[0])) - (int(q[0]) - int(p[0])) * (int(r[1]) - int(q[1]))
+    return COLLINEAR if v == 0 else (CLOCKWISE if v > 0 else COUNTERCLOCKWISE)
+
+
+def find_convex_hull(points):
+    """utils.rs:113-152 (gift wrapping from the left-most point, first one on ties; the last counter-clockwise candidate wins)."""
+    n = len(points)
+    if n == 0:
+        raise IndexError("find_convex_hull of no points")   # the reference indexes points[0] and panics
+    l = 0
+    for i in range(n):
+        if points[i][0] < points[l][0]:
+            l = i
+    hull, p = [], l
+    while p != l or not hull:
+        hull.append(tuple(points[p]))
+        q = (p + 1) % n
+        for i in range(n):
+            if orientation(points[p], points[i], points[q]) == COUNTERCLOCKWISE:
+                q = i
+        p = q
+        if len(hull) > n:   # collinear duplicates can make the reference loop forever; stop where it would start repeating
+            break
+    return hull
+
+
 class UnionFind:
     """Result of connected_components: canonical root (smallest index of the set) and set size per pixel."""
 
@@ -29,7 +77,7 @@ class UnionFind:
 
 class CatDetector:
     def __init__(self, width, height, valid_tags=(), device=0):
-        self.width, self.height, self.valid_tags = width, height, tuple(valid_tags)
+        self.width, self.height, self.valid_tags, self.device = width, height, tuple(valid_tags), device
         self._det = AprilTagDetector(width, height, max_batch=1, device=device)
         self._L = _bind(lib())
         self.buf = np.zeros((height, width), np.uint8)          # alloc_zeroed: all Black (lib.rs:166-167)
@@ -38,6 +86,10 @@ class CatDetector:
 
     def close(self):
         self._det.close()
+
+    def clone(self):
+        """lib.rs:663-667: a fresh detector of the same size with no valid tags."""
+        return CatDetector(self.width, self.height, (), device=self.device)
 
     def calc_otsu(self, rgb):
         rgb = np.ascontiguousarray(rgb, np.uint8)
@@ -90,3 +142,27 @@ class CatDetector:
         check(self._L.ck_cat_connected_components(self._det._h, self.buf.ctypes.data, self.width, self.height, roots.ctypes.data,
                                                   sizes.ctypes.data), "ck_cat_connected_components")
         return UnionFind(roots, sizes)
+
+    def draw(self, path="lines.ppm"):
+        """lib.rs:615-661: classes as black / white / 0x777777 and, in green, every checked line whose end points lie in
+        one component.  The reference writes lines.png through `ril`; this writes a binary PPM (no PNG encoder here).
+        Returns the drawn lines."""
+        img = np.zeros((self.height, self.width, 3), np.uint8)
+        img[self.buf == WHITE] = 255
+        img[self.buf == OTHER] = 0x77
+        uf = self.connected_components()
+        drawn = []
+        for x1, y1, x2, y2 in self.lines.tolist():
+            if uf.find(y1 * self.width + x1) != uf.find(y2 * self.width + x2):
+                continue
+            drawn.append((x1, y1, x2, y2))
+            n = max(abs(x2 - x1), abs(y2 - y1), 1)
+            for k in range(n + 1):   # integer DDA
+                x = x1 + ((x2 - x1) * k * 2 + n) // (2 * n) if x2 >= x1 else x1 - ((x1 - x2) * k * 2 + n) // (2 * n)
+                y = y1 + ((y2 - y1) * k * 2 + n) // (2 * n) if y2 >= y1 else y1 - ((y1 - y2) * k * 2 + n) // (2 * n)
+                img[y, x] = (0, 255, 0)
+        if path:
+            with open(path, "wb") as f:
+                f.write(b"P6\n%d %d\n255\n" % (self.width, self.height))
+                f.write(img.tobytes())
+        return drawn

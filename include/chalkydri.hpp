@@ -94,6 +94,48 @@ namespace apriltags {
 
 enum class Color : uint8_t { Black = 0, White = 1, Other = 2 }; // src/utils.rs:2-6
 
+// src/utils.rs helpers (crate-private in the reference and, except grayscale, unused by its pipeline; kept under the same names).
+namespace utils {
+// utils.rs:33-46: trunc(fma(r, .33f, fma(g, .33f, b * .33f))), saturating cast
+inline uint8_t grayscale(uint8_t r, uint8_t g, uint8_t b) {
+    float v = std::fmaf((float)r, 0.33f, std::fmaf((float)g, 0.33f, (float)b * 0.33f));
+    return v >= 255.0f ? 255 : (v <= 0.0f ? 0 : (uint8_t)v);
+}
+// utils.rs:51-72: FAST ring position 1..16 -> degrees
+inline float fast_angle(uint8_t p) {
+    if (p < 1 || p > 16) throw Panic("invalid FAST point", CK_EINVAL);
+    return (float)(p - 1) * 22.5f;
+}
+enum class Orientation { Collinear, Clockwise, Counterclockwise }; // utils.rs:74-79
+using Point = std::pair<size_t, size_t>;
+// utils.rs:82-101
+inline Orientation orientation(Point p, Point q, Point r) {
+    int32_t v = ((int32_t)q.second - (int32_t)p.second) * ((int32_t)r.first - (int32_t)q.first) -
+                ((int32_t)q.first - (int32_t)p.first) * ((int32_t)r.second - (int32_t)q.second);
+    return v == 0 ? Orientation::Collinear : (v > 0 ? Orientation::Clockwise : Orientation::Counterclockwise);
+}
+// utils.rs:113-152: gift wrapping from the left-most point
+struct PresentWrapper {
+    static std::vector<Point> find_convex_hull(const std::vector<Point> &points) {
+        if (points.empty()) throw Panic("index out of bounds: find_convex_hull of no points", CK_EINVAL);
+        size_t l = 0, n = points.size();
+        for (size_t i = 0; i < n; i++)
+            if (points[i].first < points[l].first) l = i;
+        std::vector<Point> hull;
+        size_t p = l;
+        while (p != l || hull.empty()) {
+            hull.push_back(points[p]);
+            size_t q = (p + 1) % n;
+            for (size_t i = 0; i < n; i++)
+                if (orientation(points[p], points[i], points[q]) == Orientation::Counterclockwise) q = i;
+            p = q;
+            if (hull.size() > n) break; // degenerate (collinear duplicate) input: stop where the walk starts repeating
+        }
+        return hull;
+    }
+};
+} // namespace utils
+
 // Result of Detector::connected_components (lib.rs:42-113).  The device returns the forest already flattened:
 // find() is the canonical root (smallest index of the set), get_size() the size of the set.
 class UnionFind {

@@ -43,6 +43,14 @@ static int selfcheck() {
     apriltags::UnionFind uf(8);
     uf.union_(1, 2); uf.union_(2, 5);
     if (uf.find(5) != uf.find(1) || uf.get_size(uf.find(1)) != 3 || uf.find(7) != 7) { std::puts("FAIL union-find"); return 1; }
+    {   // src/utils.rs helpers
+        namespace u = apriltags::utils;
+        std::vector<u::Point> pts = {{5, 5}, {0, 0}, {10, 0}, {10, 10}, {0, 10}, {3, 7}};
+        auto hull = u::PresentWrapper::find_convex_hull(pts);
+        if (hull.size() != 4 || hull[0] != u::Point{0, 0}) { std::puts("FAIL convex hull"); return 1; }
+        if (u::grayscale(200, 200, 200) != 198 || u::grayscale(255, 255, 255) != 252 || u::fast_angle(9) != 180.0f ||
+            u::orientation({0, 0}, {4, 4}, {8, 0}) != u::Orientation::Clockwise) { std::puts("FAIL utils"); return 1; }
+    }
     {   // whacknet: one measurement = one 64-byte datagram with exactly the struct's bytes; the gyro is a little-endian f64
         int rx = ::socket(AF_INET, SOCK_DGRAM, 0);
         sockaddr_in a{};

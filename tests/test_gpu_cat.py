@@ -80,3 +80,27 @@ def test_golden_vectors(built):
         uf = det.connected_components()
         assert G.crc(uf._roots, np.uint32) == c["roots_crc32"] and G.crc(uf._sizes, np.uint32) == c["sizes_crc32"]
         det.close()
+
+
+def test_draw_and_clone(oracle, tmp_path):
+    """draw (lib.rs:615-661) keeps exactly the lines whose end points share a component; clone is a fresh detector."""
+    from chalkydri_amd.cat import CatDetector
+    w, h = 320, 240
+    rgb = _rgb(8, w, h, "tags")
+    det = CatDetector(w, h, valid_tags=(1, 2))
+    det.process_frame(rgb)
+    out = tmp_path / "lines.ppm"
+    drawn = det.draw(str(out))
+    roots, _ = oracle.cat_connected_components(oracle.cat_calc_otsu(rgb))
+    want = [tuple(l) for l in det.lines.tolist() if roots[l[1], l[0]] == roots[l[3], l[2]]]
+    assert drawn == want
+    raw = out.read_bytes()
+    head = b"P6\n%d %d\n255\n" % (w, h)
+    assert raw.startswith(head) and len(raw) == len(head) + 3 * w * h
+    px = np.frombuffer(raw[len(head):], np.uint8).reshape(h, w, 3)
+    for x1, y1, x2, y2 in drawn:
+        assert tuple(px[y1, x1]) == (0, 255, 0) and tuple(px[y2, x2]) == (0, 255, 0)
+    other = det.clone()
+    assert (other.width, other.height, other.valid_tags) == (w, h, ()) and not other.buf.any() and len(other.points) == 0
+    other.close()
+    det.close()

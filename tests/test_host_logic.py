@@ -5,6 +5,7 @@ import subprocess
 import sys
 
 import numpy as np
+import pytest
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
@@ -72,3 +73,26 @@ def test_two_rank_gloo_gather(tmp_path):
     outs = [p.communicate(timeout=180)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
     assert "ok 0" in outs[0] and "ok 1" in outs[1]
+
+
+def test_cat_utils_helpers(oracle):
+    """src/utils.rs helpers mirrored on the host: grayscale against the oracle's fmaf version over a value sweep,
+    fast_angle, orientation and the gift-wrapping hull (utils.rs:33-46,51-72,82-101,113-152)."""
+    from chalkydri_amd import cat
+    L = oracle.lib()
+    rng = np.random.default_rng(4)
+    for r, g, b in rng.integers(0, 256, (4000, 3)).tolist() + [[v, v, v] for v in range(256)]:
+        assert cat.grayscale(r, g, b) == L.ora_cat_grayscale(r, g, b), (r, g, b)
+    assert [cat.fast_angle(p) for p in (1, 5, 9, 16)] == [0.0, 90.0, 180.0, 337.5]
+    with pytest.raises(ValueError):
+        cat.fast_angle(0)
+    assert cat.orientation((0, 0), (4, 4), (8, 8)) == cat.COLLINEAR
+    assert cat.orientation((0, 0), (4, 4), (8, 0)) == cat.CLOCKWISE
+    assert cat.orientation((0, 0), (4, 4), (0, 8)) == cat.COUNTERCLOCKWISE
+    pts = [(5, 5), (0, 0), (10, 0), (10, 10), (0, 10), (3, 7), (6, 2)]
+    hull = cat.find_convex_hull(pts)
+    assert sorted(hull) == [(0, 0), (0, 10), (10, 0), (10, 10)] and hull[0] == (0, 0)
+    # walking the hull never turns clockwise-positive: every interior point is on one side of every edge
+    for i in range(len(hull)):
+        a, b = hull[i], hull[(i + 1) % len(hull)]
+        assert all(cat.orientation(a, p, b) != cat.COUNTERCLOCKWISE for p in pts)
