@@ -211,6 +211,7 @@ static int fetch_detections(ck_handle *h, int n, ck_detection_t *dets, int cap, 
 
 extern "C" int ck_detect_uploaded(ck_handle_t *h, int32_t n, ck_detection_t *dets, int32_t cap, int32_t *counts, uint32_t *status) {
     if (!h || !dets || !counts || cap < 1 || n < 0 || n > h->n_staged) return CK_EINVAL;
+    if (n == 0) return CK_OK;
     CK_HIP(hipSetDevice(h->device));
     CK_HIP(hipEventRecord(h->ev[0], h->stream));
     ck_split sp;
@@ -222,7 +223,8 @@ extern "C" int ck_detect_uploaded(ck_handle_t *h, int32_t n, ck_detection_t *det
 
 extern "C" int ck_detect_batch(ck_handle_t *h, const ck_image_u8_t *imgs, int32_t n, ck_detection_t *dets, int32_t cap,
                                int32_t *counts, uint32_t *status) {
-    if (!h || !dets || !counts || cap < 1) return CK_EINVAL;
+    if (!h || !dets || !counts || cap < 1 || n < 0) return CK_EINVAL;
+    if (n == 0) return CK_OK;
     CK_HIP(hipSetDevice(h->device));
     CK_HIP(hipEventRecord(h->ev[0], h->stream));
     int rc = ck_upload_frames(h, imgs, n);
@@ -236,7 +238,8 @@ extern "C" int ck_detect_batch(ck_handle_t *h, const ck_image_u8_t *imgs, int32_
 
 extern "C" int ck_detect_batch_device(ck_handle_t *h, const uint8_t *d_frames, int32_t n, int32_t stride, int64_t frame_pitch,
                                       ck_detection_t *dets, int32_t cap, int32_t *counts, uint32_t *status) {
-    if (!h || !dets || !counts || cap < 1) return CK_EINVAL;
+    if (!h || !dets || !counts || cap < 1 || n < 0) return CK_EINVAL;
+    if (n == 0) return CK_OK;
     CK_HIP(hipSetDevice(h->device));
     CK_HIP(hipEventRecord(h->ev[0], h->stream));
     const uint8_t *use; int us; size_t up;
