@@ -58,12 +58,22 @@ static_assert(TH * NSEG * 2 == KNT, "k_tile thread mapping: colour x row x segme
 static_assert(TH * TW <= 65536, "node indices are u16");
 static_assert(TW == 128, "label pass splits a node index with >> 7 / & 127");
 
+#ifdef CK_TILE_PROFILE
+#define TCNT_ARG , uint32_t &tcnt
+#define TCNT_PASS , tcnt
+#define TCNT_INC ++tcnt
+#else
+#define TCNT_ARG
+#define TCNT_PASS
+#define TCNT_INC
+#endif
 // find with path halving.  Plain stores race with the min-hooks of lds_union, but every value ever written to p[a]
 // is an ancestor of a, so the forest stays valid (a lost hook is re-issued by its own union).
 // two halving finds walked in lockstep: both chains have a read in flight at every step (the kernel is bound by LDS
 // round-trip latency, not LDS bandwidth)
-__device__ __forceinline__ void lds_find2(volatile uint16_t *p, uint32_t &a, uint32_t &b) {
+__device__ __forceinline__ void lds_find2(volatile uint16_t *p, uint32_t &a, uint32_t &b TCNT_ARG) {
     for (;;) {
+        TCNT_INC;
         uint32_t na = p[a], nb = p[b];
         bool da = (na == a), db = (nb == b);
         if (da && db) return;
@@ -87,9 +97,9 @@ __device__ __forceinline__ uint32_t lds_min16(uint16_t *p, uint32_t idx, uint32_
     }
 }
 // root = smaller index
-__device__ __forceinline__ void lds_union(uint16_t *p, uint32_t a, uint32_t b) {
+__device__ __forceinline__ void lds_union(uint16_t *p, uint32_t a, uint32_t b TCNT_ARG) {
     for (;;) {
-        lds_find2(p, a, b);
+        lds_find2(p, a, b TCNT_PASS);
         if (a == b) return;
         if (a < b) { uint32_t t = a; a = b; b = t; }
         uint32_t old = lds_min16(p, a, b);
@@ -354,24 +364,41 @@ __global__ __launch_bounds__(KNT) void k_tile(const uint8_t *__restrict__ frames
     __syncthreads();
     if (stop_after == 4 || stop_after == 5) return; // diagnostics (CK_TILE_STOP_AFTER)
     // ---- P5b: the remaining links (a run touching a second, third ... earlier run) go through the atomic union
-    if (hleft) lds_union(parent, base, left_node);
+#ifdef CK_TILE_PROFILE
+    uint32_t tcnt = 0, tun = 0;
+#define TUN ++tun
+#else
+#define TUN
+#endif
+    if (hleft) { TUN; lds_union(parent, base, left_node TCNT_PASS); }
     while (Ev) {
+        TUN;
         int i = mctz(Ev);
         Ev &= Ev - 1;
-        lds_union(parent, base + run_start(S, i), base - TW + run_start(Su, i));
+        lds_union(parent, base + run_start(S, i), base - TW + run_start(Su, i) TCNT_PASS);
     }
     while (DL) {
         int i = mctz(DL);
         DL &= DL - 1;
-        lds_union(parent, base + run_start(S, i), up_left_node(i));
+        TUN;
+        lds_union(parent, base + run_start(S, i), up_left_node(i) TCNT_PASS);
     }
     while (DR) {
         int i = mctz(DR);
         DR &= DR - 1;
-        lds_union(parent, base + run_start(S, i), up_right_node(i));
+        TUN;
+        lds_union(parent, base + run_start(S, i), up_right_node(i) TCNT_PASS);
     }
     __syncthreads();
     TPROF(3);
+#ifdef CK_TILE_PROFILE
+    {   // [8] unions, [9] find2 iterations summed over lanes, [10] per-wave maximum of a lane's find2 iterations
+        uint32_t su = tun, sc = tcnt, mx = tcnt;
+        for (int o = 32; o; o >>= 1) { su += __shfl_xor(su, o); sc += __shfl_xor(sc, o); mx = max(mx, (uint32_t)__shfl_xor(mx, o)); }
+        if ((tid & 63) == 0) { atomicAdd(&g_tile_prof[8], su); atomicAdd(&g_tile_prof[9], sc); atomicAdd(&g_tile_prof[10], mx); }
+    }
+    uint32_t wruns = 0, whops = 0, wit = 0;
+#endif
 
     __syncthreads(); // halving stores must land before the owners publish final roots
     if (stop_after == 6) return; // diagnostics (CK_TILE_STOP_AFTER)
@@ -405,12 +432,18 @@ __global__ __launch_bounds__(KNT) void k_tile(const uint8_t *__restrict__ frames
             const volatile uint16_t *vp = parent;
             for (int it = 0; it < 8192; it++) {
                 uint32_t n0 = vp[root[0]], n1 = vp[root[1]], n2 = vp[root[2]], n3 = vp[root[3]];
+#ifdef CK_TILE_PROFILE
+                wit++; whops += (n0 != root[0]) + (n1 != root[1]) + (n2 != root[2]) + (n3 != root[3]);
+#endif
                 if (n0 == root[0] && n1 == root[1] && n2 == root[2] && n3 == root[3]) break;
                 root[0] = n0; root[1] = n1; root[2] = n2; root[3] = n3;
             }
 #pragma unroll
             for (int q = 0; q < 4; q++)
                 if (live[q]) {
+#ifdef CK_TILE_PROFILE
+                    wruns++;
+#endif
                     parent[node[q]] = (uint16_t)root[q];
                     if (root[q] == acc_root) { acc_add += add[q]; acc_ring = acc_ring || ring[q]; }
                     else {
@@ -423,6 +456,13 @@ __global__ __launch_bounds__(KNT) void k_tile(const uint8_t *__restrict__ frames
     }
     __syncthreads();
     TPROF(4);
+#ifdef CK_TILE_PROFILE
+    {   // [11] runs, [12] hops summed over lanes, [13] per-wave maximum of a lane's walk iterations
+        uint32_t sr = wruns, sh = whops, mx = wit;
+        for (int o = 32; o; o >>= 1) { sr += __shfl_xor(sr, o); sh += __shfl_xor(sh, o); mx = max(mx, (uint32_t)__shfl_xor(mx, o)); }
+        if ((tid & 63) == 0) { atomicAdd(&g_tile_prof[11], sr); atomicAdd(&g_tile_prof[12], sh); atomicAdd(&g_tile_prof[13], mx); }
+    }
+#endif
 
     if (stop_after == 7) return; // diagnostics (CK_TILE_STOP_AFTER)
     // ---- P7: write label words (16 pixels per item) -------------------------------------------------------------------
@@ -453,21 +493,29 @@ __global__ __launch_bounds__(KNT) void k_tile(const uint8_t *__restrict__ frames
             const uint32_t carryB = sbase + (lb ? (uint32_t)(SEGW - 1 - mclz(lb)) : 0u);
             const uint32_t cbase = sbase + (uint32_t)sh;
             const uint32_t gbase = (uint32_t)ty0 * (uint32_t)w + (uint32_t)tx0;
+            // Straight-line code, no exec-mask regions: a pixel's run starts at the nearest start bit of EITHER colour at or
+            // below it (a start of the other colour cannot lie inside a run), or before the chunk (then the run has the colour
+            // of pixel 0 and the carried node of that colour).  Uncoloured pixels look up a harmless in-range node.
+            const uint32_t any16 = w16 | b16, st16 = sw16 | sb16;
+            uint32_t cur = (w16 & 1u) ? carryW : carryB;
+            uint32_t nodev[16], rootv[16], sizev[16];
 #pragma unroll
             for (int k = 0; k < 16; k++) {
-                const bool isw = (w16 >> k) & 1u, isb = (b16 >> k) & 1u;
-                const uint32_t m = (isw ? sw16 : sb16) & ((2u << k) - 1u);
-                const uint32_t node = m ? cbase + (uint32_t)(31 - __builtin_clz(m)) : (isw ? carryW : carryB);
-                uint32_t word = CK_LBL_INVALID;
-                if (isw || isb) {
-                    const uint32_t root = parent[node];
-                    const uint32_t sw = size8[root];
-                    const uint32_t gidx = gbase + (root >> 7) * (uint32_t)w + (root & (TW - 1));
-                    word = gidx | ((sw & 0x80u) ? CK_LBL_BORDER : ((int)(sw & 0x7Fu) < min_comp ? CK_LBL_SMALL : 0u));
-                    // a ring-touching root: a run start whose label word points at itself
-                    if ((sw & 0x80u) && root == cbase + (uint32_t)k) roots_mask |= 1u << k;
-                }
-                outw[k] = word;
+                cur = ((st16 >> k) & 1u) ? cbase + (uint32_t)k : cur;
+                nodev[k] = cur;
+            }
+#pragma unroll
+            for (int k = 0; k < 16; k++) rootv[k] = parent[nodev[k]];
+#pragma unroll
+            for (int k = 0; k < 16; k++) sizev[k] = size8[rootv[k]];
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                const uint32_t root = rootv[k], sw = sizev[k];
+                const uint32_t gidx = gbase + (root >> 7) * (uint32_t)w + (root & (TW - 1));
+                const uint32_t cls = (sw & 0x80u) ? CK_LBL_BORDER : ((int)(sw & 0x7Fu) < min_comp ? CK_LBL_SMALL : 0u);
+                outw[k] = ((any16 >> k) & 1u) ? (gidx | cls) : CK_LBL_INVALID;
+                // a ring-touching root: a run start whose label word points at itself
+                roots_mask |= ((sw & 0x80u) && root == cbase + (uint32_t)k) ? (1u << k) : 0u; // roots are run starts: never an uncoloured pixel
             }
             uint32_t *dst = labels + fbase + (size_t)gy * w + gx;
 #pragma unroll

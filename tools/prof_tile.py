@@ -38,4 +38,7 @@ for noise in (3, 1):
     tot = sum(buf[k] for k in range(7)) or 1
     tiles = 130 * n * 5
     print("noise", noise, "ms/pass", round(ms, 3), "cycles/tile", round(tot / tiles), {names[k]: round(100 * buf[k] / tot, 1) for k in range(7)})
+    wv = 130 * n * 5 * 4   # waves
+    print("   P5b: unions/tile", round(buf[8] / tiles), "find2 iterations/union", round(buf[9] / max(1, buf[8]), 2), "max lane iterations per wave", round(buf[10] / wv, 1))
+    print("   P6 : runs/tile", round(buf[11] / tiles), "hops/run", round(buf[12] / max(1, buf[11]), 2), "max lane walk iterations per wave", round(buf[13] / wv, 1))
     det.close()
