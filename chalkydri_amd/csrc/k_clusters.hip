@@ -73,18 +73,42 @@ __global__ __launch_bounds__(NT) void k_emit(EmitArgs a) {
     ck_run *runs = ws.d_runs + (size_t)frame * ws.run_cap;
 
     for (int i = tid; i < LHT; i += NT) { sKey[i] = 0ull; sCnt[i] = 0; }
-    for (int i = tid; i < LH * LW; i += NT) {
-        int ly = i / LW, lx = i - ly * LW;
-        int gy = y0 + ly, gx = x0 - 1 + lx;
-        uint8_t t = 127;
-        uint32_t r = SKIP;
-        if (gy < h && gx >= 0 && gx < w) {
-            uint32_t p = (uint32_t)gy * (uint32_t)w + (uint32_t)gx;
-            t = T[p];
-            if (t != 127) r = resolve(L, C, p, a.min_comp);
+    {   // staging: every thread's pixels go through the (up to three) dependent loads side by side, so a thread waits for
+        // three memory round trips, not three per pixel
+        constexpr int SPT = (LH * LW + NT - 1) / NT;
+        uint32_t lab[SPT], hop[SPT], csz[SPT];
+        uint8_t tv[SPT];
+#pragma unroll
+        for (int q = 0; q < SPT; q++) {
+            const int i = tid + q * NT;
+            const int ly = i / LW, lx = i - ly * LW;
+            const int gy = y0 + ly, gx = x0 - 1 + lx;
+            tv[q] = 127; lab[q] = CK_LBL_INVALID;
+            if (i < LH * LW && gy < h && gx >= 0 && gx < w) {
+                const uint32_t p = (uint32_t)gy * (uint32_t)w + (uint32_t)gx;
+                tv[q] = T[p]; lab[q] = L[p];
+            }
         }
-        sT[ly][lx] = t;
-        sR[ly][lx] = r;
+#pragma unroll
+        for (int q = 0; q < SPT; q++) { // ring-touching components: the tile-local root's word holds the frame-level root
+            const bool two = tv[q] != 127 && !(lab[q] & CK_LBL_SMALL) && (lab[q] & CK_LBL_BORDER);
+            hop[q] = two ? L[lab[q] & CK_LBL_IDX_MASK] : CK_LBL_INVALID;
+        }
+#pragma unroll
+        for (int q = 0; q < SPT; q++) csz[q] = (hop[q] != CK_LBL_INVALID) ? C[hop[q] & CK_LBL_IDX_MASK] : 0u;
+#pragma unroll
+        for (int q = 0; q < SPT; q++) {
+            const int i = tid + q * NT;
+            if (i >= LH * LW) continue;
+            const int ly = i / LW, lx = i - ly * LW;
+            uint32_t r = SKIP;
+            if (tv[q] != 127 && !(lab[q] & CK_LBL_SMALL)) { // SMALL covers CK_LBL_INVALID too
+                r = lab[q] & CK_LBL_IDX_MASK;
+                if (lab[q] & CK_LBL_BORDER) r = ((int)csz[q] < a.min_comp) ? SKIP : (hop[q] & CK_LBL_IDX_MASK);
+            }
+            sT[ly][lx] = tv[q];
+            sR[ly][lx] = r;
+        }
     }
     __syncthreads();
     if (a.stop_after == 0) return;
