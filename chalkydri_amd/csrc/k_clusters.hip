@@ -183,21 +183,28 @@ __global__ __launch_bounds__(NT) void k_emit(EmitArgs a) {
         }
         const uint32_t excl = before + incl - (c0 + c1);
         sTBase[2 * tid] = excl; sTBase[2 * tid + 1] = excl + c0;
+        {   // both first probes of the frame table in flight together; only a probe that met another key walks on
+            const uint32_t hm = (uint32_t)(ws.ht_size - 1);
+            const uint32_t g0 = key_hash(k0) & hm, g1 = key_hash(k1) & hm;
+            const unsigned long long p0 = k0 ? atomicCAS(&gkeys[g0], 0ull, k0) : 0ull;
+            const unsigned long long p1 = k1 ? atomicCAS(&gkeys[g1], 0ull, k1) : 0ull;
 #pragma unroll
-        for (int q = 0; q < 2; q++) {
-            const unsigned long long key = q ? k1 : k0;
-            const int s = 2 * tid + q;
-            if (key == 0ull) continue;
-            uint32_t g = key_hash(key) & (uint32_t)(ws.ht_size - 1);
-            uint32_t found = SKIP;
-            for (int probe = 0; probe < ws.ht_size; probe++) {
-                unsigned long long prev = atomicCAS(&gkeys[g], 0ull, key);
-                if (prev == 0ull || prev == key) { found = g; break; }
-                g = (g + 1) & (uint32_t)(ws.ht_size - 1);
+            for (int q = 0; q < 2; q++) {
+                const unsigned long long key = q ? k1 : k0, pv = q ? p1 : p0;
+                if (key == 0ull) continue;
+                uint32_t g = q ? g1 : g0, found = SKIP;
+                if (pv == 0ull || pv == key) found = g;
+                else {
+                    for (int probe = 1; probe < ws.ht_size; probe++) {
+                        g = (g + 1) & hm;
+                        unsigned long long prev = atomicCAS(&gkeys[g], 0ull, key);
+                        if (prev == 0ull || prev == key) { found = g; break; }
+                    }
+                }
+                if (found == SKIP) atomicOr(&counters[CK_CNT_STATUS], (uint32_t)CK_FRAME_CLUSTERS_OVERFLOW);
+                sSlot[2 * tid + q] = found;
+                if (q) found1 = found; else found0 = found;
             }
-            if (found == SKIP) atomicOr(&counters[CK_CNT_STATUS], (uint32_t)CK_FRAME_CLUSTERS_OVERFLOW);
-            sSlot[s] = found;
-            if (q) found1 = found; else found0 = found;
         }
         if (found0 != SKIP) atomicAdd(&gcount[found0], c0); // result unused: nothing waits for these
         if (found1 != SKIP) atomicAdd(&gcount[found1], c1);
