@@ -169,7 +169,7 @@ def main():
             "dtype": "u8 (threshold/segment/clusters: integer; quad fit/decode/SQPnP: f64)", "data": "synthetic",
             "config": {"workload": f"{w}x{h} mono8 batch={n}/GPU, tag36h11, {args.tags} field tags/frame (3-D scenes), background ramp+-24 "
                                    f"noise+-{args.noise}, quad_decimate={args.decimate}, detect+pose, one stream per GPU",
-                       "frames_with_pose": round(valid_frac, 4), "post_segment_streams": int(os.environ.get("CK_STREAMS", "2")), "gather": "RCCL all_gather of 64-byte records" if world > 1 else "none (1 GPU)"},
+                       "frames_with_pose": round(valid_frac, 4), "post_segment_streams": int(os.environ.get("CK_STREAMS", "1")), "gather": "RCCL all_gather of 64-byte records" if world > 1 else "none (1 GPU)"},
             "roofline": {"bound": "hbm", "kernel": "threshold+segment (k_tile + k_merge + k_roots)", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "measured_copy_GBps": round(copy_gbps, 1),
                          "algorithmic_bytes_per_launch": ALG_BYTES_PER_PX * w * h * n, "avg_launch_ms": round(ms_thr, 4)},

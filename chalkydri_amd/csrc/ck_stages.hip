@@ -88,13 +88,15 @@ void ck_stage_free(ck_handle *h) {
 }
 
 // the whole detector on n frames resident on the device
-// The stages after segmentation are irregular (persistent grids with tails, one-workgroup-per-frame kernels, latency
-// chains): two half-batches on two streams fill each other's gaps.  Threshold + segmentation always run for the whole batch
-// on the handle's stream (that is the stage the HBM roofline is quoted on); then the second half of the frames continues
+// The stages after segmentation can run as consecutive pieces of the batch on two streams (CK_STREAMS=2), each piece filling
+// the other's gaps (one-workgroup-per-frame kernels, latency chains).  Threshold + segmentation always run for the whole
+// batch on the handle's stream (that is the stage the HBM roofline is quoted on); then the later pieces continue
 // on stream2 through a VIEW of the handle — a copy whose per-frame pointers are advanced by n0 frames and whose scratch
 // regions are the second copies allocated for it.  Frames are independent, so the results do not depend on the split.
 static int streams_wanted() {
-    static const int v = getenv("CK_STREAMS") ? atoi(getenv("CK_STREAMS")) : 2;
+    // default 1: since the fit kernels dequeue their clusters in chunks (no long tail left to fill) two dense kernels side by
+    // side only get in each other's way (21.8 vs 22.4 ms per 1280x800x256 batch); CK_STREAMS=2 keeps the split available
+    static const int v = getenv("CK_STREAMS") ? atoi(getenv("CK_STREAMS")) : 1;
     return v;
 }
 static ck_handle make_view(const ck_handle *h, int f0, bool second_stream = true) {

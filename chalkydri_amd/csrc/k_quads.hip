@@ -577,18 +577,23 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(WPS, 8))) v
     uint16_t *sW = reinterpret_cast<uint16_t *>(sKeys) + 2 * CAP; // bytes [4*CAP, 6*CAP)
     uint16_t *sMaxIdx = reinterpret_cast<uint16_t *>(sKeys) + 3 * CAP; // bytes [6*CAP, 8*CAP): free once the keys are packed
 
-    // static striding over the class work list: no dequeue atomics (520 k clusters per batch through one counter cost more
-    // than any phase of the fit); clusters of one class are similar enough for the load to even out over ~100 per workgroup
+    // chunked dequeue from the class work list: DQ consecutive clusters per atomic.  One atomic per cluster is too much for
+    // the small class (520 k clusters per batch through one counter cost more than any phase of the fit), static striding
+    // leaves the slowest workgroup ~25 % behind the average (the sum of ~100 clusters' work still varies that much); a
+    // chunk keeps the counter traffic at a few thousand adds per launch and the tail at one chunk.
     const uint32_t n_work = *a.list_count;
-    // the big classes hold few, very unequal clusters: they dequeue (one atomic per cluster is nothing there)
-    constexpr bool DYN = CAP > 2048;
-    for (uint32_t work = blockIdx.x;; work += gridDim.x) {
+    constexpr uint32_t DQ = CAP <= 512 ? 16u : (CAP <= 2048 ? 4u : 1u);
+    uint32_t chunk_base = 0, chunk_left = 0;
+    for (;;) {
         __syncthreads();
-        if constexpr (DYN) {
-            if (tid == 0) sWork = atomicAdd(a.head, 1u);
+        if (chunk_left == 0) {
+            if (tid == 0) sWork = atomicAdd(a.head, DQ);
             __syncthreads();
-            work = sWork;
+            chunk_base = sWork;
+            chunk_left = DQ;
         }
+        const uint32_t work = chunk_base + (DQ - chunk_left);
+        chunk_left--;
         if (work >= n_work) break;
         const uint32_t item = a.list[work];
         const int frame = (int)(item >> 20), ci = (int)(item & 0xFFFFFu);

@@ -1,5 +1,6 @@
-"""The post-segmentation stages run as consecutive pieces of the batch on two streams (ck_stages.hip: run_pipeline).  Frames
-are independent, so every split — none, the default two halves, three uneven pieces — must give the same bytes."""
+"""The post-segmentation stages can run as consecutive pieces of the batch on two streams (ck_stages.hip: run_pipeline,
+CK_STREAMS=2).  Frames are independent, so every split — none (the default), two halves, three uneven pieces — must give
+the same bytes."""
 import hashlib
 import os
 import subprocess
@@ -50,5 +51,6 @@ def _run(env_extra):
 def test_results_do_not_depend_on_the_split(built):
     single, nvalid = _run({"CK_STREAMS": "1"})
     assert nvalid == 6                       # 7 frames, one without gyro
-    assert _run({}) [0] == single            # default: two halves on two streams
-    assert _run({"CK_PARTS": "3"})[0] == single
+    assert _run({})[0] == single                                        # default
+    assert _run({"CK_STREAMS": "2"})[0] == single                       # two halves on two streams
+    assert _run({"CK_STREAMS": "2", "CK_PARTS": "3"})[0] == single      # three uneven pieces
