@@ -556,9 +556,10 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(WPS, 8))) v
     __shared__ int sSelIdx[MAXSEL];
     // moment prefix sums at the selected maxima: they are born after the maxima list has been consumed, so the
     // LDS-resident classes keep them in its bytes
-    __shared__ long long sSelStore[MLDS ? 1 : 2 * MAXSEL * 6];
+    // ... and the large class keeps them in the error array, which is dead once the chunk loop has produced the maxima
+    static_assert(MLDS || sizeof(double) * SL >= sizeof(long long) * 2 * MAXSEL * 6, "selected-maxima sums must fit in sErr");
     static_assert(!MLDS || sizeof(double) * MAXM >= sizeof(long long) * 2 * MAXSEL * 6, "selected-maxima sums must fit in sMaxVal");
-    long long (*sSelI)[6] = reinterpret_cast<long long (*)[6]>(MLDS ? reinterpret_cast<long long *>(sMaxVal) : sSelStore);
+    long long (*sSelI)[6] = reinterpret_cast<long long (*)[6]>(MLDS ? reinterpret_cast<long long *>(sMaxVal) : reinterpret_cast<long long *>(sErr));
     long long (*sSelE)[6] = sSelI + MAXSEL;
     __shared__ double sRed[NTH / 64 + 1];
     __shared__ int sRedI[NTH / 64 + 1];
