@@ -37,8 +37,8 @@ struct ck_dev_family {
 };
 
 // One boundary point while it waits to be grouped (k_clusters.hip)
-// size classes of the quad fit (k_quads.hip): <= 512, <= 2048, <= 4096, <= 16384 points per cluster
-constexpr int CK_FIT_CLASSES = 4;
+// size classes of the quad fit (k_quads.hip): <= 512, <= 2048, <= 4096, <= 8192, <= 16384 points per cluster
+constexpr int CK_FIT_CLASSES = 5;
 constexpr int CK_LSCRATCH_PER_WG = 16384, CK_LSCRATCH_WGS = 1024; // large class: points per cluster, workgroups in its grid (at most)
 
 // A boundary point inside the pipeline, packed into 32 bits: [x:13][y:13][direction:2][sign:1] at bits 28..16, 15..3, 2..1, 0.

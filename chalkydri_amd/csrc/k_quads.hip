@@ -663,7 +663,7 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(WPS, 8))) v
             const int epl = n2 / NTH;
             __syncthreads(); // raw points staged by other threads
             bool sorted = false;
-            if constexpr (CAP <= 4096)
+            if constexpr (MLDS) // keys fit in registers (CAP / NTH <= 16)
                 dot = keys_bucket_sort<NTH, EPLS>(sKeys, reinterpret_cast<uint32_t *>(sPraw), sScratch, sz0, xmin, xmax, ymin, ymax,
                                                   a.normal_ok, a.reversed_ok, a.stop_after != 11, &sorted);
             else
@@ -1270,7 +1270,7 @@ __global__ __launch_bounds__(1024) void k_classify(ck_stage_ws ws, int n, uint32
     const uint32_t *counters = ws.d_counters + (size_t)frame * CK_CNT_STRIDE;
     const uint32_t nc = counters[CK_CNT_CLUSTERS];
     const ck_cluster_t *cls = ws.d_clusters + (size_t)frame * ws.cluster_cap;
-    auto class_of = [](uint32_t c) { return c <= 512 ? 0 : (c <= 2048 ? 1 : (c <= 4096 ? 2 : 3)); };
+    auto class_of = [](uint32_t c) { return c <= 512 ? 0 : (c <= 2048 ? 1 : (c <= 4096 ? 2 : (c <= 8192 ? 3 : 4))); };
     if (tid < CK_FIT_CLASSES) sCnt[tid] = 0;
     __syncthreads();
     for (uint32_t i = tid; i < nc; i += 1024) atomicAdd(&sCnt[class_of(cls[i].count)], 1u);
@@ -1348,6 +1348,8 @@ int ck_launch_fit_quads(ck_handle *h, const uint8_t *qframes, int qstride, size_
     a.list = lists + 2 * (size_t)list_cap; a.list_count = list_counts + 2; a.head = heads + 2;
     hipLaunchKernelGGL((k_fit<256, 4096, 512, true, 2>), dim3((unsigned)(cus * 2)), dim3(256), 0, h->stream, a);
     a.list = lists + 3 * (size_t)list_cap; a.list_count = list_counts + 3; a.head = heads + 3;
+    hipLaunchKernelGGL((k_fit<512, 8192, 512, true, 2>), dim3((unsigned)cus), dim3(512), 0, h->stream, a);
+    a.list = lists + 4 * (size_t)list_cap; a.list_count = list_counts + 4; a.head = heads + 4;
     hipLaunchKernelGGL((k_fit<512, 16384, 512, false, 2>), dim3((unsigned)cus), dim3(512), 0, h->stream, a);
     hipLaunchKernelGGL(k_clamp_counts, dim3(1), dim3(64), 0, h->stream, list_counts, list_cap, ws, n);
     CK_HIP(hipGetLastError());
