@@ -583,12 +583,19 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(WPS, 8))) v
     // leaves the slowest workgroup ~25 % behind the average (the sum of ~100 clusters' work still varies that much); a
     // chunk keeps the counter traffic at a few thousand adds per launch and the tail at one chunk.
     const uint32_t n_work = *a.list_count;
-    constexpr uint32_t DQ = CAP <= 512 ? 16u : (CAP <= 2048 ? 4u : 1u);
-    uint32_t chunk_base = 0, chunk_left = 0;
+    // A short list (one frame per call) is handed out one cluster at a time so that it still spreads over the whole grid.
+    constexpr uint32_t DQMAX = CAP <= 512 ? 16u : (CAP <= 2048 ? 4u : 1u);
+    const uint32_t per_wg4 = n_work / (gridDim.x * 4u);
+    const uint32_t DQ = per_wg4 < 1u ? 1u : (per_wg4 > DQMAX ? DQMAX : per_wg4);
+    // The first chunk of every workgroup is its own (no atomic: a launch with little or no work — one frame per call, an empty
+    // class — must not queue thousands of adds on one address); the counter hands out what lies beyond those.
+    const uint32_t static_total = gridDim.x * DQ;
+    uint32_t chunk_base = blockIdx.x * DQ, chunk_left = DQ;
     for (;;) {
         __syncthreads();
         if (chunk_left == 0) {
-            if (tid == 0) sWork = atomicAdd(a.head, DQ);
+            if (static_total >= n_work) break;
+            if (tid == 0) sWork = static_total + atomicAdd(a.head, DQ);
             __syncthreads();
             chunk_base = sWork;
             chunk_left = DQ;
