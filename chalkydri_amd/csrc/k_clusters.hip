@@ -37,18 +37,6 @@ struct EmitArgs {
     ck_stage_ws ws;
 };
 
-// resolved component id of pixel i, or SKIP when it has no component / the component is too small
-__device__ __forceinline__ uint32_t resolve(const uint32_t *L, const uint32_t *C, uint32_t i, int min_comp) {
-    uint32_t l = L[i];
-    if (l & CK_LBL_SMALL) return SKIP; // covers CK_LBL_INVALID too
-    uint32_t rep = l & CK_LBL_IDX_MASK;
-    if (l & CK_LBL_BORDER) {
-        rep = L[rep] & CK_LBL_IDX_MASK;
-        if ((int)C[rep] < min_comp) return SKIP;
-    }
-    return rep;
-}
-
 __global__ __launch_bounds__(NT) void k_emit(EmitArgs a) {
     __shared__ uint8_t sT[LH][LW + 2];
     __shared__ uint32_t sR[LH][LW];
