@@ -254,7 +254,9 @@ struct SolveArgs {
     int n;
     int max_points; // capacity of the per-problem world-point scratch
     double *world;  // [n][max_points][3]
+    int stop_after; // diagnostics (CK_SQ_STOP_AFTER): 1 after Omega, 2 after the eigen-decomposition, 3 after the refinements
 };
+static int sq_stop_after() { static const int v = getenv("CK_SQ_STOP_AFTER") ? atoi(getenv("CK_SQ_STOP_AFTER")) : 99; return v; }
 
 constexpr int SQ_NT = 128; // two waves: six candidate groups of 16 lanes in the refinement, 128-wide loops elsewhere
 __global__ __launch_bounds__(SQ_NT) void k_sqpnp(SolveArgs a) {
@@ -329,6 +331,7 @@ __global__ __launch_bounds__(SQ_NT) void k_sqpnp(SolveArgs a) {
         sOmega[e] = om; sA[e] = om; sV[e] = (i == j) ? 1.0 : 0.0;
     }
     __syncthreads();
+    if (a.stop_after == 1) return;
     // symmetric eigen-decomposition of Omega: cyclic Jacobi, 9 lanes update one element of the rotated rows/columns
     for (int sweep = 0; sweep < 64; sweep++) {
         double off = 0;
@@ -361,6 +364,7 @@ __global__ __launch_bounds__(SQ_NT) void k_sqpnp(SolveArgs a) {
         sRot[0] = cos(pr.gyro); sRot[1] = sin(pr.gyro);
     }
     __syncthreads();
+    if (a.stop_after == 2) return;
     double Rrc[9];
     quat_to_mat(pr.robot_to_cam.q, Rrc);
     const double fwd[3] = {Rrc[0], Rrc[3], Rrc[6]}; // column 0 (lib.rs:313-318)
@@ -385,6 +389,7 @@ __global__ __launch_bounds__(SQ_NT) void k_sqpnp(SolveArgs a) {
         }
     }
     __syncthreads();
+    if (a.stop_after == 3) return;
     if (lane >= 64) return; // the first wave picks the winner: every lane replays the (cheap) selection, the cheirality test
                             // over the points is spread over the lanes
     int order[6] = {0, 1, 2, 3, 4, 5};
@@ -595,7 +600,7 @@ extern "C" int ck_sqpnp_solve_batch(ck_handle_t *h, const ck_sqpnp_params_t *par
     if (n_tags_total) CK_HIP(hipMemcpyAsync(dt.p, tags, sizeof(ck_iso3_t) * (size_t)n_tags_total, hipMemcpyHostToDevice, h->stream));
     if (n_bearings_total) CK_HIP(hipMemcpyAsync(db.p, bearings, sizeof(double) * 3 * (size_t)n_bearings_total, hipMemcpyHostToDevice, h->stream));
     SolveArgs a;
-    a.prm = *params; a.problems = dp.p; a.tags = dt.p; a.bearings = db.p; a.out = dr.p; a.n = n; a.max_points = max_pts; a.world = dw.p;
+    a.prm = *params; a.problems = dp.p; a.tags = dt.p; a.bearings = db.p; a.out = dr.p; a.n = n; a.max_points = max_pts; a.world = dw.p; a.stop_after = sq_stop_after();
     hipLaunchKernelGGL(k_sqpnp, dim3((unsigned)n), dim3(SQ_NT), 0, h->stream, a);
     CK_HIP(hipGetLastError());
     CK_HIP(hipMemcpyAsync(out, dr.p, sizeof(ck_sqpnp_result_t) * (size_t)n, hipMemcpyDeviceToHost, h->stream));
@@ -659,7 +664,7 @@ int ck_run_pose(ck_handle *h, int n, const ck_process_params_t *pp, const double
     hipLaunchKernelGGL(k_glue, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, h->stream, g);
     SolveArgs a;
     a.prm = pp->sqpnp; a.problems = ws.d_problems; a.tags = ws.d_pose_tags; a.bearings = ws.d_bearings; a.out = ws.d_results; a.n = n;
-    a.max_points = ws.det_cap * 4; a.world = ws.d_world;
+    a.max_points = ws.det_cap * 4; a.world = ws.d_world; a.stop_after = sq_stop_after();
     hipLaunchKernelGGL(k_sqpnp, dim3((unsigned)n), dim3(SQ_NT), 0, h->stream, a);
     hipLaunchKernelGGL(k_measure, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, h->stream, ws, ws.d_results, pp->camera_id, ws.d_meas, ws.d_valid, n);
     CK_HIP(hipGetLastError());
