@@ -106,7 +106,7 @@ struct ck_handle {
     ck_config_t cfg;
     int device;
     hipStream_t stream;
-    hipStream_t stream2;  // the second half of a batch runs its irregular stages here (ck_stages.hip: split_batch)
+    hipStream_t stream2;  // with CK_STREAMS=2 the later pieces of a batch run their irregular stages here (ck_stages.hip: run_pipeline)
     hipEvent_t ev[16];
     hipEvent_t ev_fork, ev_join;
     int w, h;            // full-resolution frame

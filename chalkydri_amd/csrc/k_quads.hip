@@ -15,9 +15,9 @@
 //   5. the max_nmaxima strongest maxima (rank-based selection), moment sums at them from a 32/128-point table, one line
 //      fit per ordered pair, every 4-subset evaluated in parallel (argmin with the oracle's lexicographic tie-break);
 //   6. lines, corners, area/angle/winding checks on four lanes, wave-parallel edge refinement.
-// Clusters are dispatched through per-size-class work lists built by k_classify (<= 512, <= 2048, <= 4096, <= 16384
-// points); each variant is a persistent grid: static striding for the two small classes, a dequeue counter for the two
-// large ones.  The phases can be cut short for measurements with CK_FIT_STOP_AFTER (tools/ablate_fit.sh).
+// Clusters are dispatched through per-size-class work lists built by k_classify (<= 512, <= 2048, <= 4096, <= 8192,
+// <= 16384 points); each variant is a persistent grid whose workgroups take a first chunk of their list by index and the
+// rest from a dequeue counter.  The phases can be cut short for measurements with CK_FIT_STOP_AFTER (tools/ablate_fit.sh).
 #include <stdlib.h>
 
 #include "ck_internal.h"
@@ -1345,8 +1345,8 @@ int ck_launch_fit_quads(ck_handle *h, const uint8_t *qframes, int qstride, size_
     if (a.min_tag_width < 3) a.min_tag_width = 3;
     a.ws = ws;
     { const char *e = getenv("CK_FIT_STOP_AFTER"); a.stop_after = e ? atoi(e) : 99; }
-    // chunk sizes: 512 points for the three multi-wave classes (fewer scans and barriers per point, 9 % less halo work); their
-    // LDS then sits right at the occupancy steps — 52.9 KB (3 workgroups/CU), 80.5 KB (2/CU) and 163 816 of 163 840 bytes (1/CU)
+    // chunk sizes: 512 points for the multi-wave classes (fewer scans and barriers per point, 9 % less halo work); their LDS
+    // then sits at the occupancy steps — 52.9 KB (3 workgroups/CU), 80.5 KB (2/CU), ≈ 124 KB and ≈ 163 KB (1/CU each)
     int cus = 256;
     a.list = lists; a.list_count = list_counts; a.head = heads;
     hipLaunchKernelGGL((k_fit<64, 512, 64, true, 3>), dim3((unsigned)(cus * 12)), dim3(64), 0, h->stream, a);
