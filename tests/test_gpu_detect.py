@@ -321,3 +321,35 @@ def test_detect_matches_oracle_under_other_front_end_settings(oracle, kw):
         assert status[i] == st
         _same_dets(dets[i], want)
     det.close()
+
+
+@pytest.mark.parametrize("kind", ["checker1", "vstripes1", "random", "saturated", "tag_in_random"])
+def test_adversarial_frames_match_oracle(oracle, kind):
+    """Frames built to stress the lock-free phases rather than to look like a camera image: the whole pipeline must return what
+    the oracle returns (detections, status bits), not hang and not fault."""
+    from chalkydri_amd.detector import AprilTagDetector
+    w, h, n = 640, 480, 2
+    rng = np.random.default_rng(77)
+    yy, xx = np.mgrid[0:h, 0:w]
+    if kind == "checker1":
+        frames = np.broadcast_to((((yy + xx) & 1) * 255).astype(np.uint8), (n, h, w)).copy()
+    elif kind == "vstripes1":
+        frames = np.zeros((n, h, w), np.uint8); frames[:, :, ::2] = 255
+    elif kind == "random":
+        frames = rng.integers(0, 256, (n, h, w), dtype=np.uint8)
+    elif kind == "saturated":
+        frames = np.full((n, h, w), 255, np.uint8); frames[1] = 0
+    else:   # a real tag scene with every second row replaced by full-range noise
+        frames, _ = synth.render_batch(15, n, w, h, 4)
+        frames = frames.copy(); frames[:, ::2, :] = rng.integers(0, 256, (n, h // 2, w), dtype=np.uint8)
+    det = AprilTagDetector(w, h, max_batch=n)
+    got, status = det.detect_batch(frames, cap=64, return_status=True)
+    cfg = default_config(w, h)
+    for i in range(n):
+        want, st = oracle.detect(frames[i], cfg)
+        full = 1 | 2   # CK_FRAME_POINTS_OVERFLOW | CK_FRAME_CLUSTERS_OVERFLOW: the oracle reports both kinds as the first
+        assert bool(status[i] & full) == bool(st & full)
+        if not (st & full):   # which clusters survive a full buffer is not part of the contract; that it is reported is
+            assert status[i] == st
+            _same_dets(got[i], want)
+    det.close()

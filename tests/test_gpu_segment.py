@@ -32,11 +32,18 @@ def _frames(kind, w, h, n, seed):
             f[:, k:h - k, k] = 255; f[:, k, k:w - k] = 255
             f[:, k + 2:h - k, w - 1 - k] = 255; f[:, h - 1 - k, k + 2:w - k] = 255
         return f
+    if kind == "checker1":   # one-pixel checkerboard: every black pixel its own component, all white pixels one (8-connected)
+        yy, xx = np.mgrid[0:h, 0:w]
+        return np.broadcast_to((((yy + xx) & 1) * 255).astype(np.uint8), (n, h, w)).copy()
+    if kind == "vstripes1":  # one-pixel vertical stripes: the most runs a row can have, every one spanning all tiles of its column
+        f = np.zeros((n, h, w), np.uint8)
+        f[:, :, ::2] = 255
+        return f
     raise ValueError(kind)
 
 
 @pytest.mark.parametrize("w,h", [(640, 480), (272, 200), (128, 64), (132, 68), (1280, 800)])
-@pytest.mark.parametrize("kind", ["synth", "noise", "flat", "stripes", "blobs", "spiral"])
+@pytest.mark.parametrize("kind", ["synth", "noise", "flat", "stripes", "blobs", "spiral", "checker1", "vstripes1"])
 def test_threshold_segment_bit_exact(oracle, w, h, kind):
     from chalkydri_amd.detector import AprilTagDetector
     n = 2
