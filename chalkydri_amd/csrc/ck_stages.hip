@@ -12,7 +12,7 @@ int ck_stage_alloc(ck_handle *h) {
     const ck_config_t &cfg = h->cfg;
     const size_t nb = (size_t)cfg.max_batch;
     const int npix = (int)h->npix;
-    ws.point_cap = cfg.max_points_per_frame > 0 ? cfg.max_points_per_frame : 2 * npix;
+    ws.point_cap = cfg.max_points_per_frame > 0 ? cfg.max_points_per_frame : 4 * npix; // a pixel has four forward neighbours: no frame has more
     ws.cluster_cap = cfg.max_clusters_per_frame > 0 ? cfg.max_clusters_per_frame : npix / 32;
     if (ws.cluster_cap < 1024) ws.cluster_cap = 1024;
     if (ws.cluster_cap > (1 << 19)) ws.cluster_cap = 1 << 19; // keeps the hash table (2x) at most 2^20 slots per frame

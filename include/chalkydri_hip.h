@@ -104,7 +104,8 @@ typedef struct ck_config {
     int32_t max_hamming;          /* bits_corrected: 3 with a config, 1 without (lib.rs:230,280) */
     int32_t n_families;
     const ck_family_t *families[CK_MAX_FAMILIES];
-    /* capacities of the irregular stages (0 = derive from geometry) */
+    /* capacities of the irregular stages (0 = derive from geometry: 4 points per pixel — the most a frame can produce,
+     * one per forward neighbour —, one cluster per 32 pixels, 1024 quads) */
     int32_t max_points_per_frame;
     int32_t max_clusters_per_frame;
     int32_t max_quads_per_frame;

@@ -816,8 +816,8 @@ int ora_detect(const uint8_t *img, int w, int h, int stride, const ck_config_t *
     uint32_t *labels = (uint32_t *)malloc(n * 4), *sizes = (uint32_t *)malloc(n * 4);
     ora_threshold(q, qw, qh, qstride, cfg->min_white_black_diff, th);
     ora_segment(th, qw, qh, labels, sizes);
-    int pcap = cfg->max_points_per_frame > 0 ? cfg->max_points_per_frame : (int)(2 * n);
-    int ccap = cfg->max_clusters_per_frame > 0 ? cfg->max_clusters_per_frame : (int)(n / 8 + 1024);
+    int pcap = cfg->max_points_per_frame > 0 ? cfg->max_points_per_frame : (int)(4 * n);
+    int ccap = cfg->max_clusters_per_frame > 0 ? cfg->max_clusters_per_frame : (n / 32 < 1024 ? 1024 : (int)(n / 32)); /* the library's defaults */
     int qcap = cfg->max_quads_per_frame > 0 ? cfg->max_quads_per_frame : 1024;
     ck_cluster_t *cl = (ck_cluster_t *)malloc((size_t)ccap * sizeof *cl);
     ck_cluster_point_t *pts = (ck_cluster_point_t *)malloc((size_t)pcap * sizeof *pts);
