@@ -268,6 +268,34 @@ def test_full_size_batch_properties(oracle):
     task.detector.close()
 
 
+def test_config4_stream_batch_properties(oracle):
+    """BASELINE config 4, one GPU's share: one camera stream (seed offset s * 10^6) at batch 1024.  Eight distinct
+    frames fill the batch in shuffled positions: every copy of a frame must give the same record wherever it sits (frame
+    indices above 255 exercise the wide end of the frame << 20 | cluster work items), and the eight records equal the oracle's."""
+    from chalkydri_amd.apriltags import AprilTags
+    w, h, n, uniq, stream = 1280, 800, 1024, 8, 5
+    frames8, gyro8, layout, calib, r2c = scenes.bench_stream(2, uniq, w, h, 6, stream=stream, unique=uniq, noise_amp=3)
+    rng = np.random.default_rng(4)
+    which = rng.permutation(np.repeat(np.arange(uniq), n // uniq))
+    task = AprilTags(w, h, layout, calib, r2c, cam_id=stream, max_batch=n)
+    recs, valid = task.process_batch(frames8[which], [float(gyro8[k]) for k in which])
+    assert valid.all()
+    first = {}
+    for i in range(n):
+        k = int(which[i])
+        assert first.setdefault(k, bytes(recs[i])) == bytes(recs[i]), f"frame copy {i} of {k} differs"
+    cfg = default_config(w, h)
+    for k in range(uniq):
+        out = A.VisionMeasurement()
+        v = C.c_int(0)
+        oracle.lib().ora_process_frame(C.c_void_p(frames8[k].ctypes.data), w, h, w, C.byref(cfg), C.byref(task._pp),
+                                       C.c_double(float(gyro8[k])), 1, C.byref(out), C.byref(v))
+        r = A.VisionMeasurement.from_buffer_copy(first[k])
+        assert v.value == 1 and r.tag_count == out.tag_count and r.camera_id == stream
+        assert abs(r.pose_x - out.pose_x) < 1e-6 and abs(r.pose_y - out.pose_y) < 1e-6 and abs(r.pose_rot - out.pose_rot) < 1e-7
+    task.detector.close()
+
+
 def test_glue_filters(oracle):
     """AprilTags::process filters (crates/apriltags/src/lib.rs:306-330): tags missing from the field layout do not enter the
     solve but still count in tag_count; a frame whose tags are all unknown, a frame without tags, and a frame without gyro
