@@ -332,7 +332,15 @@ __global__ __launch_bounds__(SQ_NT) void k_sqpnp(SolveArgs a) {
     }
     __syncthreads();
     if (a.stop_after == 1) return;
-    // symmetric eigen-decomposition of Omega: cyclic Jacobi, 9 lanes update one element of the rotated rows/columns
+    // symmetric eigen-decomposition of Omega: cyclic Jacobi, 9 lanes update one element of the rotated rows/columns.  The
+    // first wave does it alone: a wave's LDS accesses execute in program order, so the three hand-overs of a rotation need
+    // no workgroup barrier (36 rotations x ~10 sweeps x 3 barriers were a third of this kernel's dependency chain).
+    auto wave_sync = [] {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    if (lane < 64)
     for (int sweep = 0; sweep < 64; sweep++) {
         double off = 0;
         for (int i = 0; i < 9; i++)
@@ -346,14 +354,15 @@ __global__ __launch_bounds__(SQ_NT) void k_sqpnp(SolveArgs a) {
                 double theta = (aqq - app) / (2.0 * apq);
                 double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
                 double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
-                __syncthreads();
+                wave_sync();
                 if (lane < 9) { int k = lane; double akp = sA[k * 9 + p], akq = sA[k * 9 + q]; sA[k * 9 + p] = c * akp - s * akq; sA[k * 9 + q] = s * akp + c * akq; }
-                __syncthreads();
+                wave_sync();
                 if (lane < 9) { int k = lane; double apk = sA[p * 9 + k], aqk = sA[q * 9 + k]; sA[p * 9 + k] = c * apk - s * aqk; sA[q * 9 + k] = s * apk + c * aqk; }
                 if (lane < 9) { int k = lane; double vkp = sV[k * 9 + p], vkq = sV[k * 9 + q]; sV[k * 9 + p] = c * vkp - s * vkq; sV[k * 9 + q] = s * vkp + c * vkq; }
-                __syncthreads();
+                wave_sync();
             }
     }
+    __syncthreads();
     if (lane == 0) {
         for (int i = 0; i < 9; i++) { sW[i] = sA[i * 9 + i]; sIdx[i] = i; }
         for (int i = 1; i < 9; i++) { // stable ascending order of eigenvalues (lib.rs:400-401)
