@@ -172,7 +172,8 @@ def main():
                        "frames_with_pose": round(valid_frac, 4), "post_segment_streams": int(os.environ.get("CK_STREAMS", "1")), "gather": "RCCL all_gather of 64-byte records" if world > 1 else "none (1 GPU)"},
             "roofline": {"bound": "hbm", "kernel": "threshold+segment (k_tile + k_merge + k_roots)", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "measured_copy_GBps": round(copy_gbps, 1),
-                         "algorithmic_bytes_per_launch": ALG_BYTES_PER_PX * w * h * n, "avg_launch_ms": round(ms_thr, 4)},
+                         "algorithmic_bytes_per_launch": ALG_BYTES_PER_PX * w * h * n, "avg_launch_ms": round(ms_thr, 4),
+                         "launch_ms_p10_median_p90": [round(float(np.percentile(thr_ms, q)), 4) for q in (10, 50, 90)]},
             "stage_ms_last_step": {k: round(v, 3) for k, v in stage.items()},
         }
         if world == 1 and not args.no_extras:
