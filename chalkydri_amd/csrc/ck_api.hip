@@ -28,7 +28,10 @@ extern "C" int ck_create(const ck_config_t *cfg, ck_handle_t **out) {
     for (int i = 0; i < cfg->n_families; i++)
         if (!cfg->families[i] || cfg->families[i]->nbits > 64 || cfg->families[i]->total_width > 16) return CK_EINVAL;
     int qw = cfg->width / cfg->quad_decimate, qh = cfg->height / cfg->quad_decimate;
-    if ((qw & 3) || (qh & 3)) return CK_EUNSUPPORTED; // the threshold kernel assumes whole 4x4 tiles
+    if (qw & 3) return CK_EUNSUPPORTED; // rows are handled in 4-pixel words
+    // a height that is not a multiple of 4 leaves one to three rows below the last whole 4x4 tile; they take that tile's
+    // threshold, which the segmentation kernel finds in its own 64-row tile unless the leftover rows start a new one
+    if ((qh & 3) && ((qh & ~3) % CK_TH) == 0) return CK_EUNSUPPORTED;
     if (cfg->min_component_px < 1 || cfg->min_component_px > 127) return CK_EUNSUPPORTED; // tile-local sizes saturate at 127 (k_ccl.hip)
     if (ck_device_count() <= 0) return CK_ENODEVICE;
     ck_handle *h = new (std::nothrow) ck_handle();

@@ -250,9 +250,12 @@ __global__ __launch_bounds__(KNT) void k_tile(const uint8_t *__restrict__ frames
         uint4 px = *reinterpret_cast<const uint4 *>(lds + OFF_IMG + (r + 4) * IMG_PITCH + 16 + 16 * c);
         uint32_t in[4] = {px.x, px.y, px.z, px.w}, out[4];
         uint32_t wbits = 0, bbits = 0;
+        // the one to three rows below the last whole 4x4 tile take that tile's threshold (the oracle's ragged-edge rule);
+        // ck_create refuses the heights whose last whole tile row belongs to the workgroup above
+        const int r4 = min((ty0 + r) >> 2, h4 - 1) - (ty0 >> 2);
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            uint32_t tw_ = PRE ? 0u : thr[(r >> 2) * (TW / 4) + 4 * c + k];
+            uint32_t tw_ = PRE ? 0u : thr[r4 * (TW / 4) + 4 * c + k];
             uint32_t o;
             if (gy >= h || gx + 4 * k >= w) o = 0x7F7F7F7Fu;      // outside the frame: no colour
             else if (PRE) o = in[k];

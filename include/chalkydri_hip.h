@@ -131,6 +131,9 @@ const char *ck_strerror(int code);
 const char *ck_last_error(void); /* text of the most recent CK_EDEVICE on this thread */
 int ck_device_count(void);       /* 0 when no HIP device is visible */
 
+/* Frame geometry accepted by ck_create (checked on the image the front end works on, i.e. after quad_decimate): 16..4095
+ * pixels per side, width a multiple of 4, any height except 64k+1..64k+3 (CK_EUNSUPPORTED otherwise); quad_decimate 1 or 2;
+ * min_component_px 1..127.  Arguments are validated before a device is looked for (CK_ENODEVICE). */
 int ck_create(const ck_config_t *cfg, ck_handle_t **out);
 void ck_destroy(ck_handle_t *h);
 

@@ -90,7 +90,8 @@ def test_create_validates_before_touching_a_device(built):
         cfg = default_config(size[0], size[1], **kw)
         return L.ck_create(C.byref(cfg), C.byref(h))
     assert rc(size=(8, 8)) == A.CK_EINVAL                       # smaller than the 16-pixel minimum
-    assert rc(size=(642, 480)) == A.CK_EUNSUPPORTED             # sides must be multiples of 4
+    assert rc(size=(642, 480)) == A.CK_EUNSUPPORTED             # the width must be a multiple of 4
+    assert rc(size=(640, 450)) == A.CK_EUNSUPPORTED             # 450 = 7 * 64 + 2: the two leftover rows would start a tile of their own
     assert rc(quad_decimate=3) == A.CK_EUNSUPPORTED
     assert rc(min_component_px=200) == A.CK_EUNSUPPORTED        # tile-local sizes saturate at 127
     assert rc() in (A.CK_OK, A.CK_ENODEVICE)                    # a valid config fails only for lack of a device

@@ -220,10 +220,12 @@ def test_detector_golden_vectors(built):
             assert [[float.fromhex(v) for v in p] for p in e["corners"]] == np.asarray(d.corners()).tolist()
 
 
-@pytest.mark.parametrize("w,h", [(16, 16), (32, 20), (68, 52), (132, 68), (260, 72), (516, 36)])
+@pytest.mark.parametrize("w,h", [(16, 16), (32, 20), (68, 52), (132, 68), (260, 72), (516, 36),
+                                 (64, 18), (132, 70), (260, 135), (640, 483)])   # the last four: height not a multiple of 4
 def test_small_and_ragged_frames(oracle, w, h):
     """Frames much smaller than a 64x128 tile and not multiples of it: binary noise, blobs and a frame-filling square —
-    labels, clusters, quads and detections still equal the oracle's (nothing reads or writes outside the frame)."""
+    labels, clusters, quads and detections still equal the oracle's (nothing reads or writes outside the frame).  Heights
+    that are not multiples of 4 leave rows below the last whole 4x4 tile: they take that tile's threshold, as in the oracle."""
     from chalkydri_amd.detector import AprilTagDetector
     rng = np.random.default_rng(w * 1000 + h)
     f0 = rng.integers(0, 256, (h, w), dtype=np.uint8)                                   # full-contrast noise
@@ -352,4 +354,22 @@ def test_adversarial_frames_match_oracle(oracle, kind):
         if not (st & full):   # which clusters survive a full buffer is not part of the contract; that it is reported is
             assert status[i] == st
             _same_dets(got[i], want)
+    det.close()
+
+
+@pytest.mark.parametrize("w,h", [(640, 480), (1280, 800), (800, 652)])   # 652 / 2 = 326: two rows below the last whole 4x4 tile
+def test_detect_matches_oracle_at_the_default_decimation(oracle, w, h):
+    """quad_decimate = 2 is the detector's library default and therefore what the reference runs (it never changes detector
+    settings, crates/apriltags/src/lib.rs:258-262): threshold / segmentation / clusters / fit on the half-size image, edge
+    refinement and decoding on the full one — detections and status bits equal the oracle's."""
+    from chalkydri_amd.detector import AprilTagDetector
+    n = 2
+    frames, _ = _synth(17, w, h, n, 4, noise_amp=3)
+    det = AprilTagDetector(w, h, max_batch=n, quad_decimate=2)
+    cfg = default_config(w, h, quad_decimate=2)
+    dets, status = det.detect_batch(frames, cap=64, return_status=True)
+    for i in range(n):
+        want, st = oracle.detect(frames[i], cfg)
+        assert status[i] == st and len(want) >= 2
+        _same_dets(dets[i], want)
     det.close()
