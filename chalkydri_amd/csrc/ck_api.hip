@@ -62,6 +62,9 @@ extern "C" int ck_create(const ck_config_t *cfg, ck_handle_t **out) {
     for (auto &e : h->ev) CK_TRY(hipEventCreate(&e));
     CK_TRY(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
     CK_TRY(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+    CK_TRY(hipEventCreateWithFlags(&h->ev_fit_fork, hipEventDisableTiming));
+    for (auto &st : h->fit_stream) CK_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    for (auto &e : h->ev_fit_join) CK_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     CK_TRY(hipMalloc(&h->d_frames, h->frame_pitch * nb));
     if (cfg->quad_decimate > 1) CK_TRY(hipMalloc(&h->d_qframes, (size_t)round_up(qw, 16) * qh * nb));
     CK_TRY(hipMalloc(&h->d_thresh, h->npix * nb));
@@ -81,12 +84,16 @@ extern "C" void ck_destroy(ck_handle_t *h) {
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->stream2) (void)hipStreamSynchronize(h->stream2);
+    for (auto &st : h->fit_stream) if (st) (void)hipStreamSynchronize(st);
     ck_stage_free(h);
     (void)hipFree(h->d_frames); (void)hipFree(h->d_qframes); (void)hipFree(h->d_thresh); (void)hipFree(h->d_labels);
     (void)hipFree(h->d_csize); (void)hipFree(h->d_broots); (void)hipFree(h->d_broot_count);
     for (auto &e : h->ev) if (e) (void)hipEventDestroy(e);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
+    if (h->ev_fit_fork) (void)hipEventDestroy(h->ev_fit_fork);
+    for (auto &e : h->ev_fit_join) if (e) (void)hipEventDestroy(e);
+    for (auto &st : h->fit_stream) if (st) (void)hipStreamDestroy(st);
     if (h->stream2) (void)hipStreamDestroy(h->stream2);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;

@@ -39,6 +39,8 @@ struct ck_dev_family {
 // One boundary point while it waits to be grouped (k_clusters.hip)
 // size classes of the quad fit (k_quads.hip): <= 512, <= 2048, <= 4096, <= 8192, <= 16384 points per cluster
 constexpr int CK_FIT_CLASSES = 5;
+constexpr int CK_FIT_PARALLEL_MAX_FRAMES = 4; // calls with at most this many frames run the classes side by side ...
+constexpr int CK_FIT_SIDE_STREAMS = 2;         // ... on the handle's stream and this many more (a process has few hardware queues)
 constexpr int CK_LSCRATCH_PER_WG = 16384, CK_LSCRATCH_WGS = 1024; // large class: points per cluster, workgroups in its grid (at most)
 
 // A boundary point inside the pipeline, packed into 32 bits: [x:13][y:13][direction:2][sign:1] at bits 28..16, 15..3, 2..1, 0.
@@ -109,6 +111,10 @@ struct ck_handle {
     hipStream_t stream2;  // with CK_STREAMS=2 the later pieces of a batch run their irregular stages here (ck_stages.hip: run_pipeline)
     hipEvent_t ev[16];
     hipEvent_t ev_fork, ev_join;
+    // a call with a few frames runs the size classes of the quad fit side by side (k_quads.hip): each class is then a handful of
+    // workgroups whose time is one cluster's dependency chain, and five chains in a row were a quarter of a one-frame call
+    hipStream_t fit_stream[CK_FIT_SIDE_STREAMS];
+    hipEvent_t ev_fit_fork, ev_fit_join[CK_FIT_SIDE_STREAMS];
     int w, h;            // full-resolution frame
     int qw, qh;          // geometry of the image the quad stages run on (w/decimate)
     int tiles_x, tiles_y;

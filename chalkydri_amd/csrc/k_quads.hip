@@ -1348,16 +1348,34 @@ int ck_launch_fit_quads(ck_handle *h, const uint8_t *qframes, int qstride, size_
     // chunk sizes: 512 points for the multi-wave classes (fewer scans and barriers per point, 9 % less halo work); their LDS
     // then sits at the occupancy steps — 52.9 KB (3 workgroups/CU), 80.5 KB (2/CU), ≈ 124 KB and ≈ 163 KB (1/CU each)
     int cus = 256;
-    a.list = lists; a.list_count = list_counts; a.head = heads;
-    hipLaunchKernelGGL((k_fit<64, 512, 64, true, 3>), dim3((unsigned)(cus * 12)), dim3(64), 0, h->stream, a);
-    a.list = lists + list_cap; a.list_count = list_counts + 1; a.head = heads + 1;
-    hipLaunchKernelGGL((k_fit<256, 2048, 512, true, 3>), dim3((unsigned)(cus * 3)), dim3(256), 0, h->stream, a);
-    a.list = lists + 2 * (size_t)list_cap; a.list_count = list_counts + 2; a.head = heads + 2;
-    hipLaunchKernelGGL((k_fit<256, 4096, 512, true, 2>), dim3((unsigned)(cus * 2)), dim3(256), 0, h->stream, a);
-    a.list = lists + 3 * (size_t)list_cap; a.list_count = list_counts + 3; a.head = heads + 3;
-    hipLaunchKernelGGL((k_fit<512, 8192, 512, true, 2>), dim3((unsigned)cus), dim3(512), 0, h->stream, a);
-    a.list = lists + 4 * (size_t)list_cap; a.list_count = list_counts + 4; a.head = heads + 4;
-    hipLaunchKernelGGL((k_fit<512, 16384, 512, false, 2>), dim3((unsigned)cus), dim3(512), 0, h->stream, a);
+    // A small call (one frame per call is the reference's own pattern) gives every class a handful of workgroups whose time is
+    // one cluster's dependency chain: the classes then run side by side on their own streams instead of one after the other.
+    const bool side_by_side = n <= CK_FIT_PARALLEL_MAX_FRAMES;
+    // three lanes of similar length for a typical frame: {S, M1} on the handle's stream, {L1} and {M2, L2} on the side streams
+    // (more streams than that end up sharing hardware queues and wait for each other anyway)
+    hipStream_t cs[CK_FIT_CLASSES] = {h->stream, h->stream, h->stream, h->stream, h->stream};
+    if (side_by_side) {
+        cs[3] = h->fit_stream[0]; cs[2] = h->fit_stream[1]; cs[4] = h->fit_stream[1];
+        CK_HIP(hipEventRecord(h->ev_fit_fork, h->stream));
+        for (int k = 0; k < CK_FIT_SIDE_STREAMS; k++) CK_HIP(hipStreamWaitEvent(h->fit_stream[k], h->ev_fit_fork, 0));
+    }
+    auto launch = [&](int c) {
+        a.list = lists + (size_t)c * list_cap; a.list_count = list_counts + c; a.head = heads + c;
+        switch (c) {
+        case 0: hipLaunchKernelGGL((k_fit<64, 512, 64, true, 3>), dim3((unsigned)(cus * 12)), dim3(64), 0, cs[c], a); break;
+        case 1: hipLaunchKernelGGL((k_fit<256, 2048, 512, true, 3>), dim3((unsigned)(cus * 3)), dim3(256), 0, cs[c], a); break;
+        case 2: hipLaunchKernelGGL((k_fit<256, 4096, 512, true, 2>), dim3((unsigned)(cus * 2)), dim3(256), 0, cs[c], a); break;
+        case 3: hipLaunchKernelGGL((k_fit<512, 8192, 512, true, 2>), dim3((unsigned)cus), dim3(512), 0, cs[c], a); break;
+        default: hipLaunchKernelGGL((k_fit<512, 16384, 512, false, 2>), dim3((unsigned)cus), dim3(512), 0, cs[c], a); break;
+        }
+    };
+    if (side_by_side) { launch(3); launch(2); launch(4); launch(0); launch(1); } // the side lanes first, then the handle's own
+    else for (int c = 0; c < CK_FIT_CLASSES; c++) launch(c);
+    if (side_by_side)
+        for (int k = 0; k < CK_FIT_SIDE_STREAMS; k++) {
+            CK_HIP(hipEventRecord(h->ev_fit_join[k], h->fit_stream[k]));
+            CK_HIP(hipStreamWaitEvent(h->stream, h->ev_fit_join[k], 0));
+        }
     hipLaunchKernelGGL(k_clamp_counts, dim3(1), dim3(64), 0, h->stream, list_counts, list_cap, ws, n);
     CK_HIP(hipGetLastError());
     return CK_OK;
