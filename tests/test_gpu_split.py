@@ -17,7 +17,8 @@ sys.path.insert(0, %r); sys.path.insert(0, %r)
 import numpy as np
 import scenes
 from chalkydri_amd.apriltags import AprilTags
-w, h, f, n = 640, 480, 600.0, 7
+import os
+w, h, f, n = 640, 480, 600.0, int(os.environ.get("SPLIT_N", "7"))
 layout = scenes.wall_layout(6, cols=3)
 r2c = {"roll": 0.0, "pitch": 0.0, "yaw": 0.0, "x": 0.2, "y": 0.0, "z": 0.6}
 calib = scenes.pinhole_calib(f, w / 2.0, h / 2.0)
@@ -26,7 +27,7 @@ frames, gyros = [], []
 for i in range(n):
     pose = (rng.uniform(1.8, 2.4), rng.uniform(-0.2, 0.2), rng.uniform(-0.1, 0.1))
     frames.append(scenes.render_view(900 + i, w, h, f, layout, pose, r2c, noise_amp=3)[0]); gyros.append(pose[2])
-gyros[4] = None
+if n > 4: gyros[4] = None
 task = AprilTags(w, h, layout, calib, r2c, cam_id=1, max_batch=n)
 recs, valid = task.process_batch(np.stack(frames), gyros)
 dets, status = task.detector.detect_batch(np.stack(frames), cap=32, return_status=True)
@@ -54,3 +55,12 @@ def test_results_do_not_depend_on_the_split(built):
     assert _run({})[0] == single                                        # default
     assert _run({"CK_STREAMS": "2"})[0] == single                       # two halves on two streams
     assert _run({"CK_STREAMS": "2", "CK_PARTS": "3"})[0] == single      # three uneven pieces
+
+
+def test_small_calls_do_not_depend_on_the_split_either(built):
+    """Three frames: the quad fit's size classes run side by side on their own streams (calls with at most 4 frames), with and
+    without the two-stream split of the batch on top."""
+    single, nvalid = _run({"CK_STREAMS": "1", "SPLIT_N": "3"})
+    assert nvalid == 3
+    assert _run({"CK_STREAMS": "2", "SPLIT_N": "3"})[0] == single
+    assert _run({"CK_STREAMS": "2", "CK_PARTS": "3", "SPLIT_N": "3"})[0] == single
