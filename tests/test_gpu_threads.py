@@ -19,11 +19,12 @@ def _key(frames_dets):
 def test_two_handles_on_two_host_threads(built):
     from chalkydri_amd.detector import AprilTagDetector
     w, h, n = 640, 480, 6
+    ns = (n, 3)   # the second handle makes small calls: its quad-fit classes run on the handle's side streams
     stacks = [np.stack([synth.render(synth.frame_seed(7, 10 * t + i), w, h, 4, min_side=40, max_side=140, noise_amp=3)[0]
-                        for i in range(n)]) for t in range(2)]
+                        for i in range(ns[t])]) for t in range(2)]
     dets = [AprilTagDetector(w, h, max_batch=n) for _ in range(2)]
     want = [_key(dets[t].detect_batch(stacks[t])) for t in range(2)]
-    assert all(sum(len(f) for f in k) >= n for k in want)
+    assert all(sum(len(f) for f in k) >= len(k) for k in want)
     got = [[None] * 8 for _ in range(2)]
     errs = []
 
