@@ -136,6 +136,16 @@ __device__ void nearest_so3(const double r_vec[9], double out[9]) { // column-ma
 // column is the unpivoted lane with the largest |entry| (smallest logical row on ties, like the sequential scan), its row
 // is broadcast by shuffles and every other unpivoted lane eliminates in registers.  Each entry sees exactly the operations
 // of the sequential code, in the same order, so the result is bit-identical to it.
+// one step of an all-reduce over a DPP row (16 lanes): combine with the lane N places round the row (row_ror:N)
+template <int N>
+__device__ __forceinline__ void row_max_step(double &best, int &meta) {
+    const long long bits = __double_as_longlong(best);
+    const int lo = __builtin_amdgcn_update_dpp((int)bits, (int)bits, 0x120 + N, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp((int)(bits >> 32), (int)(bits >> 32), 0x120 + N, 0xF, 0xF, false);
+    const int om = __builtin_amdgcn_update_dpp(meta, meta, 0x120 + N, 0xF, 0xF, false);
+    const double ob = __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+    if (ob > best || (ob == best && om < meta)) { best = ob; meta = om; }
+}
 __device__ double optimization16(int max_iter, double tol_sq, double r[9], const double *omega, int gl) {
     const int row = gl; // 0..14 own a row; 15 computes along on a zero row and is never a pivot
     for (int it = 0; it < max_iter; it++) {
@@ -191,14 +201,13 @@ __device__ double optimization16(int max_iter, double tol_sq, double r[9], const
         for (int col = 0; col < 15; col++) {
             // pivot: largest |A[.][col]| among unpivoted lanes, smallest logical row on ties (the sequential scan keeps the
             // first maximum because it only replaces on a strictly larger value)
+            // The 16 lanes of a group are one DPP row: four rotations (by 8, 4, 2, 1) with this combiner leave the same winner
+            // in every lane — the order (value descending, logical row ascending) is total over the unpivoted lanes, so the
+            // reduction order does not matter — and cost register moves instead of sixteen trips through the LDS crossbar.
             double best = pivoted ? -1.0 : fabs(A[col]);
-            int bl = pivoted ? 99 : lrow, bs = gl;
-#pragma unroll
-            for (int d = 8; d >= 1; d >>= 1) {
-                const double ob = __shfl_xor(best, d, 16);
-                const int ol = __shfl_xor(bl, d, 16), os = __shfl_xor(bs, d, 16);
-                if (ob > best || (ob == best && ol < bl)) { best = ob; bl = ol; bs = os; }
-            }
+            int meta = ((pivoted ? 99 : lrow) << 8) | gl; // logical row, then the lane that holds it
+            row_max_step<8>(best, meta); row_max_step<4>(best, meta); row_max_step<2>(best, meta); row_max_step<1>(best, meta);
+            const int bl = meta >> 8, bs = meta & 0xFF;
             if (best == 0.0) { singular = true; break; }
             // the lane that held logical row `col` takes over the pivot lane's logical row (a swap, without moving data)
             if (!pivoted && lrow == col && gl != bs) lrow = bl;
