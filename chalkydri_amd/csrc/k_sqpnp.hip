@@ -53,9 +53,13 @@ __device__ int mat3_try_inverse(const double m[9], double o[9]) {
 // serial cyclic Jacobi for small symmetric matrices (used for the 3x3 cases)
 __device__ void jacobi3(double A[9], double V[9], double w[3]) {
     for (int i = 0; i < 9; i++) V[i] = (i % 4 == 0);
+    double tot = 0; // same stop rule and summation order as the oracle's jacobi_eigen
+    for (int i = 0; i < 9; i++) tot += A[i] * A[i];
+    const double stop = 1e-32 * tot;
     for (int sweep = 0; sweep < 64; sweep++) {
-        double off = A[1] * A[1] + A[2] * A[2] + A[5] * A[5];
-        if (off < 1e-300) break;
+        double off = 0;
+        off += A[1] * A[1]; off += A[2] * A[2]; off += A[5] * A[5];
+        if (off <= stop) break;
         for (int p = 0; p < 3; p++)
             for (int q = p + 1; q < 3; q++) {
                 double apq = A[p * 3 + q];
@@ -349,12 +353,15 @@ __global__ __launch_bounds__(SQ_NT) void k_sqpnp(SolveArgs a) {
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     };
+    double jtot = 0; // Frobenius norm^2 of Omega: the sweeps stop at 1e-32 of it (oracle: jacobi_eigen)
+    for (int e = 0; e < 81; e++) jtot += sA[e] * sA[e];
+    const double jstop = 1e-32 * jtot;
     if (lane < 64)
     for (int sweep = 0; sweep < 64; sweep++) {
         double off = 0;
         for (int i = 0; i < 9; i++)
             for (int j = i + 1; j < 9; j++) off += sA[i * 9 + j] * sA[i * 9 + j];
-        if (off < 1e-300) break;
+        if (off <= jstop) break;
         for (int p = 0; p < 9; p++)
             for (int q = p + 1; q < 9; q++) {
                 double apq = sA[p * 9 + q];

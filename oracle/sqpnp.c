@@ -78,11 +78,17 @@ static int mat3_try_inverse(const double m[9], double o[9]) {
 static void jacobi_eigen(double *A, int n, double *V, double *w) {
     for (int i = 0; i < n; i++)
         for (int j = 0; j < n; j++) V[i * n + j] = (i == j);
+    /* sweeps stop once the off-diagonal part is below 1e-16 of the matrix in the Frobenius norm (rotations preserve that
+     * norm, so it is taken once): further sweeps would only push already negligible entries towards underflow */
+    double tot = 0;
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < n; j++) tot += A[i * n + j] * A[i * n + j];
+    const double stop = 1e-32 * tot;
     for (int sweep = 0; sweep < 64; sweep++) {
         double off = 0;
         for (int i = 0; i < n; i++)
             for (int j = i + 1; j < n; j++) off += A[i * n + j] * A[i * n + j];
-        if (off < 1e-300) break;
+        if (off <= stop) break;
         for (int p = 0; p < n; p++)
             for (int q = p + 1; q < n; q++) {
                 double apq = A[p * n + q];
