@@ -292,6 +292,9 @@ __global__ __launch_bounds__(SNT) void k_scan(ck_stage_ws ws, int min_cluster, i
 }
 
 // One wave per run: a (tile, cluster) run of the temp array goes to its place inside the cluster, coalesced on both sides.
+// RPW: run records a wave takes per round — 64 for batches; a call with a few frames has too few runs to keep the chip busy
+// that way (8 k runs = 128 waves), so it hands them out 8 at a time over eight times as many waves
+template <int RPW>
 __global__ __launch_bounds__(NT) void k_scatter(ck_stage_ws ws) {
     const int frame = blockIdx.y;
     const uint32_t *counters = ws.d_counters + (size_t)frame * CK_CNT_STRIDE;
@@ -305,10 +308,10 @@ __global__ __launch_bounds__(NT) void k_scatter(ck_stage_ws ws) {
     const uint32_t wave = blockIdx.x * (NT / 64) + (threadIdx.x >> 6), nwaves = gridDim.x * (NT / 64);
     // 64 runs per wave and round: every lane fetches one run record and its cluster offset (two dependent loads paid once
     // for 64 runs), then the wave copies the runs one after the other (runs of up to 64 points: 16 lanes each, four runs at a time)
-    for (uint32_t r0 = wave * 64; r0 < nruns; r0 += nwaves * 64) {
+    for (uint32_t r0 = wave * RPW; r0 < nruns; r0 += nwaves * RPW) {
         ck_run mine = {0, 0, 0, 0};
         uint32_t moff = SKIP;
-        if (r0 + lane < nruns) { mine = runs[r0 + lane]; moff = goff[mine.slot]; }
+        if (lane < RPW && r0 + lane < nruns) { mine = runs[r0 + lane]; moff = goff[mine.slot]; }
         if (moff == SKIP) mine.count = 0; // cluster dropped by k_scan (too small / too large / no room)
         // goff[slot] starts as the cluster's offset and serves as its fill cursor: the add returns where this run goes
         const uint32_t dst0 = mine.count ? atomicAdd(&goff[mine.slot], mine.count) : 0u;
@@ -380,7 +383,8 @@ int ck_launch_clusters(ck_handle *h, int n) {
     hipLaunchKernelGGL(k_emit, dim3((unsigned)(a.tiles_x * a.tiles_y * n)), dim3(NT), 0, h->stream, a);
     int min_cluster = h->cfg.min_cluster_pixels < 24 ? 24 : h->cfg.min_cluster_pixels;
     hipLaunchKernelGGL(k_scan, dim3((unsigned)n), dim3(SNT), 0, h->stream, ws, min_cluster, ws.max_cluster_points);
-    hipLaunchKernelGGL(k_scatter, dim3(32u, (unsigned)n), dim3(NT), 0, h->stream, ws);
+    if (n <= 4) hipLaunchKernelGGL(k_scatter<8>, dim3(256u, (unsigned)n), dim3(NT), 0, h->stream, ws);
+    else hipLaunchKernelGGL(k_scatter<64>, dim3(32u, (unsigned)n), dim3(NT), 0, h->stream, ws);
     CK_HIP(hipGetLastError());
     return CK_OK;
 }
