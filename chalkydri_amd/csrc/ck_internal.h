@@ -175,6 +175,26 @@ int ck_process_frames(ck_handle *h, const uint8_t *frames, int stride, size_t pi
 int ck_run_pose(ck_handle *h, int n, const ck_process_params_t *pp, const double *gyro, const uint8_t *has_gyro,
                 ck_vision_measurement_t *out, int32_t *valid, bool upload_field = true, bool sync = true);
 
+// Layout of the fit scratch (ck_stage_ws::d_fit_scratch): [CK_FIT_CLASSES][list_cap] work-list entries, 8 list counts,
+// 8 dequeue heads, then (256-byte aligned) the decode candidates' per-frame counts and the candidates themselves.
+struct ck_fit_layout {
+    int list_cap;
+    uint32_t *lists, *list_counts, *heads, *cand_count;
+    ck_detection_t *cands;
+};
+static inline ck_fit_layout ck_fit_scratch_layout(const ck_stage_ws &ws, int max_batch) {
+    ck_fit_layout L;
+    L.list_cap = ws.cluster_cap * max_batch;
+    L.lists = reinterpret_cast<uint32_t *>(ws.d_fit_scratch);
+    L.list_counts = L.lists + (size_t)CK_FIT_CLASSES * L.list_cap;
+    L.heads = L.list_counts + 8;
+    const size_t list_bytes = ((size_t)CK_FIT_CLASSES * L.list_cap + 16) * sizeof(uint32_t);
+    uint8_t *base = reinterpret_cast<uint8_t *>(ws.d_fit_scratch) + ((list_bytes + 255) / 256) * 256;
+    L.cand_count = reinterpret_cast<uint32_t *>(base);
+    L.cands = reinterpret_cast<ck_detection_t *>(base + (((size_t)max_batch * 4 + 255) / 256) * 256);
+    return L;
+}
+
 #ifdef __HIPCC__
 // Wave-wide inclusive sums on the DPP path (no LDS crossbar, no lane-index arithmetic): four row_shr steps inside each
 // row of 16 lanes, then row_bcast:15 into rows 1 and 3 and row_bcast:31 into rows 2 and 3.  Lanes without a source add 0.

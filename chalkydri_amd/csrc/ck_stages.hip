@@ -302,6 +302,7 @@ extern "C" int ck_quads_batch(ck_handle_t *h, const ck_image_u8_t *imgs, int32_t
     CK_HIP(hipMemcpy(counters.data(), ws.d_counters, counters.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
     for (int i = 0; i < n; i++) {
         uint32_t nq = counters[(size_t)i * CK_CNT_STRIDE + CK_CNT_QUADS];
+        if (nq > (uint32_t)ws.quad_cap) nq = (uint32_t)ws.quad_cap; // the counter keeps counting past the capacity (status bit set)
         if ((int)nq > quad_cap) return CK_ECAPACITY;
         CK_HIP(hipMemcpy(quads + (size_t)i * quad_cap, ws.d_quads + (size_t)i * ws.quad_cap, sizeof(ck_quad_t) * nq, hipMemcpyDeviceToHost));
         n_quads[i] = (int32_t)nq;

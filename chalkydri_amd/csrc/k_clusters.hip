@@ -239,6 +239,18 @@ __global__ __launch_bounds__(NT) void k_emit(EmitArgs a) {
     }
 }
 
+// zeroes the frames' key and count tables (16 bytes per thread) and, with its first threads, three short arrays
+__global__ __launch_bounds__(NT) void k_clear(uint4 *keys4, size_t nkeys4, uint4 *cnt4, size_t ncnt4, uint32_t *c0, uint32_t n0, uint32_t *c1,
+                                              uint32_t n1, uint32_t *c2, uint32_t n2) {
+    const size_t i = (size_t)blockIdx.x * NT + threadIdx.x;
+    const uint4 z = make_uint4(0, 0, 0, 0);
+    if (i < nkeys4) keys4[i] = z;
+    else if (i - nkeys4 < ncnt4) cnt4[i - nkeys4] = z;
+    if (i < n0) c0[i] = 0;
+    if (i < n1) c1[i] = 0;
+    if (i < n2) c2[i] = 0;
+}
+
 // ---- per-frame scan of the hash table -------------------------------------------------------------------------
 constexpr int SNT = 1024;
 // One workgroup per frame; every wave owns a contiguous 1/16 of the table and walks it 64 slots at a time (coalesced
@@ -372,9 +384,16 @@ __global__ __launch_bounds__(NT) void k_scatter(ck_stage_ws ws) {
 
 int ck_launch_clusters(ck_handle *h, int n) {
     ck_stage_ws &ws = h->ws;
-    CK_HIP(hipMemsetAsync(ws.d_ht_keys, 0, sizeof(unsigned long long) * (size_t)ws.ht_size * n, h->stream));
-    CK_HIP(hipMemsetAsync(ws.d_ht_count, 0, sizeof(uint32_t) * (size_t)ws.ht_size * n, h->stream));
-    CK_HIP(hipMemsetAsync(ws.d_counters, 0, sizeof(uint32_t) * CK_CNT_STRIDE * (size_t)n, h->stream));
+    {   // one launch clears everything the rest of the call counts into: the frames' key / count tables and counters, the fit's
+        // list counts and dequeue heads, the decode candidates' counts (five fills before; their launches were a twentieth of
+        // a one-frame call)
+        const ck_fit_layout fl = ck_fit_scratch_layout(ws, h->cfg.max_batch);
+        const size_t nkeys4 = (size_t)ws.ht_size * n / 2, ncnt4 = (size_t)ws.ht_size * n / 4; // ht_size is a multiple of 1024
+        const size_t total4 = nkeys4 + ncnt4;
+        hipLaunchKernelGGL(k_clear, dim3((unsigned)((total4 + NT - 1) / NT)), dim3(NT), 0, h->stream,
+                           reinterpret_cast<uint4 *>(ws.d_ht_keys), nkeys4, reinterpret_cast<uint4 *>(ws.d_ht_count), ncnt4, ws.d_counters,
+                           (uint32_t)(CK_CNT_STRIDE * n), fl.list_counts, 16u, fl.cand_count, (uint32_t)n);
+    }
     EmitArgs a;
     a.thresh = h->d_thresh; a.labels = h->d_labels; a.csize = h->d_csize;
     a.w = h->qw; a.h = h->qh; a.tiles_x = (h->qw + ETW - 1) / ETW; a.tiles_y = (h->qh + ETH - 1) / ETH;

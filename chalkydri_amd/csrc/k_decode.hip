@@ -317,13 +317,11 @@ int ck_launch_decode(ck_handle *h, const uint8_t *frames, int stride, size_t pit
     a.im = frames; a.w = h->w; a.h = h->h; a.stride = stride; a.pitch = pitch;
     a.sharpening = h->cfg.decode_sharpening; a.max_hamming = h->cfg.max_hamming; a.n_families = h->cfg.n_families;
     a.fams = h->d_fams; a.ws = ws;
-    // candidate buffer lives behind the work lists in the fit scratch
-    const size_t list_bytes = ((size_t)CK_FIT_CLASSES * ws.cluster_cap * h->cfg.max_batch + 16) * sizeof(uint32_t);
-    uint8_t *base = reinterpret_cast<uint8_t *>(ws.d_fit_scratch) + ((list_bytes + 255) / 256) * 256;
+    // candidate buffer lives behind the work lists in the fit scratch; the per-frame counts were zeroed with the cluster tables
+    const ck_fit_layout fl = ck_fit_scratch_layout(ws, h->cfg.max_batch);
     a.cand_cap = ws.quad_cap * h->cfg.n_families;
-    a.cand_count = reinterpret_cast<uint32_t *>(base);
-    a.cands = reinterpret_cast<ck_detection_t *>(base + (((size_t)h->cfg.max_batch * 4 + 255) / 256) * 256);
-    CK_HIP(hipMemsetAsync(a.cand_count, 0, sizeof(uint32_t) * (size_t)n, h->stream));
+    a.cand_count = fl.cand_count;
+    a.cands = fl.cands;
     hipLaunchKernelGGL(k_decode, dim3((unsigned)ws.quad_cap, (unsigned)n), dim3(64), 0, h->stream, a);
     hipLaunchKernelGGL(k_finalize, dim3((unsigned)n), dim3(FNT), sizeof(int) * (size_t)a.cand_cap, h->stream, a);
     CK_HIP(hipGetLastError());

@@ -32,6 +32,7 @@ struct FitArgs {
     double cos_critical, max_mse;
     ck_stage_ws ws;
     int stop_after;         // diagnostics (CK_FIT_STOP_AFTER): end every cluster after phase k; 99 = run everything
+    int list_cap;           // capacity of one class list
     const uint32_t *list;   // work list of this size class: frame << 20 | cluster index
     const uint32_t *list_count;
     uint32_t *head;         // dequeue counter
@@ -582,7 +583,7 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(WPS, 8))) v
     // the small class (520 k clusters per batch through one counter cost more than any phase of the fit), static striding
     // leaves the slowest workgroup ~25 % behind the average (the sum of ~100 clusters' work still varies that much); a
     // chunk keeps the counter traffic at a few thousand adds per launch and the tail at one chunk.
-    const uint32_t n_work = *a.list_count;
+    const uint32_t n_work = min(*a.list_count, (uint32_t)a.list_cap);
     // A short list (one frame per call) is handed out one cluster at a time so that it still spreads over the whole grid.
     constexpr uint32_t DQMAX = CAP <= 512 ? 16u : (CAP <= 2048 ? 4u : 1u);
     const uint32_t per_wg4 = n_work / (gridDim.x * 4u);
@@ -1292,15 +1293,6 @@ __global__ __launch_bounds__(1024) void k_classify(ck_stage_ws ws, int n, uint32
         if (pos < (uint32_t)list_cap) lists[(size_t)k * list_cap + pos] = ((uint32_t)frame << 20) | i;
     }
 }
-__global__ void k_clamp_counts(uint32_t *list_counts, int list_cap, ck_stage_ws ws, int n) {
-    int t = threadIdx.x;
-    if (t < CK_FIT_CLASSES && list_counts[t] > (uint32_t)list_cap) list_counts[t] = (uint32_t)list_cap;
-    for (int f = t; f < n; f += blockDim.x) {
-        uint32_t *c = ws.d_counters + (size_t)f * CK_CNT_STRIDE;
-        if (c[CK_CNT_QUADS] > (uint32_t)ws.quad_cap) c[CK_CNT_QUADS] = (uint32_t)ws.quad_cap;
-    }
-}
-
 } // namespace
 
 #ifdef CK_FIT_PROFILE
@@ -1316,14 +1308,12 @@ int ck_launch_fit_quads(ck_handle *h, const uint8_t *qframes, int qstride, size_
                         size_t pitch, int n) {
     ck_stage_ws &ws = h->ws;
     if (n > 4095 || ws.cluster_cap > (1 << 20)) return CK_EINVAL;
-    // work lists live in the fit scratch: [CK_FIT_CLASSES][list_cap] entries + counts + heads
-    const int list_cap = ws.cluster_cap * h->cfg.max_batch;
-    uint32_t *lists = reinterpret_cast<uint32_t *>(ws.d_fit_scratch);
-    uint32_t *list_counts = lists + (size_t)CK_FIT_CLASSES * list_cap;
-    uint32_t *heads = list_counts + 8;
-    CK_HIP(hipMemsetAsync(list_counts, 0, sizeof(uint32_t) * 16, h->stream));
+    // work lists, their counts and the dequeue heads live in the fit scratch; counts and heads were zeroed with the cluster
+    // tables (k_clusters.hip: k_clear)
+    const ck_fit_layout fl = ck_fit_scratch_layout(ws, h->cfg.max_batch);
+    const int list_cap = fl.list_cap;
+    uint32_t *lists = fl.lists, *list_counts = fl.list_counts, *heads = fl.heads;
     hipLaunchKernelGGL(k_classify, dim3((unsigned)n), dim3(1024), 0, h->stream, ws, n, lists, list_counts, list_cap);
-    hipLaunchKernelGGL(k_clamp_counts, dim3(1), dim3(64), 0, h->stream, list_counts, list_cap, ws, 0);
     FitArgs a;
     a.qim = qframes; a.qw = h->qw; a.qh = h->qh; a.qstride = qstride; a.qpitch = qpitch;
     a.wimg = ws.d_wimg;
@@ -1343,7 +1333,7 @@ int ck_launch_fit_quads(ck_handle *h, const uint8_t *qframes, int qstride, size_
     }
     a.min_tag_width /= h->cfg.quad_decimate;
     if (a.min_tag_width < 3) a.min_tag_width = 3;
-    a.ws = ws;
+    a.ws = ws; a.list_cap = list_cap;
     { const char *e = getenv("CK_FIT_STOP_AFTER"); a.stop_after = e ? atoi(e) : 99; }
     // chunk sizes: 512 points for the multi-wave classes (fewer scans and barriers per point, 9 % less halo work); their LDS
     // then sits at the occupancy steps — 52.9 KB (3 workgroups/CU), 80.5 KB (2/CU), ≈ 124 KB and ≈ 163 KB (1/CU each)
@@ -1376,7 +1366,6 @@ int ck_launch_fit_quads(ck_handle *h, const uint8_t *qframes, int qstride, size_
             CK_HIP(hipEventRecord(h->ev_fit_join[k], h->fit_stream[k]));
             CK_HIP(hipStreamWaitEvent(h->stream, h->ev_fit_join[k], 0));
         }
-    hipLaunchKernelGGL(k_clamp_counts, dim3(1), dim3(64), 0, h->stream, list_counts, list_cap, ws, n);
     CK_HIP(hipGetLastError());
     return CK_OK;
 }
