@@ -71,12 +71,16 @@ static_assert(TW == 128, "label pass splits a node index with >> 7 / & 127");
 // is an ancestor of a, so the forest stays valid (a lost hook is re-issued by its own union).
 // two halving finds walked in lockstep: both chains have a read in flight at every step (the kernel is bound by LDS
 // round-trip latency, not LDS bandwidth)
-__device__ __forceinline__ void lds_find2(volatile uint16_t *p, uint32_t &a, uint32_t &b TCNT_ARG) {
+// (plain loads behind compiler barriers, not volatile ones: a volatile read is waited for before the next is issued, which
+// would put the two chains' reads one after the other)
+__device__ __forceinline__ void lds_find2(uint16_t *p, uint32_t &a, uint32_t &b TCNT_ARG) {
     for (;;) {
         TCNT_INC;
+        __asm__ volatile("" ::: "memory");
         uint32_t na = p[a], nb = p[b];
         bool da = (na == a), db = (nb == b);
         if (da && db) return;
+        __asm__ volatile("" ::: "memory");
         uint32_t ga = p[na], gb = p[nb];
         if (!da) { if (ga != na) p[a] = (uint16_t)ga; a = ga; }
         if (!db) { if (gb != nb) p[b] = (uint16_t)gb; b = gb; }
@@ -413,6 +417,12 @@ __global__ __launch_bounds__(KNT) void k_tile(const uint8_t *__restrict__ frames
         // the one spanning component): their pixels are summed in registers and flushed once per change of root
         uint32_t acc_root = 0xFFFFFFFFu, acc_add = 0;
         bool acc_ring = false;
+#ifdef CK_TILE_PROFILE
+        unsigned long long tq0 = __builtin_readcyclecounter(), tq_ext = 0, tq_walk = 0, tq_tail = 0;
+#define TQ(acc) do { unsigned long long t_ = __builtin_readcyclecounter(); acc += t_ - tq0; tq0 = t_; } while (0)
+#else
+#define TQ(acc)
+#endif
         while (St) { // four runs per round: their root walks proceed in lockstep
             uint32_t node[4], root[4], add[4];
             bool ring[4], live[4];
@@ -432,8 +442,12 @@ __global__ __launch_bounds__(KNT) void k_tile(const uint8_t *__restrict__ frames
                 }
                 root[q] = node[q];
             }
-            const volatile uint16_t *vp = parent;
+            TQ(tq_ext);
+            // plain loads behind a compiler barrier: the four reads of a step are independent and go out together (as volatile
+            // reads each one was waited for before the next was issued: four LDS round trips per step instead of one)
+            const uint16_t *vp = parent;
             for (int it = 0; it < 8192; it++) {
+                __asm__ volatile("" ::: "memory");
                 uint32_t n0 = vp[root[0]], n1 = vp[root[1]], n2 = vp[root[2]], n3 = vp[root[3]];
 #ifdef CK_TILE_PROFILE
                 wit++; whops += (n0 != root[0]) + (n1 != root[1]) + (n2 != root[2]) + (n3 != root[3]);
@@ -441,6 +455,7 @@ __global__ __launch_bounds__(KNT) void k_tile(const uint8_t *__restrict__ frames
                 if (n0 == root[0] && n1 == root[1] && n2 == root[2] && n3 == root[3]) break;
                 root[0] = n0; root[1] = n1; root[2] = n2; root[3] = n3;
             }
+            TQ(tq_walk);
 #pragma unroll
             for (int q = 0; q < 4; q++)
                 if (live[q]) {
@@ -454,8 +469,12 @@ __global__ __launch_bounds__(KNT) void k_tile(const uint8_t *__restrict__ frames
                         acc_root = root[q]; acc_add = add[q]; acc_ring = ring[q];
                     }
                 }
+            TQ(tq_tail);
         }
         if (acc_root != 0xFFFFFFFFu) lds_size_add(size8, acc_root, acc_add, acc_ring);
+#ifdef CK_TILE_PROFILE
+        if (tid == 0) { atomicAdd(&g_tile_prof[14], tq_ext); atomicAdd(&g_tile_prof[15], tq_walk); atomicAdd(&g_tile_prof[7], tq_tail); }
+#endif
     }
     __syncthreads();
     TPROF(4);

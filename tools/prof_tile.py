@@ -23,10 +23,15 @@ import numpy as np
 from chalkydri_amd import synth
 from chalkydri_amd.detector import AprilTagDetector
 w, h, n = 1280, 800, 64
+if len(sys.argv) > 1 and sys.argv[1] == "single":   # one tile alone on the chip: the length of a workgroup's own dependency chain
+    w, h, n = 128, 64, 1
 L = _lib.lib()
 for noise in (3, 1):
-    base = np.stack([synth.render(synth.frame_seed(2, i), w, h, 6, noise_amp=noise)[0] for i in range(16)])
-    frames = np.concatenate([base] * 4)
+    if n == 1:
+        frames = (128 + np.random.default_rng(noise).integers(-noise, noise + 1, (1, h, w))).astype(np.uint8)
+    else:
+        base = np.stack([synth.render(synth.frame_seed(2, i), w, h, 6, noise_amp=noise)[0] for i in range(16)])
+        frames = np.concatenate([base] * 4)
     det = AprilTagDetector(w, h, max_batch=n)
     det.upload(frames)
     buf = (C.c_ulonglong * 16)()
@@ -36,9 +41,10 @@ for noise in (3, 1):
     L.ck_tile_profile_read(buf, 1)
     names = ["P0 load", "P1-2 minmax", "P3 thresh+masks", "P4-5 unions", "P6 flatten+sizes", "P7 labels out", "P8 roots append"]
     tot = sum(buf[k] for k in range(7)) or 1
-    tiles = 130 * n * 5
+    tiles = (130 if n > 1 else 1) * n * 5
     print("noise", noise, "ms/pass", round(ms, 3), "cycles/tile", round(tot / tiles), {names[k]: round(100 * buf[k] / tot, 1) for k in range(7)})
-    wv = 130 * n * 5 * 4   # waves
+    wv = tiles * 4   # waves
     print("   P5b: unions/tile", round(buf[8] / tiles), "find2 iterations/union", round(buf[9] / max(1, buf[8]), 2), "max lane iterations per wave", round(buf[10] / wv, 1))
     print("   P6 : runs/tile", round(buf[11] / tiles), "hops/run", round(buf[12] / max(1, buf[11]), 2), "max lane walk iterations per wave", round(buf[13] / wv, 1))
+    print("   P6 split (cycles of wave 0 per tile): run extraction", round(buf[14] / tiles), "lock-step walk", round(buf[15] / tiles), "stores + size adds", round(buf[7] / tiles))
     det.close()
