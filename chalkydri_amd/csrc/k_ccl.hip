@@ -147,6 +147,7 @@ __device__ __forceinline__ uint32_t msb_nibble(uint32_t v) {
 // Diagnostic build only (-DCK_TILE_PROFILE): per-phase cycle totals of k_tile in a buffer of their own.
 #ifdef CK_TILE_PROFILE
 __device__ unsigned long long g_tile_prof[16];
+__device__ unsigned long long g_tile_prof2[8]; // wave 0's cycles inside the union phase: setup, adoption, barrier, atomic unions, barrier
 #define TPROF_DECL unsigned long long tp0 = __builtin_readcyclecounter()
 #define TPROF(k) do { unsigned long long t_ = __builtin_readcyclecounter(); if (threadIdx.x == 0) atomicAdd(&g_tile_prof[k], t_ - tp0); tp0 = t_; } while (0)
 #else
@@ -349,7 +350,14 @@ __global__ __launch_bounds__(KNT) void k_tile(const uint8_t *__restrict__ frames
     auto up_right_node = [&](int i) -> uint32_t { // bit 0 of the segment on the right always starts a run
         return (i < SEGW - 1) ? base - TW + (uint32_t)run_start(Su, i + 1) : base - TW + SEGW;
     };
+#ifdef CK_TILE_PROFILE
+    unsigned long long tu0 = __builtin_readcyclecounter();
+#define TU(k) do { unsigned long long t_ = __builtin_readcyclecounter(); if (tid == 0) atomicAdd(&g_tile_prof2[k], t_ - tu0); tu0 = t_; } while (0)
+#else
+#define TU(k)
+#endif
     __syncthreads(); // parent[] initialised everywhere before the first adoption lands
+    TU(0);
     if (stop_after == 3) return; // diagnostics (CK_TILE_STOP_AFTER)
     // ---- P5a: every run adopts ONE earlier run as its parent with a plain store.  Only the owner writes the entry
     // and nothing reads parent[] in this phase, so no find and no atomic is needed for these links; the target always
@@ -368,7 +376,9 @@ __global__ __launch_bounds__(KNT) void k_tile(const uint8_t *__restrict__ frames
             else if (i == 0 && hleft) { hleft = false; parent[base] = (uint16_t)left_node; }
         }
     }
+    TU(1);
     __syncthreads();
+    TU(2);
     if (stop_after == 4 || stop_after == 5) return; // diagnostics (CK_TILE_STOP_AFTER)
     // ---- P5b: the remaining links (a run touching a second, third ... earlier run) go through the atomic union
 #ifdef CK_TILE_PROFILE
@@ -396,7 +406,9 @@ __global__ __launch_bounds__(KNT) void k_tile(const uint8_t *__restrict__ frames
         TUN;
         lds_union(parent, base + run_start(S, i), up_right_node(i) TCNT_PASS);
     }
+    TU(3);
     __syncthreads();
+    TU(4);
     TPROF(3);
 #ifdef CK_TILE_PROFILE
     {   // [8] unions, [9] find2 iterations summed over lanes, [10] per-wave maximum of a lane's find2 iterations
@@ -580,6 +592,12 @@ extern "C" int ck_tile_profile_read(unsigned long long *out, int reset) {
     unsigned long long z[16] = {};
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tile_prof), sizeof z) != hipSuccess) return -1;
     if (reset && hipMemcpyToSymbol(HIP_SYMBOL(g_tile_prof), z, sizeof z) != hipSuccess) return -1;
+    return 0;
+}
+extern "C" int ck_tile_profile2_read(unsigned long long *out, int reset) {
+    unsigned long long z[8] = {};
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tile_prof2), sizeof z) != hipSuccess) return -1;
+    if (reset && hipMemcpyToSymbol(HIP_SYMBOL(g_tile_prof2), z, sizeof z) != hipSuccess) return -1;
     return 0;
 }
 namespace {

@@ -35,10 +35,11 @@ for noise in (3, 1):
     det = AprilTagDetector(w, h, max_batch=n)
     det.upload(frames)
     buf = (C.c_ulonglong * 16)()
+    buf2 = (C.c_ulonglong * 8)()
     det.time_threshold_segment(n, 2)
-    L.ck_tile_profile_read(buf, 1)
+    L.ck_tile_profile_read(buf, 1); L.ck_tile_profile2_read(buf2, 1)
     ms = det.time_threshold_segment(n, 4)
-    L.ck_tile_profile_read(buf, 1)
+    L.ck_tile_profile_read(buf, 1); L.ck_tile_profile2_read(buf2, 1)
     names = ["P0 load", "P1-2 minmax", "P3 thresh+masks", "P4-5 unions", "P6 flatten+sizes", "P7 labels out", "P8 roots append"]
     tot = sum(buf[k] for k in range(7)) or 1
     tiles = (130 if n > 1 else 1) * n * 5
@@ -46,5 +47,7 @@ for noise in (3, 1):
     wv = tiles * 4   # waves
     print("   P5b: unions/tile", round(buf[8] / tiles), "find2 iterations/union", round(buf[9] / max(1, buf[8]), 2), "max lane iterations per wave", round(buf[10] / wv, 1))
     print("   P6 : runs/tile", round(buf[11] / tiles), "hops/run", round(buf[12] / max(1, buf[11]), 2), "max lane walk iterations per wave", round(buf[13] / wv, 1))
+    print("   P4-5 split (cycles of wave 0 per tile): init+link masks", round(buf2[0] / tiles), "adoption", round(buf2[1] / tiles), "barrier", round(buf2[2] / tiles),
+          "atomic unions", round(buf2[3] / tiles), "barrier", round(buf2[4] / tiles))
     print("   P6 split (cycles of wave 0 per tile): run extraction", round(buf[14] / tiles), "lock-step walk", round(buf[15] / tiles), "stores + size adds", round(buf[7] / tiles))
     det.close()
