@@ -387,24 +387,16 @@ __global__ __launch_bounds__(KNT) void k_tile(const uint8_t *__restrict__ frames
 #else
 #define TUN
 #endif
-    if (hleft) { TUN; lds_union(parent, base, left_node TCNT_PASS); }
-    while (Ev) {
+    // One loop over all of a lane's remaining links, whatever their kind: the wave then runs max-over-lanes(links) union slots
+    // instead of max(vertical) + max(left diagonals) + max(right diagonals) + 1, and every slot costs the deepest find in the wave
+    while (hleft || Ev || DL || DR) {
+        uint32_t ua, ub;
+        if (hleft) { hleft = false; ua = base; ub = left_node; }
+        else if (Ev) { int i = mctz(Ev); Ev &= Ev - 1; ua = base + run_start(S, i); ub = base - TW + run_start(Su, i); }
+        else if (DL) { int i = mctz(DL); DL &= DL - 1; ua = base + run_start(S, i); ub = up_left_node(i); }
+        else { int i = mctz(DR); DR &= DR - 1; ua = base + run_start(S, i); ub = up_right_node(i); }
         TUN;
-        int i = mctz(Ev);
-        Ev &= Ev - 1;
-        lds_union(parent, base + run_start(S, i), base - TW + run_start(Su, i) TCNT_PASS);
-    }
-    while (DL) {
-        int i = mctz(DL);
-        DL &= DL - 1;
-        TUN;
-        lds_union(parent, base + run_start(S, i), up_left_node(i) TCNT_PASS);
-    }
-    while (DR) {
-        int i = mctz(DR);
-        DR &= DR - 1;
-        TUN;
-        lds_union(parent, base + run_start(S, i), up_right_node(i) TCNT_PASS);
+        lds_union(parent, ua, ub TCNT_PASS);
     }
     TU(3);
     __syncthreads();
