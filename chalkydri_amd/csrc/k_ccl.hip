@@ -296,7 +296,7 @@ __global__ __launch_bounds__(KNT) void k_tile(const uint8_t *__restrict__ frames
         const uint32_t lo = (uint32_t)i | ((uint32_t)(i + 1) << 16);
         *reinterpret_cast<uint4 *>(&parent[i]) = make_uint4(lo, lo + 0x00020002u, lo + 0x00040004u, lo + 0x00060006u);
     }
-    for (int i = tid * 16; i < TH * TW; i += KNT * 16) *reinterpret_cast<uint4 *>(size8 + i) = make_uint4(0, 0, 0, 0);
+    // (the size bytes are zeroed after P5b: until then their 8 KB hold the waves' link pools)
 
     // ---- P5: unions.  thread = (colour, row, segment) --------------------------------------------------------------
     const mask_t *masks = reinterpret_cast<const mask_t *>(lds + OFF_MASK);
@@ -387,20 +387,48 @@ __global__ __launch_bounds__(KNT) void k_tile(const uint8_t *__restrict__ frames
 #else
 #define TUN
 #endif
-    // One loop over all of a lane's remaining links, whatever their kind: the wave then runs max-over-lanes(links) union slots
-    // instead of max(vertical) + max(left diagonals) + max(right diagonals) + 1, and every slot costs the deepest find in the wave
-    while (hleft || Ev || DL || DR) {
-        uint32_t ua, ub;
-        if (hleft) { hleft = false; ua = base; ub = left_node; }
-        else if (Ev) { int i = mctz(Ev); Ev &= Ev - 1; ua = base + run_start(S, i); ub = base - TW + run_start(Su, i); }
-        else if (DL) { int i = mctz(DL); DL &= DL - 1; ua = base + run_start(S, i); ub = up_left_node(i); }
-        else { int i = mctz(DR); DR &= DR - 1; ua = base + run_start(S, i); ub = up_right_node(i); }
-        TUN;
-        lds_union(parent, ua, ub TCNT_PASS);
+    // The links of a wave are pooled and dealt out evenly: a lane with eight links no longer holds 63 others up — the wave runs
+    // ceil(links / 64) union slots (3-4 in a noisy tile) instead of max-over-lanes(links) (7-8), and every slot costs the deepest
+    // find in the wave.  The pool is the wave's quarter of the (not yet used) size array: POOL links of two u16 nodes; links
+    // that do not fit stay with their lane and are joined the old way.
+    {
+        constexpr int POOL = TH * TW / (KNT / 64) / 4; // u32 entries per wave
+        uint32_t *pool = reinterpret_cast<uint32_t *>(size8) + (tid >> 6) * POOL;
+        const uint32_t mine = (hleft ? 1u : 0u) + (uint32_t)mpopc(Ev) + (uint32_t)mpopc(DL) + (uint32_t)mpopc(DR);
+        const uint32_t incl = wave_scan_u32(mine);
+        const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        uint32_t pos = incl - mine;
+        while ((hleft || Ev || DL || DR) && pos < (uint32_t)POOL) {
+            uint32_t ua, ub;
+            if (hleft) { hleft = false; ua = base; ub = left_node; }
+            else if (Ev) { int i = mctz(Ev); Ev &= Ev - 1; ua = base + run_start(S, i); ub = base - TW + run_start(Su, i); }
+            else if (DL) { int i = mctz(DL); DL &= DL - 1; ua = base + run_start(S, i); ub = up_left_node(i); }
+            else { int i = mctz(DR); DR &= DR - 1; ua = base + run_start(S, i); ub = up_right_node(i); }
+            pool[pos++] = ua | (ub << 16);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const uint32_t pooled = total < (uint32_t)POOL ? total : (uint32_t)POOL;
+        for (uint32_t j = (uint32_t)(tid & 63); j < pooled; j += 64) {
+            const uint32_t e = pool[j];
+            TUN;
+            lds_union(parent, e & 0xFFFFu, e >> 16 TCNT_PASS);
+        }
+        while (hleft || Ev || DL || DR) { // overflow of the pool (pathological tiles only)
+            uint32_t ua, ub;
+            if (hleft) { hleft = false; ua = base; ub = left_node; }
+            else if (Ev) { int i = mctz(Ev); Ev &= Ev - 1; ua = base + run_start(S, i); ub = base - TW + run_start(Su, i); }
+            else if (DL) { int i = mctz(DL); DL &= DL - 1; ua = base + run_start(S, i); ub = up_left_node(i); }
+            else { int i = mctz(DR); DR &= DR - 1; ua = base + run_start(S, i); ub = up_right_node(i); }
+            TUN;
+            lds_union(parent, ua, ub TCNT_PASS);
+        }
     }
     TU(3);
     __syncthreads();
     TU(4);
+    for (int i = tid * 16; i < TH * TW; i += KNT * 16) *reinterpret_cast<uint4 *>(size8 + i) = make_uint4(0, 0, 0, 0); // pools -> sizes
     TPROF(3);
 #ifdef CK_TILE_PROFILE
     {   // [8] unions, [9] find2 iterations summed over lanes, [10] per-wave maximum of a lane's find2 iterations
