@@ -9,7 +9,8 @@ import os
 from . import _abi as A
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libchalkydri_hip.so")
+# CHALKYDRI_HIP_LIB selects another build of the library (same-box A/B measurements, out-of-tree installs)
+LIB_PATH = os.environ.get("CHALKYDRI_HIP_LIB") or os.path.join(_HERE, "lib", "libchalkydri_hip.so")
 _lib = None
 
 
