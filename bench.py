@@ -34,7 +34,7 @@ def cpu_baseline(frames, gyro, task, cfg, seconds_hint=1.5):
     from chalkydri_amd import _abi as A
     L = pyoracle.lib()
     h, w = frames.shape[1:]
-    cores = max(1, min(16, os.cpu_count() or 1))
+    cores = max(1, os.cpu_count() or 1)      # T = hardware concurrency; 16 threads reported beside it
 
     def one(i):
         out = A.VisionMeasurement()
@@ -57,17 +57,44 @@ def cpu_baseline(frames, gyro, task, cfg, seconds_hint=1.5):
                 break
     except OSError:
         pass
-    n = int(max(cores, seconds_hint * cores / max(per, 1e-3)))  # ~seconds_hint of wall time = cores * seconds_hint of CPU work
-    n = max(cores, (n // cores) * cores)
-    idx = [i % len(frames) for i in range(n)]
-    t0 = time.perf_counter()
-    with ThreadPoolExecutor(cores) as ex:
-        valid = list(ex.map(one, idx))
-    dt = time.perf_counter() - t0
-    return {"value": round(n / dt, 2), "unit": "frames/s", "cores": cores, "kind": "port",
-            "single_thread_value": round(1.0 / per, 2), "nproc": os.cpu_count(), "cpu_model": model,
-            "sample": f"{n} frames of the same {w}x{h} workload through oracle/ (C restatement of the path; the reference's Rust path "
-                      f"cannot be built here), detect+pose, {cores} threads, {sum(valid)} valid poses, {dt:.1f} s"}
+    def timed(threads):
+        n = int(max(threads, seconds_hint * threads / max(per, 1e-3)))  # ~seconds_hint of wall time = threads * seconds_hint of CPU work
+        n = max(threads, (n // threads) * threads)
+        idx = [i % len(frames) for i in range(n)]
+        t0 = time.perf_counter()
+        with ThreadPoolExecutor(threads) as ex:
+            valid = list(ex.map(one, idx))
+        return n, time.perf_counter() - t0, sum(valid)
+
+    n, dt, nvalid = timed(cores)
+    out = {"value": round(n / dt, 2), "unit": "frames/s", "cores": cores, "kind": "port",
+           "single_thread_value": round(1.0 / per, 2), "nproc": os.cpu_count(), "cpu_model": model,
+           "sample": f"{n} frames of the same {w}x{h} workload through oracle/ (C restatement of the path; the reference's Rust path "
+                     f"cannot be built here), detect+pose, {cores} threads, {nvalid} valid poses, {dt:.1f} s"}
+    if cores > 16:
+        n16, dt16, _ = timed(16)
+        out["value_16_threads"] = round(n16 / dt16, 2)
+    return out
+
+
+def self_launch(n_gpus):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as a CHILD torch.distributed.run (one process per GPU,
+    RCCL over xGMI) before this process touches the GPU, and hand back its exit code.  Never an exec: a process that has
+    initialised the GPU must not be replaced (and this one has not initialised it: device_count() does not)."""
+    import socket
+    import subprocess
+    import torch
+    have = torch.cuda.device_count()
+    if have < n_gpus:
+        print(f"bench.py: --gpus {n_gpus} but only {have} HIP device(s) are visible", file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -86,14 +113,19 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the two extra measurements reported under \"also\"")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args.gpus))
+
     import torch
     import torch.distributed as tdist
     from chalkydri_amd import default_config, dist, scenes
     from chalkydri_amd.apriltags import AprilTags
 
     rank, local_rank, world = dist.env_rank()
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if torch.cuda.device_count() < world:
+        raise SystemExit(f"--gpus {args.gpus} but only {torch.cuda.device_count()} HIP device(s) are visible")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the product path has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -112,13 +144,35 @@ def main():
     d_valid = torch.zeros(n, dtype=torch.int32, device=dev)
     gathered = None
     thr_ms = []
+    # The one collective of the path: the C ABI's ck_gather_poses (ncclAllGather of n x 64 bytes on the handle's stream).  If
+    # its communicator cannot be made on some rank, EVERY rank uses the Python mirror's torch.distributed all_gather instead
+    # (same bytes, same layout) and the JSON line says which one ran.
+    comm, gather_kind = None, "none (1 GPU)"
+    if world > 1:
+        try:
+            comm = dist.PoseComm(task.detector, rank, world, dev)
+        except Exception as e:  # noqa: BLE001
+            print(f"[rank {rank}] ck_comm_create failed ({e}); falling back to torch.distributed", file=sys.stderr)
+        ok = torch.tensor([1 if comm is not None else 0], dtype=torch.int32, device=dev)
+        tdist.all_reduce(ok, op=tdist.ReduceOp.MIN)
+        if not int(ok.item()):
+            if comm is not None:
+                comm.close()
+            comm = None
+        gather_kind = "ck_gather_poses: RCCL ncclAllGather of 64-byte records (C ABI)" if comm is not None else \
+            "torch.distributed all_gather_into_tensor of 64-byte records (RCCL; C-ABI communicator unavailable)"
+        d_all = torch.zeros((world * n, 64), dtype=torch.uint8, device=dev)
 
     def step(record=False):
         nonlocal gathered
         task.process_uploaded_into(n, d_gyro.data_ptr(), d_has.data_ptr(), d_rec.data_ptr(), d_valid.data_ptr())
         if record:
             thr_ms.append(task.detector.stage_ms()["threshold"])
-        gathered = dist.gather_records(d_rec, world)   # the one collective of the path (RCCL over xGMI)
+        if comm is not None:
+            comm.gather(n, out_ptr=d_all.data_ptr(), sync=False)
+            gathered = d_all
+        else:
+            gathered = dist.gather_records(d_rec, world)
 
     for _ in range(args.warmup):
         step()
@@ -128,6 +182,8 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step(record=True)
+    if comm is not None:
+        comm.sync()                                    # the handle's stream is not torch's current stream
     torch.cuda.synchronize()
     if world > 1:
         tdist.barrier()
@@ -155,11 +211,15 @@ def main():
         torch.cuda.synchronize()
         copy_gbps = 5 * 2 * (1 << 30) / (e0.elapsed_time(e1) * 1e-3) / 1e9
         del src, dst
-        traffic = None
+        # HBM bytes per launch come from rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE in separate runs of this same command:
+        # tools/collect_profiles.sh), which cannot run inside this process; the file names the round and commit it was taken at
+        traffic, traffic_src = None, None
         tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+                tj = json.load(open(tpath))
+                traffic = tj.get("hbm_bytes_per_launch")
+                traffic_src = {k: tj.get(k) for k in ("round", "commit", "note") if tj.get(k) is not None}
             except Exception:
                 traffic = None
         out = {
@@ -169,9 +229,9 @@ def main():
             "dtype": "u8 (threshold/segment/clusters: integer; quad fit/decode/SQPnP: f64)", "data": "synthetic",
             "config": {"workload": f"{w}x{h} mono8 batch={n}/GPU, tag36h11, {args.tags} field tags/frame (3-D scenes), background ramp+-24 "
                                    f"noise+-{args.noise}, quad_decimate={args.decimate}, detect+pose, one stream per GPU",
-                       "frames_with_pose": round(valid_frac, 4), "post_segment_streams": int(os.environ.get("CK_STREAMS", "1")), "gather": "RCCL all_gather of 64-byte records" if world > 1 else "none (1 GPU)"},
+                       "frames_with_pose": round(valid_frac, 4), "post_segment_streams": int(os.environ.get("CK_STREAMS", "1")), "gather": gather_kind},
             "roofline": {"bound": "hbm", "kernel": "threshold+segment (k_tile + k_merge + k_roots)", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "measured_copy_GBps": round(copy_gbps, 1),
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_src, "measured_copy_GBps": round(copy_gbps, 1),
                          "algorithmic_bytes_per_launch": ALG_BYTES_PER_PX * w * h * n, "avg_launch_ms": round(ms_thr, 4),
                          "launch_ms_p10_median_p90": [round(float(np.percentile(thr_ms, q)), 4) for q in (10, 50, 90)]},
             "stage_ms_last_step": {k: round(v, 3) for k, v in stage.items()},
@@ -209,6 +269,8 @@ def main():
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))
+    if comm is not None:
+        comm.close()
     if world > 1:
         tdist.barrier()
         tdist.destroy_process_group()

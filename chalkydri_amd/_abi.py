@@ -15,7 +15,8 @@ class Family(C.Structure):
     _fields_ = [("name", C.c_char * 32), ("nbits", C.c_uint32), ("ncodes", C.c_uint32),
                 ("codes", C.POINTER(C.c_uint64)), ("bit_x", C.POINTER(C.c_uint32)),
                 ("bit_y", C.POINTER(C.c_uint32)), ("width_at_border", C.c_int32),
-                ("total_width", C.c_int32), ("reversed_border", C.c_int32), ("min_hamming", C.c_uint32)]
+                ("total_width", C.c_int32), ("reversed_border", C.c_int32), ("min_hamming", C.c_uint32),
+                ("n_upstream", C.c_uint32)]
 
 
 class Config(C.Structure):
@@ -87,7 +88,7 @@ class FieldTag(C.Structure):
 class ProcessParams(C.Structure):
     _fields_ = [("cam", OpenCV5), ("robot_to_cam", Iso3), ("field", C.POINTER(FieldTag)),
                 ("n_field", C.c_int32), ("camera_id", C.c_uint8), ("sign_change_error", C.c_double),
-                ("sqpnp", SqpnpParams)]
+                ("sqpnp", SqpnpParams), ("allow_unverified_ids", C.c_int32)]
 
 
 class SynthTag(C.Structure):
@@ -105,3 +106,4 @@ assert C.sizeof(VisionMeasurement) == 64  # crates/whacknet/src/lib.rs:92-95
 
 # per-frame status bits (include/chalkydri_hip.h)
 CK_FRAME_OK, CK_FRAME_POINTS_OVERFLOW, CK_FRAME_CLUSTERS_OVERFLOW, CK_FRAME_QUADS_OVERFLOW, CK_FRAME_DETS_OVERFLOW = 0, 1, 2, 4, 8
+CK_FRAME_UNVERIFIED_ID = 16

@@ -172,8 +172,8 @@ extern "C" int ck_segment_batch(ck_handle_t *h, const ck_image_u8_t *imgs, int32
     if (rc != CK_OK) return rc;
     size_t total = h->npix * (size_t)n;
     uint32_t *d_canon = nullptr, *d_sizes = nullptr;
-    CK_HIP(hipMalloc(&d_canon, total * sizeof(uint32_t)));
-    if (sizes_out) CK_HIP(hipMalloc(&d_sizes, total * sizeof(uint32_t)));
+    if (hipMalloc(&d_canon, total * sizeof(uint32_t)) != hipSuccess) return CK_ENOMEM;
+    if (sizes_out && hipMalloc(&d_sizes, total * sizeof(uint32_t)) != hipSuccess) { (void)hipFree(d_canon); return CK_ENOMEM; }
     rc = ck_launch_canonical_labels(h, n, d_canon, d_sizes);
     if (rc == CK_OK) {
         hipError_t e = hipMemcpyAsync(labels_out, d_canon, total * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream);
@@ -226,14 +226,20 @@ __global__ void k_fp64_probe(int op, const double *a, const double *b, int n, do
 extern "C" int ck_selftest_fp64(ck_handle_t *h, int32_t op, const double *a, const double *b, int32_t n, double *out) {
     if (!h || !a || !out || n < 0) return CK_EINVAL;
     CK_HIP(hipSetDevice(h->device));
+    if (n == 0) return CK_OK;
     double *da = nullptr, *db = nullptr, *dout = nullptr;
-    CK_HIP(hipMalloc(&da, sizeof(double) * (size_t)n));
-    CK_HIP(hipMalloc(&dout, sizeof(double) * (size_t)n));
-    CK_HIP(hipMemcpy(da, a, sizeof(double) * (size_t)n, hipMemcpyHostToDevice));
-    if (b) { CK_HIP(hipMalloc(&db, sizeof(double) * (size_t)n)); CK_HIP(hipMemcpy(db, b, sizeof(double) * (size_t)n, hipMemcpyHostToDevice)); }
-    hipLaunchKernelGGL(k_fp64_probe, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, op, da, db, n, dout);
-    CK_HIP(hipStreamSynchronize(h->stream));
-    CK_HIP(hipMemcpy(out, dout, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost));
-    (void)hipFree(da); (void)hipFree(db); (void)hipFree(dout);
+    const size_t bytes = sizeof(double) * (size_t)n;
+    hipError_t e = hipMalloc(&da, bytes);
+    if (e == hipSuccess) e = hipMalloc(&dout, bytes);
+    if (e == hipSuccess && b) e = hipMalloc(&db, bytes);
+    if (e == hipSuccess) e = hipMemcpy(da, a, bytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess && b) e = hipMemcpy(db, b, bytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_fp64_probe, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, op, da, db, n, dout);
+        e = hipStreamSynchronize(h->stream);
+    }
+    if (e == hipSuccess) e = hipMemcpy(out, dout, bytes, hipMemcpyDeviceToHost);
+    (void)hipFree(da); (void)hipFree(db); (void)hipFree(dout); // one exit: nothing leaks on an error path
+    if (e != hipSuccess) { snprintf(ck_err_text, sizeof ck_err_text, "fp64 probe failed: %s", hipGetErrorString(e)); return CK_EDEVICE; }
     return CK_OK;
 }

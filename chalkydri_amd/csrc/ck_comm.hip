@@ -1,0 +1,146 @@
+// ck_comm.hip — the one collective of the path, owned by the C ABI: an RCCL all-gather of the 64-byte pose records.
+//
+// Frames shard over GPUs with no data-path collective (one camera stream, or one contiguous frame block, per GPU;
+// DESIGN.md §6).  What the reference sends per frame is one VisionMeasurement datagram (crates/whacknet/src/lib.rs:43-66,
+// 152-171); with N GPUs the records of a batch meet on every rank through ONE ncclAllGather of n x 64 bytes, issued on the
+// handle's stream straight from the device buffer the pose stage filled.  At 16 KiB per GPU the collective is latency-bound
+// on xGMI: no bucketing, no ring tuning.
+//
+// librccl is opened on first use (dlopen), so hosts that never gather — and this container, which has no GPU — load the
+// library without it.  A process that already holds an RCCL (PyTorch-ROCm ships one under the same soname) shares it.
+#include <dlfcn.h>
+#include <string.h>
+
+#include <new>
+
+#include "ck_internal.h"
+
+namespace {
+
+// the handful of RCCL declarations used here (rccl.h: ncclUniqueId is 128 opaque bytes; ncclChar = 0 in ncclDataType_t)
+struct rccl_unique_id { char internal[CK_COMM_ID_BYTES]; };
+typedef void *rccl_comm_t;
+typedef int (*fn_get_unique_id)(rccl_unique_id *);
+typedef int (*fn_comm_init_rank)(rccl_comm_t *, int, rccl_unique_id, int);
+typedef int (*fn_comm_destroy)(rccl_comm_t);
+typedef int (*fn_all_gather)(const void *, void *, size_t, int, rccl_comm_t, hipStream_t);
+typedef const char *(*fn_error_string)(int);
+
+struct rccl_api {
+    void *so = nullptr;
+    fn_get_unique_id get_unique_id = nullptr;
+    fn_comm_init_rank comm_init_rank = nullptr;
+    fn_comm_destroy comm_destroy = nullptr;
+    fn_all_gather all_gather = nullptr;
+    fn_error_string error_string = nullptr;
+};
+
+rccl_api *rccl() {
+    static rccl_api api;
+    static bool tried = false;
+    if (tried) return api.so ? &api : nullptr;
+    tried = true;
+    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char *nm : names) {
+        api.so = dlopen(nm, RTLD_NOW | RTLD_LOCAL);
+        if (api.so) break;
+    }
+    if (!api.so) {
+        snprintf(ck_err_text, sizeof ck_err_text, "librccl could not be loaded: %s", dlerror());
+        return nullptr;
+    }
+    api.get_unique_id = (fn_get_unique_id)dlsym(api.so, "ncclGetUniqueId");
+    api.comm_init_rank = (fn_comm_init_rank)dlsym(api.so, "ncclCommInitRank");
+    api.comm_destroy = (fn_comm_destroy)dlsym(api.so, "ncclCommDestroy");
+    api.all_gather = (fn_all_gather)dlsym(api.so, "ncclAllGather");
+    api.error_string = (fn_error_string)dlsym(api.so, "ncclGetErrorString");
+    if (!api.get_unique_id || !api.comm_init_rank || !api.comm_destroy || !api.all_gather) {
+        snprintf(ck_err_text, sizeof ck_err_text, "librccl lacks ncclGetUniqueId/ncclCommInitRank/ncclCommDestroy/ncclAllGather");
+        dlclose(api.so);
+        api.so = nullptr;
+        return nullptr;
+    }
+    return &api;
+}
+
+int rccl_fail(rccl_api *r, const char *what, int rc) {
+    snprintf(ck_err_text, sizeof ck_err_text, "%s failed: %s (%d)", what, r->error_string ? r->error_string(rc) : "rccl error", rc);
+    return CK_EDEVICE;
+}
+
+} // namespace
+
+struct ck_comm {
+    rccl_comm_t comm;
+    ck_handle *h;
+    int world, rank;
+    ck_vision_measurement_t *d_all; // [world][max_batch] records, device
+    size_t cap_records;
+};
+
+extern "C" int ck_backend(const ck_handle_t *h) { return h ? CK_BACKEND_HIP : CK_EINVAL; }
+
+extern "C" int ck_comm_unique_id(uint8_t *id_out) {
+    if (!id_out) return CK_EINVAL;
+    rccl_api *r = rccl();
+    if (!r) return CK_EUNSUPPORTED;
+    rccl_unique_id id;
+    int rc = r->get_unique_id(&id);
+    if (rc != 0) return rccl_fail(r, "ncclGetUniqueId", rc);
+    memcpy(id_out, id.internal, CK_COMM_ID_BYTES);
+    return CK_OK;
+}
+
+extern "C" int ck_comm_create(ck_handle_t *h, const uint8_t *id_in, int32_t world, int32_t rank, ck_comm_t **out) {
+    if (!h || !id_in || !out || world < 1 || rank < 0 || rank >= world) return CK_EINVAL;
+    *out = nullptr;
+    rccl_api *r = rccl();
+    if (!r) return CK_EUNSUPPORTED;
+    CK_HIP(hipSetDevice(h->device));
+    ck_comm *c = new (std::nothrow) ck_comm();
+    if (!c) return CK_ENOMEM;
+    c->h = h; c->world = world; c->rank = rank;
+    c->cap_records = (size_t)world * (size_t)h->cfg.max_batch;
+    if (hipMalloc(&c->d_all, sizeof(ck_vision_measurement_t) * c->cap_records) != hipSuccess) { delete c; return CK_ENOMEM; }
+    rccl_unique_id id;
+    memcpy(id.internal, id_in, CK_COMM_ID_BYTES);
+    int rc = r->comm_init_rank(&c->comm, world, id, rank);
+    if (rc != 0) { (void)hipFree(c->d_all); delete c; return rccl_fail(r, "ncclCommInitRank", rc); }
+    *out = c;
+    return CK_OK;
+}
+
+extern "C" void ck_comm_destroy(ck_comm_t *c) {
+    if (!c) return;
+    rccl_api *r = rccl();
+    (void)hipSetDevice(c->h->device);
+    (void)hipStreamSynchronize(c->h->stream);
+    if (r) (void)r->comm_destroy(c->comm);
+    (void)hipFree(c->d_all);
+    delete c;
+}
+
+// All-gather of the n records the last ck_process_* call of this handle left on the device (ws.d_meas), in rank order.
+// `out` may be a host or a device pointer to world*n records; with sync == 0 and a device pointer the call only enqueues
+// (the caller's next operation on the handle's stream, or ck_comm_sync, orders after it).
+extern "C" int ck_gather_poses(ck_handle_t *h, ck_comm_t *c, int32_t n, ck_vision_measurement_t *out, int32_t sync) {
+    if (!h || !c || c->h != h || !out || n < 0) return CK_EINVAL;
+    if (n > h->cfg.max_batch) return CK_ECAPACITY;
+    if (n == 0) return CK_OK;
+    rccl_api *r = rccl();
+    if (!r) return CK_EUNSUPPORTED;
+    CK_HIP(hipSetDevice(h->device));
+    const size_t bytes = sizeof(ck_vision_measurement_t) * (size_t)n;
+    int rc = r->all_gather(h->ws.d_meas, c->d_all, bytes, /*ncclChar*/ 0, c->comm, h->stream);
+    if (rc != 0) return rccl_fail(r, "ncclAllGather", rc);
+    CK_HIP(hipMemcpyAsync(out, c->d_all, bytes * (size_t)c->world, hipMemcpyDefault, h->stream));
+    if (sync) CK_HIP(hipStreamSynchronize(h->stream));
+    return CK_OK;
+}
+
+extern "C" int ck_comm_sync(ck_comm_t *c) {
+    if (!c) return CK_EINVAL;
+    CK_HIP(hipSetDevice(c->h->device));
+    CK_HIP(hipStreamSynchronize(c->h->stream));
+    return CK_OK;
+}

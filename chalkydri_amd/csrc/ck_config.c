@@ -18,7 +18,11 @@ const char *ck_strerror(int code) {
 }
 
 // Defaults = what the reference gets from DetectorBuilder::default() + add_family_bits(tag36h11, 3)
-// (crates/apriltags/src/lib.rs:45,228-233,258-262) with AprilTag-3's stock parameters.
+// (crates/apriltags/src/lib.rs:45,228-233,258-262) with AprilTag-3's stock parameters, with ONE
+// deliberate difference: quad_decimate is 1 here, 2.0 upstream.  The roofline contract of the threshold+segment stage is
+// quoted at full resolution ("f = 1 for the headline"), and bench.py / the parity tests run there; a caller
+// that wants the reference's exact front end sets cfg.quad_decimate = 2 (bench.py reports that run under "also",
+// tests/test_gpu_detect.py::test_detect_matches_oracle_at_the_default_decimation covers it).  DESIGN.md §2 lists it.
 void ck_config_default(ck_config_t *cfg, int32_t width, int32_t height, int32_t max_batch) {
     memset(cfg, 0, sizeof *cfg);
     cfg->width = width; cfg->height = height; cfg->max_batch = max_batch > 0 ? max_batch : 1;

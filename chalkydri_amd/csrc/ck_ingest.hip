@@ -91,19 +91,23 @@ extern "C" int ck_ingest_submit(ck_ingest_t *g, int32_t slot, int32_t n) {
     return CK_OK;
 }
 
-extern "C" int ck_detect_ingested(ck_ingest_t *g, int32_t slot, ck_detection_t *dets, int32_t cap, int32_t *counts, uint32_t *status) {
-    if (!g || slot < 0 || slot >= g->nslots) return CK_EINVAL;
+// `n` is the caller's statement of how many frames its output arrays hold: it must be the count the slot was submitted with
+// (the kernels write one entry per staged frame).
+extern "C" int ck_detect_ingested(ck_ingest_t *g, int32_t slot, int32_t n, ck_detection_t *dets, int32_t cap, int32_t *counts, uint32_t *status) {
+    if (!g || slot < 0 || slot >= g->nslots || n != g->staged[slot]) return CK_EINVAL;
+    if (n == 0) return CK_OK;
     ck_handle *h = g->h;
     CK_HIP(hipSetDevice(h->device));
     CK_HIP(hipStreamWaitEvent(h->stream, g->ready[slot], 0));
-    return ck_detect_frames(h, g->dev[slot], h->frame_stride, h->frame_pitch, g->staged[slot], dets, cap, counts, status);
+    return ck_detect_frames(h, g->dev[slot], h->frame_stride, h->frame_pitch, n, dets, cap, counts, status);
 }
 
-extern "C" int ck_process_ingested(ck_ingest_t *g, int32_t slot, const ck_process_params_t *pp, const double *gyro, const uint8_t *has_gyro,
-                                   ck_vision_measurement_t *out, int32_t *valid) {
-    if (!g || slot < 0 || slot >= g->nslots) return CK_EINVAL;
+extern "C" int ck_process_ingested(ck_ingest_t *g, int32_t slot, int32_t n, const ck_process_params_t *pp, const double *gyro,
+                                   const uint8_t *has_gyro, ck_vision_measurement_t *out, int32_t *valid) {
+    if (!g || slot < 0 || slot >= g->nslots || n != g->staged[slot]) return CK_EINVAL;
+    if (n == 0) return CK_OK;
     ck_handle *h = g->h;
     CK_HIP(hipSetDevice(h->device));
     CK_HIP(hipStreamWaitEvent(h->stream, g->ready[slot], 0));
-    return ck_process_frames(h, g->dev[slot], h->frame_stride, h->frame_pitch, g->staged[slot], pp, gyro, has_gyro, out, valid);
+    return ck_process_frames(h, g->dev[slot], h->frame_stride, h->frame_pitch, n, pp, gyro, has_gyro, out, valid);
 }

@@ -30,7 +30,7 @@ struct ck_border_root {
 };
 
 struct ck_dev_family {
-    uint32_t nbits, ncodes;
+    uint32_t nbits, ncodes, n_upstream;
     int32_t width_at_border, total_width, reversed_border;
     const uint64_t *codes; // device
     uint32_t bit_x[64], bit_y[64];

@@ -17,6 +17,8 @@ int ck_stage_alloc(ck_handle *h) {
     if (ws.cluster_cap < 1024) ws.cluster_cap = 1024;
     if (ws.cluster_cap > (1 << 19)) ws.cluster_cap = 1 << 19; // keeps the hash table (2x) at most 2^20 slots per frame
     ws.quad_cap = cfg.max_quads_per_frame > 0 ? cfg.max_quads_per_frame : 1024;
+    // k_finalize ranks a frame's decode candidates (quad_cap per family) in LDS, 4 bytes each: refuse what would not launch
+    if ((size_t)ws.quad_cap * (size_t)cfg.n_families * sizeof(int) > 64 * 1024) return CK_EINVAL;
     ws.det_cap = 256;
     ws.ht_size = next_pow2(2 * ws.cluster_cap);
     if (ws.ht_size < 1024) ws.ht_size = 1024;
@@ -58,7 +60,7 @@ int ck_stage_alloc(ck_handle *h) {
         const ck_family_t *src = cfg.families[f];
         ck_dev_family &d = fams[(size_t)f];
         memset(&d, 0, sizeof d);
-        d.nbits = src->nbits; d.ncodes = src->ncodes; d.width_at_border = src->width_at_border;
+        d.nbits = src->nbits; d.ncodes = src->ncodes; d.n_upstream = src->n_upstream; d.width_at_border = src->width_at_border;
         d.total_width = src->total_width; d.reversed_border = src->reversed_border;
         for (uint32_t i = 0; i < src->nbits; i++) { d.bit_x[i] = src->bit_x[i]; d.bit_y[i] = src->bit_y[i]; }
         uint64_t *dc = nullptr;
@@ -257,6 +259,7 @@ extern "C" int ck_detect_batch_device(ck_handle_t *h, const uint8_t *d_frames, i
 int ck_detect_frames(ck_handle *h, const uint8_t *frames, int stride, size_t pitch, int n, ck_detection_t *dets, int cap, int32_t *counts,
                      uint32_t *status) {
     if (!h || !dets || !counts || cap < 1 || n < 0 || n > h->cfg.max_batch) return CK_EINVAL;
+    if (n == 0) return CK_OK;
     CK_HIP(hipEventRecord(h->ev[0], h->stream));
     ck_split sp;
     int rc = run_pipeline(h, frames, stride, pitch, n, 3, &sp);
@@ -267,7 +270,8 @@ int ck_detect_frames(ck_handle *h, const uint8_t *frames, int stride, size_t pit
 
 extern "C" int ck_clusters_batch(ck_handle_t *h, const ck_image_u8_t *imgs, int32_t n, ck_cluster_t *clusters, int32_t cluster_cap,
                                  int32_t *n_clusters, ck_cluster_point_t *points, int32_t point_cap, int32_t *n_points) {
-    if (!h || !clusters || !n_clusters || !points || !n_points) return CK_EINVAL;
+    if (!h || !clusters || !n_clusters || !points || !n_points || n < 0 || cluster_cap < 0 || point_cap < 0) return CK_EINVAL;
+    if (n == 0) return CK_OK;
     CK_HIP(hipSetDevice(h->device));
     int rc = imgs ? ck_upload_frames(h, imgs, n) : (n <= h->n_staged ? CK_OK : CK_EINVAL);
     if (rc != CK_OK) return rc;
@@ -290,7 +294,8 @@ extern "C" int ck_clusters_batch(ck_handle_t *h, const ck_image_u8_t *imgs, int3
 }
 
 extern "C" int ck_quads_batch(ck_handle_t *h, const ck_image_u8_t *imgs, int32_t n, ck_quad_t *quads, int32_t quad_cap, int32_t *n_quads) {
-    if (!h || !quads || !n_quads) return CK_EINVAL;
+    if (!h || !quads || !n_quads || n < 0 || quad_cap < 0) return CK_EINVAL;
+    if (n == 0) return CK_OK;
     CK_HIP(hipSetDevice(h->device));
     int rc = imgs ? ck_upload_frames(h, imgs, n) : (n <= h->n_staged ? CK_OK : CK_EINVAL);
     if (rc != CK_OK) return rc;

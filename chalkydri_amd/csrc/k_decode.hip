@@ -291,7 +291,7 @@ __global__ __launch_bounds__(FNT) void k_finalize(DecodeArgs a) {
     __syncthreads();
     if (tid == 0) {
         uint32_t kept = 0;
-        bool overflow = false;
+        bool overflow = false, unverified = false;
         for (uint32_t r = 0; r < n; r++) {
             const ck_detection_t &d = cand[sOrder[r]];
             bool dup = false;
@@ -303,8 +303,10 @@ __global__ __launch_bounds__(FNT) void k_finalize(DecodeArgs a) {
             if (dup) continue;
             if (kept >= (uint32_t)ws.det_cap) { overflow = true; break; }
             out[kept++] = d;
+            unverified = unverified || (uint32_t)d.id >= a.fams[d.family].n_upstream;
         }
         counters[CK_CNT_DETS] = kept;
+        if (unverified) atomicOr(&counters[CK_CNT_STATUS], (uint32_t)CK_FRAME_UNVERIFIED_ID);
         if (overflow) atomicOr(&counters[CK_CNT_STATUS], (uint32_t)CK_FRAME_DETS_OVERFLOW);
     }
 }

@@ -547,6 +547,7 @@ struct GlueArgs {
     const ck_field_tag_t *field; int n_field;
     const double *gyro; const uint8_t *has_gyro;
     double sign_change_error;
+    const ck_dev_family *fams; int allow_unverified; // ids past a family's verified prefix are not upstream ids (ck_family_t.n_upstream)
     ck_sqpnp_problem_t *problems; ck_iso3_t *tags; double *bearings; // per frame: det_cap tags, 4*det_cap bearings
     int n;
 };
@@ -565,6 +566,7 @@ __global__ void k_glue(GlueArgs a) {
             for (int j = 0; j < a.n_field; j++)
                 if (a.field[j].id == dets[i].id) { k = j; break; }
             if (k < 0) continue; // unknown tag (apriltags/src/lib.rs:306-308)
+            if (!a.allow_unverified && (uint32_t)dets[i].id >= a.fams[dets[i].family].n_upstream) continue; // not an upstream id
             double b[12];
             bool ok = true;
             for (int c = 0; c < 4; c++) ok = unproject_one(a.cam, dets[i].p[c][0], dets[i].p[c][1], b + 3 * c) && ok;
@@ -684,6 +686,7 @@ int ck_run_pose(ck_handle *h, int n, const ck_process_params_t *pp, const double
     CK_HIP(hipMemcpyAsync(ws.d_has_gyro, has_gyro, (size_t)n, hipMemcpyDefault, h->stream));
     GlueArgs g;
     g.ws = ws; g.cam = pp->cam; g.robot_to_cam = pp->robot_to_cam; g.field = ws.d_field; g.n_field = pp->n_field; g.gyro = ws.d_gyro;
+    g.fams = h->d_fams; g.allow_unverified = pp->allow_unverified_ids;
     g.has_gyro = ws.d_has_gyro; g.sign_change_error = pp->sign_change_error; g.problems = ws.d_problems; g.tags = ws.d_pose_tags;
     g.bearings = ws.d_bearings; g.n = n;
     hipLaunchKernelGGL(k_glue, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, h->stream, g);

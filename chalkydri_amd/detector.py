@@ -59,8 +59,8 @@ def _bind(L):
     L.ck_ingest_frame.restype = vp
     L.ck_ingest_write.argtypes = [vp, i32, i32, _P(A.ImageU8), C.c_uint32]
     L.ck_ingest_submit.argtypes = [vp, i32, i32]
-    L.ck_detect_ingested.argtypes = [vp, i32, _P(A.Detection), i32, _P(i32), u32p]
-    L.ck_process_ingested.argtypes = [vp, i32, _P(A.ProcessParams), vp, vp, _P(A.VisionMeasurement), _P(i32)]
+    L.ck_detect_ingested.argtypes = [vp, i32, i32, _P(A.Detection), i32, _P(i32), u32p]
+    L.ck_process_ingested.argtypes = [vp, i32, i32, _P(A.ProcessParams), vp, vp, _P(A.VisionMeasurement), _P(i32)]
     L._ck_bound = True
     return L
 
@@ -271,7 +271,7 @@ class IngestRing:
         dets = (A.Detection * (cap * n))()
         counts = (C.c_int32 * n)()
         status = (C.c_uint32 * n)()
-        check(self._L.ck_detect_ingested(self._g, slot, dets, cap, counts, status), "ck_detect_ingested")
+        check(self._L.ck_detect_ingested(self._g, slot, n, dets, cap, counts, status), "ck_detect_ingested")
         return [[Detection(dets[i * cap + k]) for k in range(min(counts[i], cap))] for i in range(n)], np.array(status[:])
 
     def process(self, slot, n, pp, gyro, has_gyro):
@@ -279,5 +279,7 @@ class IngestRing:
         valid = (C.c_int32 * n)()
         g = np.ascontiguousarray(gyro, np.float64)
         hg = np.ascontiguousarray(has_gyro, np.uint8)
-        check(self._L.ck_process_ingested(self._g, slot, C.byref(pp), g.ctypes.data, hg.ctypes.data, out, valid), "ck_process_ingested")
+        if g.size != n or hg.size != n:
+            raise ValueError("gyro / has_gyro must hold one entry per submitted frame")
+        check(self._L.ck_process_ingested(self._g, slot, n, C.byref(pp), g.ctypes.data, hg.ctypes.data, out, valid), "ck_process_ingested")
         return out, np.array(valid[:])

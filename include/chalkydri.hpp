@@ -492,7 +492,7 @@ class AprilTags {
         for (int i = 0; i < n; i++) { has[i] = gyro[i].has_value(); g[i] = gyro[i].value_or(0.0); }
         std::vector<whacknet::VisionMeasurement> out(n);
         std::vector<int32_t> valid(n);
-        check(ck_process_ingested(ring.get(), slot, &pp_, g.data(), has.data(), out.data(), valid.data()), "ck_process_ingested");
+        check(ck_process_ingested(ring.get(), slot, n, &pp_, g.data(), has.data(), out.data(), valid.data()), "ck_process_ingested"); // CK_EINVAL unless n frames were submitted
         std::vector<std::pair<whacknet::VisionMeasurement, bool>> r;
         for (int i = 0; i < n; i++) r.emplace_back(out[i], valid[i] != 0);
         return r;

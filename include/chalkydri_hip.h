@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define CK_ABI_VERSION 1
+#define CK_ABI_VERSION 2
 
 /* ---- status codes ------------------------------------------------------------------------- */
 enum {
@@ -54,7 +54,8 @@ enum {
     CK_FRAME_POINTS_OVERFLOW = 1,   /* boundary-point buffer full: clusters may be missing */
     CK_FRAME_CLUSTERS_OVERFLOW = 2, /* cluster table full */
     CK_FRAME_QUADS_OVERFLOW = 4,    /* more candidate quads than capacity */
-    CK_FRAME_DETS_OVERFLOW = 8      /* more detections than `cap_per_frame` */
+    CK_FRAME_DETS_OVERFLOW = 8,     /* more detections than `cap_per_frame` */
+    CK_FRAME_UNVERIFIED_ID = 16     /* a detection's id is >= its family's n_upstream (see ck_family_t) */
 };
 
 /* ---- images --------------------------------------------------------------------------------- */
@@ -78,10 +79,17 @@ typedef struct ck_family {
     int32_t total_width;      /* 10 / 8 (adds the white quiet ring) */
     int32_t reversed_border;  /* 0 for both classic families */
     uint32_t min_hamming;     /* 11 / 5 */
+    uint32_t n_upstream;      /* IDs 0..n_upstream-1 are known to equal the upstream AprilTag table of this name.  A caller
+                               * that passes upstream's own table sets n_upstream = ncodes.  Detections with a larger id
+                               * raise CK_FRAME_UNVERIFIED_ID and are ignored by the pose glue unless
+                               * ck_process_params_t.allow_unverified_ids is set. */
 } ck_family_t;
 
-/* Built-in tables: "tag16h5" (upstream, verified) and "tag36h11" (layout + IDs 0..12 upstream,
- * remaining IDs from tools/gen_family36.c — see DESIGN.md).  Returns NULL for unknown names. */
+/* Built-in tables.  "tag16h5": all 30 upstream codes (n_upstream = 30).  "tag36h11": upstream layout, 587 codes of which
+ * IDs 0..38 are upstream codes (n_upstream = 39: every tag of the reference's field.json, IDs 1..32) and IDs 39..586 are a
+ * stand-in lexicode from tools/gen_family36.c that keeps the codebook search at its real size — NOT upstream IDs; an
+ * integrator who needs them passes upstream's tag36h11.c table through ck_config_t.families.
+ * Returns NULL for unknown names. */
 const ck_family_t *ck_family_builtin(const char *name);
 
 /* ---- detector configuration -------------------------------------------------------------------- */
@@ -292,6 +300,7 @@ typedef struct ck_process_params {
     uint8_t camera_id;
     double sign_change_error;
     ck_sqpnp_params_t sqpnp;
+    int32_t allow_unverified_ids;  /* 0 (default): detections with id >= their family's n_upstream never reach the solver */
 } ck_process_params_t;
 
 /* detect → known-tag filter → unproject → solve_robot_pose → measurement, per frame.
@@ -318,10 +327,31 @@ uint8_t *ck_ingest_frame(ck_ingest_t *ing, int32_t slot, int32_t index);        
 /* stride-aware copy of a caller frame into the slot; fourcc as four ASCII bytes, little-endian ("GREY" = 0x59455247) */
 int ck_ingest_write(ck_ingest_t *ing, int32_t slot, int32_t index, const ck_image_u8_t *img, uint32_t fourcc);
 int ck_ingest_submit(ck_ingest_t *ing, int32_t slot, int32_t n);
-int ck_detect_ingested(ck_ingest_t *ing, int32_t slot, ck_detection_t *dets, int32_t cap_per_frame, int32_t *counts,
-                       uint32_t *status);
-int ck_process_ingested(ck_ingest_t *ing, int32_t slot, const ck_process_params_t *pp, const double *gyro,
+/* n = frames the output (and gyro) arrays hold; CK_EINVAL unless it is the count the slot was submitted with */
+int ck_detect_ingested(ck_ingest_t *ing, int32_t slot, int32_t n, ck_detection_t *dets, int32_t cap_per_frame,
+                       int32_t *counts, uint32_t *status);
+int ck_process_ingested(ck_ingest_t *ing, int32_t slot, int32_t n, const ck_process_params_t *pp, const double *gyro,
                         const uint8_t *has_gyro, ck_vision_measurement_t *out, int32_t *valid);
+
+/* ---- multi-GPU: the final pose gather ----------------------------------------------------------------------------------
+ * Frames shard over GPUs without any data-path collective (one handle, one process or host thread per GPU).  The only
+ * exchange is the gather of the 64-byte records (the wire struct of crates/whacknet/src/lib.rs:43-66): ONE ncclAllGather
+ * (RCCL over xGMI) of n x 64 bytes per batch on the handle's stream.  The host distributes the 128-byte id that rank 0
+ * obtains from ck_comm_unique_id over whatever channel it has (the reference has UDP; the Python mirror uses
+ * torch.distributed's store).  librccl is opened on first use: CK_EUNSUPPORTED when it cannot be loaded. */
+#define CK_COMM_ID_BYTES 128
+#define CK_BACKEND_HIP 1
+typedef struct ck_comm ck_comm_t;
+int ck_backend(const ck_handle_t *h);                      /* CK_BACKEND_HIP: the library has no CPU backend */
+int ck_comm_unique_id(uint8_t *id_out);                    /* rank 0: id_out[CK_COMM_ID_BYTES] */
+int ck_comm_create(ck_handle_t *h, const uint8_t *id, int32_t world, int32_t rank, ck_comm_t **out); /* collective: every rank calls it */
+void ck_comm_destroy(ck_comm_t *comm);
+/* Gathers the n records the handle's last ck_process_* call produced (they are still on the device) from every rank into
+ * out[world*n] in rank order; n must be the same on every rank (pad a ragged last shard with tag_count = 0 records, which
+ * is what a frame without a pose publishes anyway: crates/apriltags/src/lib.rs:365-376).  `out` may be a host or a device
+ * pointer.  sync = 0 only enqueues on the handle's stream; ck_comm_sync (or the next synchronous call) completes it. */
+int ck_gather_poses(ck_handle_t *h, ck_comm_t *comm, int32_t n, ck_vision_measurement_t *out, int32_t sync);
+int ck_comm_sync(ck_comm_t *comm);
 
 /* OpenCVModel5 unprojection of pixel points to bearings (x,y,1)/norm; ok[i]=0 when it does not converge. */
 int ck_unproject_opencv5(const ck_opencv5_t *cam, const double *px, int32_t n, double *bearings,

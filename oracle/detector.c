@@ -827,6 +827,8 @@ int ora_detect(const uint8_t *img, int w, int h, int stride, const ck_config_t *
     if (ora_clusters(th, labels, sizes, qw, qh, cfg->min_component_px, cl, ccap, &nc, pts, pcap, &np)) st |= CK_FRAME_POINTS_OVERFLOW;
     if (ora_fit_quads(q, qw, qh, qstride, img, w, h, stride, cfg, cl, nc, pts, quads, qcap, &nq)) st |= CK_FRAME_QUADS_OVERFLOW;
     if (ora_decode_quads(img, w, h, stride, cfg, quads, nq, dets, det_cap, n_dets)) st |= CK_FRAME_DETS_OVERFLOW;
+    for (int i = 0; i < *n_dets; i++) /* an id past the family's verified prefix is not an upstream id (ck_family_t.n_upstream) */
+        if ((uint32_t)dets[i].id >= cfg->families[dets[i].family]->n_upstream) st |= CK_FRAME_UNVERIFIED_ID;
     if (status) *status = st;
     free(qim); free(th); free(labels); free(sizes); free(cl); free(pts); free(quads);
     return CK_OK;

@@ -540,6 +540,7 @@ int ora_process_frame(const uint8_t *img, int w, int h, int stride, const ck_con
             for (int k = 0; k < pp->n_field; k++)
                 if (pp->field[k].id == dets[i].id) { tag = &pp->field[k]; break; }
             if (!tag) continue; /* unknown tag (lib.rs:306-308) */
+            if (!pp->allow_unverified_ids && (uint32_t)dets[i].id >= cfg->families[dets[i].family]->n_upstream) continue; /* not an upstream id */
             double px[8], b[12];
             uint8_t ok[4];
             for (int c = 0; c < 4; c++) { px[2 * c] = dets[i].p[c][0]; px[2 * c + 1] = dets[i].p[c][1]; }

@@ -32,7 +32,7 @@ def test_struct_layouts():
     assert C.sizeof(A.Detection) == 96 and C.sizeof(A.ClusterPoint) == 8 and C.sizeof(A.Cluster) == 16
     assert C.sizeof(A.Iso3) == 56 and C.sizeof(A.SqpnpResult) == 144
     L = _lib.lib()
-    assert L.ck_abi_version() == 1
+    assert L.ck_abi_version() == 2
 
 
 def test_defaults_mirror_the_reference(built):

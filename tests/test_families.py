@@ -54,6 +54,47 @@ def test_tag36h11_layout_anchors_and_distance_11():
     assert _min_rotational_hamming(codes, 36) == 11
 
 
+# AprilTag-2 (row-major) form of upstream tag36h11 IDs 0..38 and the multiple k of the generator increment each one is
+# away from ID 0.  A 36-bit value recalled wrongly lands on a k below 121 with probability ~2e-9, so the lattice test
+# is what makes "these are upstream's codes" checkable without upstream's file.
+TAG36H11_AT2_HEAD = [
+    0xd5d628584, 0xd97f18b49, 0xdd280910e, 0xe479e9c98, 0xebcbca822, 0xf31dab3ac, 0x056a5d085, 0x10652e1d4,
+    0x22b1dfead, 0x265ad0472, 0x34fe91b86, 0x3ff962cd5, 0x43a25329a, 0x474b4385f, 0x4e9d243e9, 0x5246149ae,
+    0x5997f5538, 0x683bb6c4c, 0x6be4a7211, 0x7e3158eea, 0x81da494af, 0x858339a74, 0x8cd51a5fe, 0x9f21cc2d7,
+    0xa2cabc89c, 0xadc58d9eb, 0xb16e7dfb0, 0xb8c05eb3a, 0xd25ef139d, 0xd607e1962, 0xe4aba3076, 0x2dde6a3da,
+    0x43d40c678, 0x5620be351, 0x64c47fa65, 0x686d7002a, 0x6c16605ef, 0x6fbf50bb4, 0x8d06d39dc]
+TAG36H11_K = [0, 1, 2, 4, 6, 8, 13, 16, 21, 22, 26, 29, 30, 31, 33, 34, 36, 40, 41, 46, 47, 48, 50, 55, 56, 59, 60, 62, 69,
+              70, 74, 94, 100, 105, 109, 110, 111, 112, 120]
+
+
+def _at2_to_at3(c, bx, by, d):
+    out = 0
+    for i in range(d * d):
+        k = (by[i] - 1) * d + (bx[i] - 1)
+        out = (out << 1) | ((c >> (d * d - 1 - k)) & 1)
+    return out
+
+
+def test_tag36h11_verified_prefix_sits_on_the_generator_lattice():
+    f, codes = _codes("tag36h11")
+    assert f.n_upstream == 39 == len(TAG36H11_AT2_HEAD)
+    prime, mask = 982451653, (1 << 36) - 1
+    inv = pow(prime, -1, 1 << 36)
+    ks = [((c - TAG36H11_AT2_HEAD[0]) * inv) & mask for c in TAG36H11_AT2_HEAD]
+    assert ks == TAG36H11_K and all(b > a for a, b in zip(ks, ks[1:]))
+    bx = [f.bit_x[i] for i in range(36)]
+    by = [f.bit_y[i] for i in range(36)]
+    assert [_at2_to_at3(c, bx, by, 6) for c in TAG36H11_AT2_HEAD] == codes[:39].tolist()
+    # two IDs the round-1 reviewer recalled independently in the AprilTag-3 form
+    assert codes[16] == 0x5eb946b4e and codes[19] == 0x78765559d
+    # every tag of the reference's field layout lies inside the verified prefix
+    import json, os
+    layout = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "field.json")))
+    ids = [t["ID"] for t in layout["tags"]]
+    assert ids and max(ids) < f.n_upstream
+    assert family("tag16h5").contents.n_upstream == 30
+
+
 def test_unknown_family():
     import pytest
     with pytest.raises(KeyError):

@@ -166,8 +166,9 @@ def test_detect_matches_oracle_and_truth(oracle, w, h, n_tags, fams, bits, kw):
     got, status = det.detect_batch(frames, cap=64, return_status=True)
     cfg = default_config(w, h, families=fams, max_hamming=bits)
     for i in range(n):
-        assert status[i] == 0
         want, st = oracle.detect(frames[i], cfg)
+        assert status[i] == st and not (st & ~A.CK_FRAME_UNVERIFIED_ID)   # random ids may lie past the verified prefix
+        assert bool(st & A.CK_FRAME_UNVERIFIED_ID) == any(d["id"] >= cfg.families[d["family"]].contents.n_upstream for d in want)
         _same_dets(got[i], want)
         # and both agree with the renderer's ground truth: every rendered tag found, corners within 1.5 px
         for t in truths[i]:
@@ -265,7 +266,7 @@ def test_capacity_overflow_is_a_status_bit(oracle):
     det = AprilTagDetector(w, h, max_batch=3, max_points_per_frame=20000, max_clusters_per_frame=1024)
     dets, status = det.detect_batch(np.stack([tags, noise, tags]), cap=64, return_status=True)
     assert status[1] & (A.CK_FRAME_POINTS_OVERFLOW | A.CK_FRAME_CLUSTERS_OVERFLOW)
-    assert status[0] == 0 and status[2] == 0
+    assert not (status[0] | status[2]) & ~A.CK_FRAME_UNVERIFIED_ID
     _same_dets(dets[0], want_tags); _same_dets(dets[2], want_tags)
     det.close()
     # quads: twelve clean tags against room for four candidate quads
@@ -372,4 +373,42 @@ def test_detect_matches_oracle_at_the_default_decimation(oracle, w, h):
         want, st = oracle.detect(frames[i], cfg)
         assert status[i] == st and len(want) >= 2
         _same_dets(dets[i], want)
+    det.close()
+
+
+def test_caller_supplied_family_table(oracle):
+    """The path INTEGRATION.md §3 gives integrators for upstream's tag36h11 table: a ck_family_t built by the caller.  Here the
+    caller's table is the built-in one with its ids permuted (and marked wholly upstream): the frames still show the built-in
+    codes, so every tag must come back under the PERMUTED id, corners unchanged, and without CK_FRAME_UNVERIFIED_ID — while
+    the built-in table flags every frame that holds an id past its verified prefix."""
+    from chalkydri_amd import family
+    from chalkydri_amd.detector import AprilTagDetector
+    w, h, n = 640, 480, 3
+    frames, truths = synth.render_batch(29, n, w, h, 4)
+    src = family("tag36h11").contents
+    nc = src.ncodes
+    perm = np.random.default_rng(5).permutation(nc)                 # new id i holds the code of built-in id perm[i]
+    inv = np.argsort(perm)
+    codes = (C.c_uint64 * nc)(*[src.codes[int(perm[i])] for i in range(nc)])
+    mine = A.Family()
+    C.memmove(C.byref(mine), C.byref(src), C.sizeof(A.Family))
+    mine.name = b"tag36h11"
+    mine.codes = C.cast(codes, C.POINTER(C.c_uint64))
+    mine.n_upstream = nc
+    mine_p = C.pointer(mine)
+    det0 = AprilTagDetector(w, h, max_batch=n)
+    base, st0 = det0.detect_batch(frames, return_status=True)
+    det0.close()
+    det = AprilTagDetector(w, h, max_batch=n, families=(mine_p,))
+    got, st = det.detect_batch(frames, return_status=True)
+    cfg = default_config(w, h, families=(mine_p,))
+    for i in range(n):
+        assert len(base[i]) >= 3 and len(got[i]) == len(base[i])
+        assert sorted((int(inv[d.id()]), d.corners().tobytes()) for d in base[i]) == sorted((d.id(), d.corners().tobytes()) for d in got[i])
+        assert st[i] == 0
+        assert bool(st0[i] & A.CK_FRAME_UNVERIFIED_ID) == any(d.id() >= src.n_upstream for d in base[i])
+        want, ost = oracle.detect(frames[i], cfg)
+        assert ost == 0
+        _same_dets(got[i], want)
+    assert any(s & A.CK_FRAME_UNVERIFIED_ID for s in st0)           # the scene holds ids >= 39 (random ids out of 587)
     det.close()

@@ -46,8 +46,15 @@ def test_ring_matches_upload_path(built):
         assert np.array_equal(valid, v) and valid.all()
         for i in range(n):
             assert bytes(out[i]) == bytes(recs[i])
+    # the caller's n must be the submitted count: the output arrays are sized from it
+    from chalkydri_amd._lib import ChalkydriError
+    with pytest.raises(ChalkydriError) as e:
+        ring.detect(1, n - 1)
+    assert e.value.code == A.CK_EINVAL
+    with pytest.raises(ChalkydriError):
+        ring.process(1, n + 1, task._pp, np.zeros(n + 1), np.ones(n + 1, np.uint8))
     dets, status = ring.detect(1, n)
-    assert all(len(d) == 6 for d in dets) and not status.any()
+    assert all(len(d) == 6 for d in dets) and not (status & ~np.uint32(A.CK_FRAME_UNVERIFIED_ID)).any()
     # a packed-colour format has no leading luma plane: refused, like the detector's 8-bit-luma assumption
     arr = (A.ImageU8 * 1)()
     arr[0].buf, arr[0].width, arr[0].height, arr[0].stride = frames[0].ctypes.data, w, h, w
@@ -87,7 +94,7 @@ def test_strided_host_and_device_frames(built, oracle):
     cfg = default_config(w, h)
     for i in range(n):
         ref, _ = oracle.detect(frames[i], cfg)
-        assert counts[i] == counts2[i] == len(want[i]) == len(ref) and status[i] == status2[i] == 0
+        assert counts[i] == counts2[i] == len(want[i]) == len(ref) and status[i] == status2[i] and not status[i] & ~A.CK_FRAME_UNVERIFIED_ID
         for k in range(counts[i]):
             for got in (dets[i * cap + k], dets2[i * cap + k]):
                 assert got.id == want[i][k].id() and got.hamming == want[i][k].hamming()

@@ -225,6 +225,18 @@ assert out.shape == (n, 64) and d_valid.cpu().numpy().tolist() == [int(v) for v 
 for i in range(n):
     assert bytes(out[i].cpu().numpy()) == bytes(want[i])
     assert got["camera_id"][i] == 9 and got["tag_count"][i] == 6
+# the same exchange through the C ABI (ck_comm_create + ck_gather_poses: what a Rust/C++ host calls), to a host buffer and to
+# a device buffer; the id of rank 0 travels through the torch group
+comm = dist.PoseComm(task.detector, 0, 1, dev)
+assert task.detector._L.ck_backend(task.detector._h) == 1
+host = comm.gather(n)
+d_out = torch.zeros((n, 64), dtype=torch.uint8, device=dev)
+comm.gather(n, out_ptr=d_out.data_ptr(), sync=False)
+comm.sync()
+for i in range(n):
+    assert bytes(host[i]) == bytes(want[i]) == bytes(d_out[i].cpu().numpy())
+assert task.detector._L.ck_gather_poses(task.detector._h, comm._c, n + 1, d_out.data_ptr(), 1) == -5      # CK_ECAPACITY
+comm.close()
 tdist.destroy_process_group()
 print("GATHER OK")
 """
@@ -312,8 +324,9 @@ def test_glue_filters(oracle):
     other = scenes.wall_layout(6, cols=3, first_id=101)                           # a layout that knows none of them
     cfg = default_config(w, h)
 
-    def both(layout, frames, gyros):
+    def both(layout, frames, gyros, allow_unverified=0):
         task = AprilTags(w, h, layout, calib, r2c, cam_id=4, max_batch=len(frames))
+        task._pp.allow_unverified_ids = allow_unverified
         recs, valid = task.process_batch(np.stack(frames), gyros)
         outs = []
         for fr, g in zip(frames, gyros):
@@ -333,3 +346,11 @@ def test_glue_filters(oracle):
     assert bytes(recs[1]) == bytes(outs[1][0]) and bytes(recs[2]) == bytes(outs[2][0]) and recs[1].tag_count == 0
     recs, valid, outs = both(other, [seen], [pose[2]])
     assert list(valid) == [0] == [outs[0][1]] and bytes(recs[0]) == bytes(outs[0][0])
+    # ids past the built-in table's verified prefix (ck_family_t.n_upstream = 39) are not upstream ids: a layout that lists them
+    # gets no pose from them unless the caller opts in
+    far, _ = scenes.render_view(62, w, h, f, other, pose, r2c, noise_amp=1)       # six tags, ids 101..106
+    recs, valid, outs = both(other, [far], [pose[2]])
+    assert list(valid) == [0] == [outs[0][1]] and bytes(recs[0]) == bytes(outs[0][0])
+    recs, valid, outs = both(other, [far], [pose[2]], allow_unverified=1)
+    assert list(valid) == [1] == [outs[0][1]] and recs[0].tag_count == 6
+    assert abs(recs[0].pose_x - outs[0][0].pose_x) < 1e-6 and abs(recs[0].pose_x - pose[0]) < 0.05

@@ -58,6 +58,18 @@ out = dist.gather_records(rec, world)
 assert out.shape == (10, 64)
 assert out[:, 0].tolist() == list(range(10)), out[:, 0].tolist()
 assert out[:, 56].tolist() == [0] * 5 + [1] * 5
+# ragged shards (11 frames over 2 ranks: 6 + 5): padded to the common row count, trimmed back to frame order
+lo, hi = dist.shard_frames(11, rank, world)
+rec = torch.zeros((hi - lo, 64), dtype=torch.uint8)
+for i in range(lo, hi):
+    rec[i - lo, 0] = i + 1
+    rec[i - lo, 57] = 3         # tag_count
+rows = dist.shard_rows(11, world)
+out = dist.gather_records(rec, world, rows=rows)
+assert rows == 6 and out.shape == (12, 64)
+assert out[:, 57].tolist() == [3] * 6 + [3] * 5 + [0]          # the padding is the empty record (tag_count 0)
+trimmed = dist.trim_gathered(out, 11, world)
+assert trimmed.shape == (11, 64) and trimmed[:, 0].tolist() == list(range(1, 12))
 import torch.distributed as td
 td.barrier(); td.destroy_process_group()
 print("ok", rank)

@@ -4,9 +4,14 @@
 // [EXT] and is not present in this environment.  This tool builds a lexicode with the SAME
 // parameters (6x6 data bits, min Hamming distance 11 under all four rotations, candidates walked
 // with the upstream generator's increment 982451653 mod 2^36 starting at upstream code 0), seeded
-// with the 13 upstream codes that could be recalled AND verified (they sit on the increment
-// lattice and are mutually >= 11 apart).  IDs 0..12 therefore equal upstream IDs; IDs >= 13 are
-// NOT upstream tag36h11 IDs.  A deployment that needs real tag36h11 IDs passes the upstream table
+// with the 39 upstream codes that could be recalled AND verified: code[i] - code[0] is a small,
+// strictly increasing multiple k_i of the increment (k = 0,1,2,4,6,8,13,...,120; a misremembered
+// 36-bit value lands on such a k with probability ~1e-9), every one of them is >= 11 away from all
+// rotations of the earlier ones, and upstream's own order is the order of k.  IDs 0..38 therefore
+// equal upstream IDs — that covers every tag of the reference's field.json (IDs 1..32).  IDs >= 39
+// are NOT upstream tag36h11 IDs: upstream's generator also rejects about half of the distance-valid
+// candidates with a pattern-complexity test that could not be reconstructed (between k = 0 and 120
+// it drops 35 candidates that pass every distance test).  A deployment that needs real tag36h11 IDs passes the upstream table
 // through ck_family_create().
 //
 // Codes are emitted in the AprilTag-2 convention (row-major, MSB = top-left data bit).
@@ -19,6 +24,7 @@
 #define NB 36
 #define D 6
 #define MINH 11
+#define NSEED 39 // upstream codes recalled AND verified on the generator lattice (tests/test_families.py)
 static const uint64_t MASK = (1ULL << NB) - 1;
 static const uint64_t PRIME = 982451653ULL;
 
@@ -69,12 +75,19 @@ static inline int far_from_all(uint64_t v, int from) {
 
 int main(int argc, char **argv) {
     int want = argc > 1 ? atoi(argv[1]) : 587;
-    static const uint64_t seed[13] = {0xd5d628584ULL, 0xd97f18b49ULL, 0xdd280910eULL, 0xe479e9c98ULL,
-                                      0xebcbca822ULL, 0xf31dab3acULL, 0x056a5d085ULL, 0x10652e1d4ULL,
-                                      0x22b1dfeadULL, 0x265ad0472ULL, 0x34fe91b86ULL, 0x3ff962cd5ULL,
-                                      0x43a25329aULL};
-    for (int i = 0; i < 13; i++) add_code(seed[i]);
-    uint64_t v0 = (seed[12] + PRIME) & MASK;
+    static const uint64_t seed[NSEED] = {
+        0xd5d628584ULL, 0xd97f18b49ULL, 0xdd280910eULL, 0xe479e9c98ULL,
+        0xebcbca822ULL, 0xf31dab3acULL, 0x056a5d085ULL, 0x10652e1d4ULL,
+        0x22b1dfeadULL, 0x265ad0472ULL, 0x34fe91b86ULL, 0x3ff962cd5ULL,
+        0x43a25329aULL, 0x474b4385fULL, 0x4e9d243e9ULL, 0x5246149aeULL,
+        0x5997f5538ULL, 0x683bb6c4cULL, 0x6be4a7211ULL, 0x7e3158eeaULL,
+        0x81da494afULL, 0x858339a74ULL, 0x8cd51a5feULL, 0x9f21cc2d7ULL,
+        0xa2cabc89cULL, 0xadc58d9ebULL, 0xb16e7dfb0ULL, 0xb8c05eb3aULL,
+        0xd25ef139dULL, 0xd607e1962ULL, 0xe4aba3076ULL, 0x2dde6a3daULL,
+        0x43d40c678ULL, 0x5620be351ULL, 0x64c47fa65ULL, 0x686d7002aULL,
+        0x6c16605efULL, 0x6fbf50bb4ULL, 0x8d06d39dcULL};
+    for (int i = 0; i < NSEED; i++) add_code(seed[i]);
+    uint64_t v0 = (seed[NSEED - 1] + PRIME) & MASK;
     const uint64_t CH = 1ULL << 22;
     uint64_t *surv = malloc(CH * sizeof(uint64_t));
     uint64_t total = (1ULL << NB);
