@@ -28,11 +28,8 @@ extern "C" int ck_create(const ck_config_t *cfg, ck_handle_t **out) {
     for (int i = 0; i < cfg->n_families; i++)
         if (!cfg->families[i] || cfg->families[i]->nbits > 64 || cfg->families[i]->total_width > 16) return CK_EINVAL;
     int qw = cfg->width / cfg->quad_decimate, qh = cfg->height / cfg->quad_decimate;
-    if (qw & 3) return CK_EUNSUPPORTED; // rows are handled in 4-pixel words
-    // a height that is not a multiple of 4 leaves one to three rows below the last whole 4x4 tile; they take that tile's
-    // threshold, which the segmentation kernel finds in its own 64-row tile unless the leftover rows start a new one
-    if ((qh & 3) && ((qh & ~3) % CK_TH) == 0) return CK_EUNSUPPORTED;
-    if (cfg->min_component_px < 1 || cfg->min_component_px > 127) return CK_EUNSUPPORTED; // tile-local sizes saturate at 127 (k_ccl.hip)
+    if (qw < 8 || qh < 8) return CK_EINVAL;
+    if (cfg->min_component_px < 1 || cfg->min_component_px > 0x3FFFFFFF) return CK_EINVAL;
     if (ck_device_count() <= 0) return CK_ENODEVICE;
     ck_handle *h = new (std::nothrow) ck_handle();
     if (!h) return CK_ENOMEM;
@@ -42,7 +39,11 @@ extern "C" int ck_create(const ck_config_t *cfg, ck_handle_t **out) {
     h->w = cfg->width; h->h = cfg->height; h->qw = qw; h->qh = qh;
     h->npix = (size_t)qw * qh;
     h->tiles_x = (qw + CK_TW - 1) / CK_TW; h->tiles_y = (qh + CK_TH - 1) / CK_TH;
-    h->broot_cap = h->tiles_x * h->tiles_y * 2 * (CK_TW + CK_TH);
+    h->broot_cap = h->tiles_x * h->tiles_y * CK_RING_CAP;
+    h->ring_len = 2 * ((size_t)h->tiles_y * qw + (size_t)h->tiles_x * qh);
+    // k_fmerge keeps a frame's ring-touching roots in LDS (at most 32767 of them; dense noise gives about 90 per tile, and a
+    // frame that has more falls back to global memory inside the kernel); larger frames use the tile-parallel kernels
+    h->lds_merge = h->tiles_x * h->tiles_y <= 320 && cfg->min_component_px <= 32767; // 320 = FM_MAX_TILES (k_ccl.hip)
     h->frame_stride = round_up(cfg->width, 16);
     h->frame_pitch = (size_t)h->frame_stride * cfg->height;
     const size_t nb = (size_t)cfg->max_batch;
@@ -70,8 +71,9 @@ extern "C" int ck_create(const ck_config_t *cfg, ck_handle_t **out) {
     CK_TRY(hipMalloc(&h->d_thresh, h->npix * nb));
     CK_TRY(hipMalloc(&h->d_labels, h->npix * nb * sizeof(uint32_t)));
     CK_TRY(hipMalloc(&h->d_csize, h->npix * nb * sizeof(uint32_t)));
-    CK_TRY(hipMalloc(&h->d_broots, (size_t)h->broot_cap * nb * sizeof(ck_border_root)));
-    CK_TRY(hipMalloc(&h->d_broot_count, nb * sizeof(uint32_t)));
+    CK_TRY(hipMalloc(&h->d_broots, 2 * (size_t)h->broot_cap * nb * sizeof(ck_border_root)));
+    CK_TRY(hipMalloc(&h->d_tile_count, (size_t)h->tiles_x * h->tiles_y * nb * sizeof(uint32_t)));
+    CK_TRY(hipMalloc(&h->d_ring, h->ring_len * nb * sizeof(uint16_t)));
     rc = ck_stage_alloc(h);
     if (rc != CK_OK) return fail(rc);
 #undef CK_TRY
@@ -87,7 +89,7 @@ extern "C" void ck_destroy(ck_handle_t *h) {
     for (auto &st : h->fit_stream) if (st) (void)hipStreamSynchronize(st);
     ck_stage_free(h);
     (void)hipFree(h->d_frames); (void)hipFree(h->d_qframes); (void)hipFree(h->d_thresh); (void)hipFree(h->d_labels);
-    (void)hipFree(h->d_csize); (void)hipFree(h->d_broots); (void)hipFree(h->d_broot_count);
+    (void)hipFree(h->d_csize); (void)hipFree(h->d_broots); (void)hipFree(h->d_tile_count); (void)hipFree(h->d_ring);
     for (auto &e : h->ev) if (e) (void)hipEventDestroy(e);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);

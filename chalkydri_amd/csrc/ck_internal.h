@@ -22,7 +22,8 @@
 
 // CCL tile geometry (one workgroup per tile)
 #define CK_TW 128
-#define CK_TH 64
+#define CK_TH 32
+#define CK_RING_CAP (2 * (CK_TW + CK_TH)) /* ring-touching roots a tile can have: one per ring pixel at most */
 
 struct ck_border_root {
     uint32_t root; // pixel index of a tile-local root whose component touches the tile ring
@@ -127,9 +128,15 @@ struct ck_handle {
     uint8_t *d_thresh;   // [n][qh][qw]
     uint32_t *d_labels;  // [n][qh][qw] label words
     uint32_t *d_csize;   // [n][qh][qw] sparse: valid at roots of BORDER components
-    ck_border_root *d_broots; // [n][broot_cap]
-    uint32_t *d_broot_count;  // [n]
-    int broot_cap;
+    ck_border_root *d_broots; // [n][2][broot_cap]: per tile a slice of CK_RING_CAP entries (k_tile), then the same entries packed (k_fmerge)
+    uint32_t *d_tile_count;   // [n][tiles]: entries used in every tile's slice
+    int broot_cap;            // tiles * CK_RING_CAP
+    // ids of the ring-touching roots along the tile boundaries (k_tile writes them, k_fmerge joins across them), per frame:
+    // HT[tiles_y][qw] top rows | HB[tiles_y][qw] bottom rows | VL[tiles_x][qh] left columns | VR[tiles_x][qh] right columns;
+    // an entry = index into the frame's d_broots list | colour << 15 (1 = white), 0xFFFF = no colour
+    uint16_t *d_ring;         // [n][ring_len]
+    size_t ring_len;
+    bool lds_merge;           // frames small enough for the one-workgroup-per-frame merge in LDS (k_fmerge); else k_merge + k_roots
     // later stages
     ck_stage_ws ws;      // workspace of clusters / quads / decode
     ck_stage_ms_t last_ms;

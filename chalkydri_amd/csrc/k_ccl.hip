@@ -4,14 +4,17 @@
 // Replaces, in the reference's production path, the threshold and connected-component stages of the external
 // AprilTag-3 detector reached at crates/apriltags/src/lib.rs:301; the connectivity rule is the one CAT spells
 // out in crates/chalkydri-apriltags/src/lib.rs:501-549 (4-connected black, 8-connected white, origin columns
-// 1..w-2).
+// 1..w-2), stated as bit operations on 32-pixel row words in ck_links.h.
 //
 // Structure (one launch each, batched over frames):
-//   k_tile   one workgroup per 64x128 tile: coalesced 16-byte loads of the tile + 4-px halo into LDS, 4x4
-//            tile min/max, 3x3 dilation, tri-state threshold (written once, 16 B/lane), bit-parallel
-//            union-find in LDS (one lane per 64-pixel row segment and colour, runs found with clz/ctz on u64
-//            masks, u16 parents, saturating u8 sizes: 26 KB of LDS, six workgroups per CU), labels written once
-//            (64 B/lane), ring-touching roots appended per wave.  HBM traffic 1.2 R + 1 W + 4 W bytes per pixel.
+//   k_tile   one workgroup (256 threads) per 32x128 tile.  Coalesced 16-byte loads of the tile + halo into LDS, 4x4
+//            min/max, 3x3 dilation, tri-state threshold (written once, 16 B/lane) and the rows' colour bits as 32-pixel
+//            words.  The union-find works on RUNS, one lane per run from a compacted list (wave prefix sums), so every
+//            phase is straight-line code with balanced lanes: (a) adoption — a run takes ONE earlier run as parent with a
+//            plain store; (b) one pointer-jumping sweep over the static adoption forest; (c) the remaining links, pooled
+//            in LDS, one lane per link, through an atomic-min union; (d) flatten + exact sizes (ds_add on u16 halves);
+//            (e) label words written once (64 B/lane), ring-touching roots appended per wave.  25.7 KB of LDS: six
+//            workgroups per CU.  HBM traffic 1.4 R + 1 W + 4 W bytes per pixel.
 //   k_merge  one thread per tile-ring pixel: links reduced to pairs of tile-local roots, de-duplicated per tile in an
 //            LDS hash set, joined with atomicMin on the label words of the roots involved.
 //   k_roots  flattens the entries of ring-touching roots and accumulates their sizes into csize[].
@@ -20,62 +23,50 @@
 #include <stdlib.h>
 
 #include "ck_internal.h"
+#include "ck_links.h"
 
 namespace {
 
 constexpr int TW = CK_TW, TH = CK_TH, NT = 256; // NT: merge / utility kernels
-constexpr int SEGW = 64;                             // pixels per row segment = width of a lane's bit masks
-using mask_t = uint64_t;                             // (32-bit segments with twice the lanes were measured: slightly slower)
-constexpr int KNT = TH * (TW / SEGW) * 2;            // k_tile: one lane per (row segment, colour)
-constexpr int IMG_PITCH = 160;          // 12 pad | 4 halo | 128 tile | 4 halo | 12 pad
+constexpr int KNT = 256;                         // k_tile: one lane per (row, word, colour) where rows are handled, one per run elsewhere
+constexpr int NWD = TW / 32;                     // 32-pixel words per tile row
+constexpr int IMG_PITCH = 160;                   // 16 left halo | 128 tile | 16 right halo (only 8 + 8 of the halo are used)
 constexpr int IMG_ROWS = TH + 8;
-constexpr int T4X = TW / 4 + 2, T4Y = TH / 4 + 2;
-constexpr int NSEG = TW / SEGW;
-constexpr int MPIECES = SEGW / 16;                   // 16-pixel chunks per mask
-constexpr mask_t MALL = ~mask_t(0), MONE = 1;
-__device__ __forceinline__ int mctz(mask_t v) { return sizeof(mask_t) == 8 ? __builtin_ctzll(v) : __builtin_ctz((uint32_t)v); }
-__device__ __forceinline__ int mclz(mask_t v) { return sizeof(mask_t) == 8 ? __builtin_clzll(v) : __builtin_clz((uint32_t)v); }
-__device__ __forceinline__ int mpopc(mask_t v) { return sizeof(mask_t) == 8 ? __popcll(v) : __popc((uint32_t)v); }
+constexpr int T4X = TW / 4 + 2, T4Y = TH / 4 + 2; // 4x4-tile min/max grid of the staged region (one ring around the tile's own)
+static_assert(TH * NWD * 2 == KNT, "k_tile thread mapping: row x word x colour");
+static_assert(TH * 8 == KNT, "threshold / label passes: one 16-pixel chunk per thread");
+static_assert(TH * TW <= 4096, "run list entries keep the node in 12 bits, the colour in bit 12");
+static_assert(TW == 128, "a node index splits with >> 7 / & 127");
 
-// LDS of k_tile, 26 KB, so that six workgroups (24 waves) share a CU — the union-find is bound by LDS round-trip
-// latency, and resident waves are what hides it:
-//   parent  u16[TH*TW]  tile-local node index of the parent (8192 nodes fit 13 bits); while the threshold is computed
+// LDS of k_tile, 25.7 KB, so that six workgroups (24 waves) share a CU:
+//   parent  u16[TH*TW]  tile-local node index of the parent (nodes = first pixels of runs); while the threshold is computed
 //                       the same bytes hold the staged image, the 4x4 min/max and the per-4x4 threshold words
-//   size    u8[TH*TW]   at the roots: pixel count saturating at 127 (only "< min_component_px" is ever asked, and
-//                       ck_create refuses min_component_px > 127) | bit 7 = component touches the tile ring
-//   masks   mask_t[TH][NSEG][2]
-constexpr int OFF_PARENT = 0;                              // u16[TH*TW] = 16384
-constexpr int OFF_IMG = 0;                                 // IMG_ROWS*IMG_PITCH = 11520
-constexpr int OFF_MINMAX = OFF_IMG + IMG_ROWS * IMG_PITCH; // u16[T4Y*T4X] (1224 -> 1280)
-constexpr int OFF_THR = OFF_MINMAX + 1280;                 // u16[(TH/4)*(TW/4)] = 1024
-constexpr int OFF_SIZE = TH * TW * 2;                      // u8[TH*TW] = 8192
-constexpr int OFF_MASK = OFF_SIZE + TH * TW;               // mask_t[TH][NSEG][2]
-constexpr int LDS_BYTES = OFF_MASK + TH * NSEG * 2 * (int)sizeof(mask_t);
-constexpr uint32_t SIZE_SAT = 127;
-static_assert(OFF_THR + 1024 <= OFF_SIZE, "threshold scratch must fit in the parent array");
-static_assert(LDS_BYTES + 64 <= 27136, "keep six workgroups per CU");
-static_assert(TH * NSEG * 2 == KNT, "k_tile thread mapping: colour x row x segment");
-static_assert(TH * TW <= 65536, "node indices are u16");
-static_assert(TW == 128, "label pass splits a node index with >> 7 / & 127");
+//   size    u16[TH*TW]  at the roots: exact pixel count in bits 0..14 (a tile has 4096 pixels) | bit 15 = touches the tile
+//                       ring; before that the same bytes are the pool of links that need an atomic union
+//   list    u16[TH*TW]  the tile's runs in scan order: node | colour << 12 (worst case one run per pixel)
+//   masks   u32[TH][NWD][2]  colour bits of every row word (0 white, 1 black)
+constexpr int OFF_PARENT = 0;                              // u16[TH*TW] = 8192
+constexpr int OFF_IMG = 0;                                 // IMG_ROWS*IMG_PITCH = 6400
+constexpr int OFF_MINMAX = OFF_IMG + IMG_ROWS * IMG_PITCH; // u16[T4Y*T4X] = 700 -> 704
+constexpr int OFF_THR = OFF_MINMAX + 704;                  // u16[(TH/4)*(TW/4)] = 512
+constexpr int OFF_SIZE = TH * TW * 2;                      // u16[TH*TW] = 8192
+constexpr int OFF_LIST = OFF_SIZE + TH * TW * 2;           // u16[TH*TW] = 8192
+constexpr int OFF_MASK = OFF_LIST + TH * TW * 2;           // u32[TH][NWD][2] = 1024
+constexpr int OFF_MISC = OFF_MASK + TH * NWD * 2 * 4;      // u32[16]
+constexpr int LDS_BYTES = OFF_MISC + 64;
+constexpr int POOL_CAP = TH * TW * 2 / 4;                  // links (two u16 nodes each) that fit the size array
+constexpr int RING_CAP = CK_RING_CAP;                      // ring-touching roots of a tile: at most one per ring pixel
+static_assert(T4Y * T4X * 2 <= 704, "min/max scratch size");
+static_assert(OFF_THR + (TH / 4) * (TW / 4) * 2 <= OFF_SIZE, "threshold scratch must fit in the parent array");
+static_assert(LDS_BYTES <= 27136, "keep six workgroups per CU");
 
-#ifdef CK_TILE_PROFILE
-#define TCNT_ARG , uint32_t &tcnt
-#define TCNT_PASS , tcnt
-#define TCNT_INC ++tcnt
-#else
-#define TCNT_ARG
-#define TCNT_PASS
-#define TCNT_INC
-#endif
 // find with path halving.  Plain stores race with the min-hooks of lds_union, but every value ever written to p[a]
 // is an ancestor of a, so the forest stays valid (a lost hook is re-issued by its own union).
-// two halving finds walked in lockstep: both chains have a read in flight at every step (the kernel is bound by LDS
-// round-trip latency, not LDS bandwidth)
+// Two halving finds walked in lockstep: both chains have a read in flight at every step
 // (plain loads behind compiler barriers, not volatile ones: a volatile read is waited for before the next is issued, which
 // would put the two chains' reads one after the other)
-__device__ __forceinline__ void lds_find2(uint16_t *p, uint32_t &a, uint32_t &b TCNT_ARG) {
+__device__ __forceinline__ void lds_find2(uint16_t *p, uint32_t &a, uint32_t &b) {
     for (;;) {
-        TCNT_INC;
         __asm__ volatile("" ::: "memory");
         uint32_t na = p[a], nb = p[b];
         bool da = (na == a), db = (nb == b);
@@ -101,9 +92,9 @@ __device__ __forceinline__ uint32_t lds_min16(uint16_t *p, uint32_t idx, uint32_
     }
 }
 // root = smaller index
-__device__ __forceinline__ void lds_union(uint16_t *p, uint32_t a, uint32_t b TCNT_ARG) {
+__device__ __forceinline__ void lds_union(uint16_t *p, uint32_t a, uint32_t b) {
     for (;;) {
-        lds_find2(p, a, b TCNT_PASS);
+        lds_find2(p, a, b);
         if (a == b) return;
         if (a < b) { uint32_t t = a; a = b; b = t; }
         uint32_t old = lds_min16(p, a, b);
@@ -111,48 +102,69 @@ __device__ __forceinline__ void lds_union(uint16_t *p, uint32_t a, uint32_t b TC
         a = old;
     }
 }
-// adds `add` pixels (and the ring flag) to the size byte of a root: saturating, and free once nothing would change —
-// the one huge component of a noisy tile saturates after a few adds and every later run only reads
-__device__ __forceinline__ void lds_size_add(uint8_t *sz, uint32_t root, uint32_t add, bool ring) {
-    uint32_t *wp = reinterpret_cast<uint32_t *>(sz) + (root >> 2);
-    const uint32_t sh = (root & 3u) * 8u;
-    uint32_t wv = *reinterpret_cast<volatile uint32_t *>(wp);
-    for (;;) {
-        const uint32_t cur = (wv >> sh) & 0xFFu;
-        uint32_t cnt = (cur & 0x7Fu) + add;
-        cnt = cnt > SIZE_SAT ? SIZE_SAT : cnt;
-        const uint32_t nv = cnt | (cur & 0x80u) | (ring ? 0x80u : 0u);
-        if (nv == cur) return;
-        const uint32_t prev = atomicCAS(wp, wv, (wv & ~(0xFFu << sh)) | (nv << sh));
-        if (prev == wv) return;
-        wv = prev;
-    }
-}
-// start bit of the run that contains bit i, given the run-start mask S (bit i's run start is <= i)
-__device__ __forceinline__ int run_start(mask_t S, int i) {
-    return SEGW - 1 - mclz(S & (MALL >> (SEGW - 1 - i)));
-}
-__device__ __forceinline__ mask_t origin_mask(int x0, int w) {
-    mask_t O = MALL;
-    if (x0 == 0) O &= ~MONE;
-    int last = (w - 1) - x0;
-    if (last >= 0 && last < SEGW) O &= ~(MONE << last);
-    return O;
-}
 // gathers bit 7 of each byte of v into a nibble (bit k = byte k)
 __device__ __forceinline__ uint32_t msb_nibble(uint32_t v) {
     return (((v >> 7) & 0x01010101u) * 0x01020408u) >> 24 & 0xFu;
 }
 
+// One run of the tile as its lane sees it: where it is, its links to earlier runs (ck_links.h) and what it takes to name
+// the runs at the other end.  All reads are of the row-word masks in LDS; the code is branch-free (every lane of a wave looks
+// at a different run): words that do not exist (first row / first or last word of the tile) are read at a safe index and
+// masked to zero.
+struct RunView {
+    uint32_t p, wbase;   // node (tile pixel index of the run's first bit), tile pixel index of bit 0 of its word
+    uint32_t R, G, flags; // ck_run_links
+    uint32_t Su;         // run starts of the upper word
+    uint32_t up_l, left; // nodes of the last run of the upper-left word / of the word on the left (used when the link exists)
+};
+__device__ __forceinline__ RunView view_run(const uint32_t *mk, uint32_t e, int tx0, int w) {
+    RunView v;
+    const uint32_t p = e & 0xFFFu, c = e >> 12;
+    const int r = (int)(p >> 7), wd = (int)(p >> 5) & 3, i = (int)(p & 31u);
+    const int mrow = (int)((p >> 5) << 1) + (int)c; // (r * NWD + wd) * 2 + c
+    const int x0 = tx0 + 32 * wd;
+    const bool has_l = wd > 0, has_u = r > 0, has_r = wd < NWD - 1, white = c == 0;
+    const uint32_t O = ck_origin32(x0, w), Op = ck_origin32(x0 - 32, w);
+    const uint32_t M = mk[mrow];
+    uint32_t Mp = mk[has_l ? mrow - 2 : mrow];
+    uint32_t U = mk[has_u ? mrow - 2 * NWD : mrow];
+    uint32_t Up = mk[(has_u && has_l) ? mrow - 2 * NWD - 2 : mrow];
+    uint32_t Un = mk[(has_u && has_r) ? mrow - 2 * NWD + 2 : mrow];
+    Mp = has_l ? Mp : 0u; U = has_u ? U : 0u;
+    Up = (has_u && has_l) ? Up : 0u; Un = (has_u && has_r) ? Un : 0u;
+    const bool on0 = (x0 + 32 >= 1) && (x0 + 32 <= w - 2);
+    const ck_run_links L = ck_links_of_run(white, M, U, O, i, (Mp >> 31) != 0, (Up >> 31) != 0, (Un & 1u) != 0, on0);
+    v.p = p; v.wbase = p - (uint32_t)i;
+    v.R = L.R; v.G = L.G; v.flags = L.flags;
+    v.Su = ck_starts32(U, O);
+    v.left = v.wbase - 32u + (uint32_t)ck_last_start32(ck_starts32(Mp, Op));
+    v.up_l = v.wbase - (uint32_t)TW - 32u + (uint32_t)ck_last_start32(ck_starts32(Up, Op));
+    return v;
+}
+__device__ __forceinline__ uint32_t links_left(const RunView &v) { return (uint32_t)__popc(v.G) + (uint32_t)__popc(v.flags); }
+// takes one link out of the view and returns the node at its other end; `self` when none is left.  Order: the links to the
+// upper word from left to right, then hleft, cross_l, cross_r (the flag bits in ascending order).
+__device__ __forceinline__ uint32_t take_link(RunView &v, uint32_t self) {
+    const bool has_g = v.G != 0;
+    const int j = __builtin_ctz(v.G | 0x80000000u);
+    const uint32_t t_up = v.wbase - (uint32_t)TW + (uint32_t)ck_run_start32(v.Su, j);
+    const uint32_t f = v.flags & (0u - v.flags); // lowest flag
+    const uint32_t t_flag = f == CK_LINK_HLEFT ? v.left : (f == CK_LINK_CROSS_L ? v.up_l : (f ? v.wbase - (uint32_t)TW + 32u : self));
+    v.flags = has_g ? v.flags : (v.flags & (v.flags - 1u));
+    v.G &= v.G - 1u; // (0 stays 0)
+    return has_g ? t_up : t_flag;
+}
+
 // Diagnostic build only (-DCK_TILE_PROFILE): per-phase cycle totals of k_tile in a buffer of their own.
 #ifdef CK_TILE_PROFILE
 __device__ unsigned long long g_tile_prof[16];
-__device__ unsigned long long g_tile_prof2[8]; // wave 0's cycles inside the union phase: setup, adoption, barrier, atomic unions, barrier
 #define TPROF_DECL unsigned long long tp0 = __builtin_readcyclecounter()
 #define TPROF(k) do { unsigned long long t_ = __builtin_readcyclecounter(); if (threadIdx.x == 0) atomicAdd(&g_tile_prof[k], t_ - tp0); tp0 = t_; } while (0)
+#define TCOUNT(k, v) do { if (threadIdx.x == 0) atomicAdd(&g_tile_prof[k], (unsigned long long)(v)); } while (0)
 #else
 #define TPROF_DECL
 #define TPROF(k)
+#define TCOUNT(k, v)
 #endif
 
 // PRE = false: `frames` are gray images and the tri-state threshold is computed here;
@@ -160,62 +172,69 @@ __device__ unsigned long long g_tile_prof2[8]; // wave 0's cycles inside the uni
 //              segmentation runs (the map is copied through to `thresh` for the merge kernel).
 template <bool PRE>
 __global__ __launch_bounds__(KNT) void k_tile(const uint8_t *__restrict__ frames, size_t frame_pitch, int stride,
-                                             int w, int h, int tiles_x, int tiles_y, int min_diff, int min_comp,
+                                             int w, int h, int tiles_x, int tiles_y, int n_frames, int xcd_map, int min_diff, int min_comp,
                                              uint8_t *__restrict__ thresh, uint32_t *__restrict__ labels,
-                                             ck_border_root *__restrict__ broots,
-                                             uint32_t *__restrict__ broot_count, int broot_cap, uint32_t *__restrict__ csize, int stop_after) {
+                                             ck_border_root *__restrict__ broots, uint32_t *__restrict__ tile_count,
+                                             uint32_t *__restrict__ csize, uint16_t *__restrict__ ring, size_t ring_len, int write_ring,
+                                             int stop_after) {
     __shared__ __attribute__((aligned(16))) uint8_t lds[LDS_BYTES];
     const int tid = threadIdx.x;
     const int tiles = tiles_x * tiles_y;
-    const int frame = blockIdx.x / tiles, tile = blockIdx.x - frame * tiles;
+    int frame, tile;
+    if (xcd_map) { // workgroups b and b + 8 share an XCD (their L2): deal whole frames to XCDs, so that the halo rows a tile shares
+                   // with its neighbours are read from HBM once
+        const int x = blockIdx.x & 7, j = blockIdx.x >> 3;
+        frame = (j / tiles) * 8 + x; tile = j % tiles;
+        if (frame >= n_frames) return;
+    } else { frame = blockIdx.x / tiles; tile = blockIdx.x - frame * tiles; }
     const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
     const int tx0 = tx * TW, ty0 = ty * TH;
     const uint8_t *img = frames + (size_t)frame * frame_pitch;
     const size_t fbase = (size_t)frame * (size_t)w * (size_t)h;
     uint16_t *parent = reinterpret_cast<uint16_t *>(lds + OFF_PARENT);
-    uint8_t *size8 = lds + OFF_SIZE;
+    uint16_t *size16 = reinterpret_cast<uint16_t *>(lds + OFF_SIZE);
+    uint32_t *size32 = reinterpret_cast<uint32_t *>(lds + OFF_SIZE);
+    uint16_t *list = reinterpret_cast<uint16_t *>(lds + OFF_LIST);
+    uint32_t *mk = reinterpret_cast<uint32_t *>(lds + OFF_MASK);
+    uint32_t *misc = reinterpret_cast<uint32_t *>(lds + OFF_MISC); // [0..3] wave run counts, [5] pooled links, [6] ring-touching roots
+    if (tid == 0) misc[6] = 0; // (the barrier after P0 publishes it)
+
+    // Whole 4x4 tiles only enter the min/max (the oracle's rule); pixels right of / below the last whole one take its
+    // threshold.  Normally the threshold grid of a workgroup tile starts at its own first 4x4 column / row (c4x, c4y); when the
+    // last workgroup tile has only 1..3 columns / rows, that 4x4 tile lies in the tile on the left / above and the grids
+    // start one 4x4 tile earlier.  The staged window always starts 16 columns left of the tile (aligned 16-byte chunks) and
+    // one 4x4 row above the min/max grid.
+    const int w4 = w >> 2, h4 = h >> 2;
+    const int c4x = min(tx0 >> 2, w4 - 1), c4y = min(ty0 >> 2, h4 - 1); // first 4x4 column / row of the threshold grid
+    const int sx0 = tx0 - 16, sy0 = 4 * (c4y - 1);                       // frame coordinates of staged byte (0, 0)
+    const int yoff = ty0 - sy0;                                          // staged row of tile row 0: 4 (8 in the ragged last tile row)
+    const int xb = 4 * (c4x - 1) - sx0;                                  // staged byte of min/max column 0: 12 (8 when ragged)
 
     TPROF_DECL;
-    // ---- P0: stage the tile and its 4-pixel halo ----------------------------------------------------------
-    for (int item = tid; item < IMG_ROWS * 8; item += KNT) {
-        int r = item >> 3, c = item & 7;
-        int gy = ty0 - 4 + r, gx = tx0 + 16 * c;
+    // ---- P0: stage the tile and its halo: IMG_ROWS rows of ten 16-byte chunks (16 left | 128 | 16 right) ------------
+    for (int item = tid; item < IMG_ROWS * 10; item += KNT) {
+        const int r = item / 10, c = item - r * 10;
+        const int gy = sy0 + r, gx = sx0 + 16 * c;
         uint4 v = make_uint4(0, 0, 0, 0);
-        if (gy >= 0 && gy < h) {
-            const uint8_t *src = img + (size_t)gy * stride + gx;
-            if (gx + 16 <= w) v = *reinterpret_cast<const uint4 *>(src);
-            else {
-                if (gx + 4 <= w) v.x = *reinterpret_cast<const uint32_t *>(src);
-                if (gx + 8 <= w) v.y = *reinterpret_cast<const uint32_t *>(src + 4);
-                if (gx + 12 <= w) v.z = *reinterpret_cast<const uint32_t *>(src + 8);
-            }
-        }
-        *reinterpret_cast<uint4 *>(lds + OFF_IMG + r * IMG_PITCH + 16 + 16 * c) = v;
-    }
-    for (int item = tid; item < IMG_ROWS * 2; item += KNT) {
-        int r = item >> 1, side = item & 1;
-        int gy = ty0 - 4 + r, gx = side ? tx0 + TW : tx0 - 4;
-        uint32_t v = 0;
-        if (gy >= 0 && gy < h && gx >= 0 && gx + 4 <= w)
-            v = *reinterpret_cast<const uint32_t *>(img + (size_t)gy * stride + gx);
-        *reinterpret_cast<uint32_t *>(lds + OFF_IMG + r * IMG_PITCH + (side ? 16 + TW : 12)) = v;
+        // rows are padded to 16 bytes (frame strides are multiples of 16): a chunk that starts inside the row is readable
+        if (gy >= 0 && gy < h && gx >= 0 && gx < w) v = *reinterpret_cast<const uint4 *>(img + (size_t)gy * stride + gx);
+        *reinterpret_cast<uint4 *>(lds + OFF_IMG + r * IMG_PITCH + 16 * c) = v;
     }
     __syncthreads();
     TPROF(0);
 
     if (stop_after == 0) return; // diagnostics (CK_TILE_STOP_AFTER)
-    // ---- P1: min/max of every 4x4 tile of the staged region -------------------------------------------
+    // ---- P1: min/max of the 4x4 tiles: grid column j = 4x4 column c4x - 1 + j, row i = 4x4 row c4y - 1 + i ----------
     uint16_t *minmax = reinterpret_cast<uint16_t *>(lds + OFF_MINMAX);
-    const int w4 = w >> 2, h4 = h >> 2;
     if (!PRE)
     for (int item = tid; item < T4Y * T4X; item += KNT) {
-        int i = item / T4X, j = item - i * T4X;
-        int g4x = (tx0 >> 2) - 1 + j, g4y = (ty0 >> 2) - 1 + i;
+        const int i = item / T4X, j = item - i * T4X;
+        const int g4x = c4x - 1 + j, g4y = c4y - 1 + i;
         uint32_t mn = 255, mx = 0;
         if (g4x >= 0 && g4x < w4 && g4y >= 0 && g4y < h4) {
 #pragma unroll
             for (int rr = 0; rr < 4; rr++) {
-                uint32_t d = *reinterpret_cast<const uint32_t *>(lds + OFF_IMG + (4 * i + rr) * IMG_PITCH + 12 + 4 * j);
+                uint32_t d = *reinterpret_cast<const uint32_t *>(lds + OFF_IMG + (4 * i + rr) * IMG_PITCH + xb + 4 * j);
 #pragma unroll
                 for (int b = 0; b < 4; b++) {
                     uint32_t v = (d >> (8 * b)) & 255u;
@@ -227,11 +246,11 @@ __global__ __launch_bounds__(KNT) void k_tile(const uint8_t *__restrict__ frames
     }
     __syncthreads();
 
-    // ---- P2: 3x3 dilation -> per-4x4-tile threshold word (bit 8 = low contrast) ---------------------------
+    // ---- P2: 3x3 dilation -> per-4x4-tile threshold word (bit 8 = low contrast); column j = 4x4 column c4x + j -------
     uint16_t *thr = reinterpret_cast<uint16_t *>(lds + OFF_THR);
     if (!PRE)
     for (int item = tid; item < (TH / 4) * (TW / 4); item += KNT) {
-        int i = item / (TW / 4), j = item - i * (TW / 4);
+        const int i = item / (TW / 4), j = item - i * (TW / 4);
         uint32_t mn = 255, mx = 0;
 #pragma unroll
         for (int di = 0; di < 3; di++)
@@ -247,29 +266,36 @@ __global__ __launch_bounds__(KNT) void k_tile(const uint8_t *__restrict__ frames
     TPROF(1);
 
     if (stop_after == 1) return; // diagnostics (CK_TILE_STOP_AFTER)
-    // ---- P3: threshold 16 pixels per item, write them, build the per-row colour masks ----------------------
-    uint16_t *mask16 = reinterpret_cast<uint16_t *>(lds + OFF_MASK); // [r][seg][colour][piece]
-    for (int item = tid; item < TH * 8; item += KNT) {
-        int r = item >> 3, c = item & 7;
-        int gy = ty0 + r, gx = tx0 + 16 * c;
-        uint4 px = *reinterpret_cast<const uint4 *>(lds + OFF_IMG + (r + 4) * IMG_PITCH + 16 + 16 * c);
+    // ---- P3: threshold 16 pixels per thread, write them, build the rows' colour words -------------------------------
+    uint16_t *mask16 = reinterpret_cast<uint16_t *>(lds + OFF_MASK); // [r][word][colour][half]
+    const bool packed_rows = (w & 3) == 0; // rows of thresh[] / labels[] start 4-pixel aligned: vector stores
+    uint32_t any_colour = 0;
+    {
+        const int r = tid >> 3, c = tid & 7;
+        const int gy = ty0 + r, gx = tx0 + 16 * c;
+        uint4 px = *reinterpret_cast<const uint4 *>(lds + OFF_IMG + (r + yoff) * IMG_PITCH + 16 + 16 * c);
         uint32_t in[4] = {px.x, px.y, px.z, px.w}, out[4];
         uint32_t wbits = 0, bbits = 0;
-        // the one to three rows below the last whole 4x4 tile take that tile's threshold (the oracle's ragged-edge rule);
-        // ck_create refuses the heights whose last whole tile row belongs to the workgroup above
-        const int r4 = min((ty0 + r) >> 2, h4 - 1) - (ty0 >> 2);
+        const int r4 = min(gy >> 2, h4 - 1) - c4y;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            uint32_t tw_ = PRE ? 0u : thr[r4 * (TW / 4) + 4 * c + k];
+            const int x = gx + 4 * k;
+            uint32_t tw_ = PRE ? 0u : thr[r4 * (TW / 4) + min(x >> 2, w4 - 1) - c4x];
             uint32_t o;
-            if (gy >= h || gx + 4 * k >= w) o = 0x7F7F7F7Fu;      // outside the frame: no colour
-            else if (PRE) o = in[k];
-            else if (tw_ & 0x100u) o = 0x7F7F7F7Fu;
+            if (gy >= h || x >= w) o = 0x7F7F7F7Fu;      // outside the frame: no colour
             else {
-                o = 0;
+                if (PRE) o = in[k];
+                else if (tw_ & 0x100u) o = 0x7F7F7F7Fu;
+                else {
+                    o = 0;
 #pragma unroll
-                for (int b = 0; b < 4; b++)
-                    if (((in[k] >> (8 * b)) & 255u) > tw_) o |= 0xFFu << (8 * b);
+                    for (int b = 0; b < 4; b++)
+                        if (((in[k] >> (8 * b)) & 255u) > tw_) o |= 0xFFu << (8 * b);
+                }
+                if (x + 4 > w) { // the frame ends inside this group (width not a multiple of 4)
+                    const uint32_t keep = 0xFFFFFFFFu >> (8 * (x + 4 - w));
+                    o = (o & keep) | (0x7F7F7F7Fu & ~keep);
+                }
             }
             out[k] = o;
             wbits |= msb_nibble(o) << (4 * k);                     // 255 -> bit 7 set
@@ -277,333 +303,272 @@ __global__ __launch_bounds__(KNT) void k_tile(const uint8_t *__restrict__ frames
         }
         if (gy < h && gx < w) {
             uint8_t *dst = thresh + fbase + (size_t)gy * w + gx;
-            if (gx + 16 <= w && (w & 15) == 0) *reinterpret_cast<uint4 *>(dst) = make_uint4(out[0], out[1], out[2], out[3]);
-            else
+            if (packed_rows && gx + 16 <= w && (w & 15) == 0) *reinterpret_cast<uint4 *>(dst) = make_uint4(out[0], out[1], out[2], out[3]);
+            else if (packed_rows) {
 #pragma unroll
                 for (int k = 0; k < 4; k++)
                     if (gx + 4 * k < w) *reinterpret_cast<uint32_t *>(dst + 4 * k) = out[k];
+            } else {
+                for (int k = 0; k < 16; k++)
+                    if (gx + k < w) dst[k] = (uint8_t)(out[k >> 2] >> (8 * (k & 3)));
+            }
         }
-        int seg = c / MPIECES, piece = c % MPIECES;
-        mask16[((r * NSEG + seg) * 2 + 0) * MPIECES + piece] = (uint16_t)wbits;
-        mask16[((r * NSEG + seg) * 2 + 1) * MPIECES + piece] = (uint16_t)bbits;
+        const int wd = c >> 1, half = c & 1;
+        mask16[(((r * NWD + wd) * 2 + 0) << 1) + half] = (uint16_t)wbits;
+        mask16[(((r * NWD + wd) * 2 + 1) << 1) + half] = (uint16_t)bbits;
+        any_colour = wbits | bbits;
     }
-    __syncthreads();
+    // a tile without a coloured pixel (a background below min_white_black_diff) has nothing to segment
+    const int tile_has_runs = __syncthreads_or((int)any_colour);
     TPROF(2);
 
     if (stop_after == 2) return; // diagnostics (CK_TILE_STOP_AFTER)
-    // ---- P4: the image scratch is dead; it becomes the parent array (parent[i] = i), sizes start at zero -------------
-    for (int i = tid * 8; i < TH * TW; i += KNT * 8) {
-        const uint32_t lo = (uint32_t)i | ((uint32_t)(i + 1) << 16);
-        *reinterpret_cast<uint4 *>(&parent[i]) = make_uint4(lo, lo + 0x00020002u, lo + 0x00040004u, lo + 0x00060006u);
-    }
-    // (the size bytes are zeroed after P5b: until then their 8 KB hold the waves' link pools)
-
-    // ---- P5: unions.  thread = (colour, row, segment) --------------------------------------------------------------
-    const mask_t *masks = reinterpret_cast<const mask_t *>(lds + OFF_MASK);
-    const int color = tid / (KNT / 2), sitem = tid % (KNT / 2);
-    const int r = sitem / NSEG, s = sitem - r * NSEG;
-    const int x0 = tx0 + SEGW * s;
-    const mask_t M = masks[(r * NSEG + s) * 2 + color];
-    const mask_t O = origin_mask(x0, w);
-    const mask_t S = M & ~((M << 1) & O); // segment-local run starts
-    const uint32_t base = (uint32_t)(r * TW + SEGW * s);
-    // Events of this segment: every link from one of its runs to a run that comes earlier in scan order
-    //   hleft : bit 0 continues the run that ends the segment on the left
-    //   Ev    : vertical links (first column of every stretch where this row and the row above overlap)
-    //   DL/DR : white only, diagonal links not already implied by a vertical one
-    mask_t Ev = 0, DL = 0, DR = 0, U = 0, Su = 0, Ul = 0;
-    uint32_t left_node = 0;
-    bool hleft = false;
-    if (M) {
-        if (s > 0 && (M & O & MONE)) {
-            mask_t Ml = masks[(r * NSEG + s - 1) * 2 + color];
-            if (Ml >> (SEGW - 1)) {
-                mask_t Ol = origin_mask(x0 - SEGW, w);
-                mask_t Sl = Ml & ~((Ml << 1) & Ol);
-                left_node = base - SEGW + (uint32_t)(SEGW - 1 - mclz(Sl));
-                hleft = true;
-            }
-        }
-        if (r > 0) {
-            U = masks[((r - 1) * NSEG + s) * 2 + color];
-            Su = U & ~((U << 1) & O);
-            mask_t V = M & U & O;
-            Ev = V & ~(V << 1);
-            if (color == 0) {
-                mask_t Ur = 0;
-                if (s > 0) Ul = masks[((r - 1) * NSEG + s - 1) * 2];
-                if (s < NSEG - 1) Ur = masks[((r - 1) * NSEG + s + 1) * 2];
-                int xn = x0 + SEGW; // origin flag of the column right of this segment
-                mask_t On = (xn >= 1 && xn <= w - 2) ? MONE : (mask_t)0;
-                mask_t MO = M & O;
-                DL = MO & ((U << 1) | (Ul >> (SEGW - 1))) & ~U & ~(MO << 1);
-                DR = MO & ((U >> 1) | (Ur << (SEGW - 1))) & ~(U & ((O >> 1) | (On << (SEGW - 1)))) & ~(MO >> 1);
-            }
-        }
-    }
-    auto up_left_node = [&](int i) -> uint32_t { // run of the pixel up-left of bit i
-        if (i > 0) return base - TW + (uint32_t)run_start(Su, i - 1);
-        mask_t Ol = origin_mask(x0 - SEGW, w);
-        mask_t Sl = Ul & ~((Ul << 1) & Ol);
-        return base - TW - SEGW + (uint32_t)(SEGW - 1 - mclz(Sl));
-    };
-    auto up_right_node = [&](int i) -> uint32_t { // bit 0 of the segment on the right always starts a run
-        return (i < SEGW - 1) ? base - TW + (uint32_t)run_start(Su, i + 1) : base - TW + SEGW;
-    };
-#ifdef CK_TILE_PROFILE
-    unsigned long long tu0 = __builtin_readcyclecounter();
-#define TU(k) do { unsigned long long t_ = __builtin_readcyclecounter(); if (tid == 0) atomicAdd(&g_tile_prof2[k], t_ - tu0); tu0 = t_; } while (0)
-#else
-#define TU(k)
-#endif
-    __syncthreads(); // parent[] initialised everywhere before the first adoption lands
-    TU(0);
-    if (stop_after == 3) return; // diagnostics (CK_TILE_STOP_AFTER)
-    // ---- P5a: every run adopts ONE earlier run as its parent with a plain store.  Only the owner writes the entry
-    // and nothing reads parent[] in this phase, so no find and no atomic is needed for these links; the target always
-    // has a smaller index, which keeps the forest invariant (parent <= self) the atomic phase relies on.
+    uint32_t nruns = 0;
+    if (tile_has_runs) {
+    // ---- P4: the tile's runs as a list, in scan order: thread = (row, word, colour) -----------------------------------
     {
-        mask_t St = S;
-        while (St) {
-            const mask_t low = St & ((mask_t)0 - St); // this run's start bit
-            const int i = mctz(low);
-            St ^= low;
-            const mask_t span = (St & ((mask_t)0 - St)) - low; // bits from this start up to the next one (or to the top: 0 - low)
-            mask_t e;
-            if ((e = Ev & span)) { int j = mctz(e); Ev &= ~(MONE << j); parent[base + i] = (uint16_t)(base - TW + (uint32_t)run_start(Su, j)); }
-            else if ((e = DL & span)) { int j = mctz(e); DL &= ~(MONE << j); parent[base + i] = (uint16_t)up_left_node(j); }
-            else if ((e = DR & span)) { int j = mctz(e); DR &= ~(MONE << j); parent[base + i] = (uint16_t)up_right_node(j); }
-            else if (i == 0 && hleft) { hleft = false; parent[base] = (uint16_t)left_node; }
+        const int r = tid >> 3, wd = (tid >> 1) & 3, c = tid & 1;
+        uint32_t S = ck_starts32(mk[tid], ck_origin32(tx0 + 32 * wd, w)); // mk index (r*NWD + wd)*2 + c == tid
+        const uint32_t cnt = (uint32_t)__popc(S);
+        const uint32_t incl = wave_scan_u32(cnt);
+        if ((tid & 63) == 63) misc[tid >> 6] = incl;
+        __syncthreads();
+        uint32_t off = incl - cnt;
+        const int wv = tid >> 6;
+        if (wv > 0) off += misc[0];
+        if (wv > 1) off += misc[1];
+        if (wv > 2) off += misc[2];
+        nruns = misc[0] + misc[1] + misc[2] + misc[3];
+        const uint32_t base = (uint32_t)(r * TW + 32 * wd) | ((uint32_t)c << 12);
+        while (S) {
+            list[off++] = (uint16_t)(base + (uint32_t)__builtin_ctz(S));
+            S &= S - 1u;
         }
+        if (tid == 0) misc[5] = 0;
     }
-    TU(1);
-    __syncthreads();
-    TU(2);
-    if (stop_after == 4 || stop_after == 5) return; // diagnostics (CK_TILE_STOP_AFTER)
-    // ---- P5b: the remaining links (a run touching a second, third ... earlier run) go through the atomic union
-#ifdef CK_TILE_PROFILE
-    uint32_t tcnt = 0, tun = 0;
-#define TUN ++tun
-#else
-#define TUN
-#endif
-    // The links of a wave are pooled and dealt out evenly: a lane with eight links no longer holds 63 others up — the wave runs
-    // ceil(links / 64) union slots (3-4 in a noisy tile) instead of max-over-lanes(links) (7-8), and every slot costs the deepest
-    // find in the wave.  The pool is the wave's quarter of the (not yet used) size array: POOL links of two u16 nodes; links
-    // that do not fit stay with their lane and are joined the old way.
-    {
-        constexpr int POOL = TH * TW / (KNT / 64) / 4; // u32 entries per wave
-        uint32_t *pool = reinterpret_cast<uint32_t *>(size8) + (tid >> 6) * POOL;
-        const uint32_t mine = (hleft ? 1u : 0u) + (uint32_t)mpopc(Ev) + (uint32_t)mpopc(DL) + (uint32_t)mpopc(DR);
-        const uint32_t incl = wave_scan_u32(mine);
-        const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-        uint32_t pos = incl - mine;
-        while ((hleft || Ev || DL || DR) && pos < (uint32_t)POOL) {
-            uint32_t ua, ub;
-            if (hleft) { hleft = false; ua = base; ub = left_node; }
-            else if (Ev) { int i = mctz(Ev); Ev &= Ev - 1; ua = base + run_start(S, i); ub = base - TW + run_start(Su, i); }
-            else if (DL) { int i = mctz(DL); DL &= DL - 1; ua = base + run_start(S, i); ub = up_left_node(i); }
-            else { int i = mctz(DR); DR &= DR - 1; ua = base + run_start(S, i); ub = up_right_node(i); }
-            pool[pos++] = ua | (ub << 16);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        const uint32_t pooled = total < (uint32_t)POOL ? total : (uint32_t)POOL;
-        for (uint32_t j = (uint32_t)(tid & 63); j < pooled; j += 64) {
-            const uint32_t e = pool[j];
-            TUN;
-            lds_union(parent, e & 0xFFFFu, e >> 16 TCNT_PASS);
-        }
-        while (hleft || Ev || DL || DR) { // overflow of the pool (pathological tiles only)
-            uint32_t ua, ub;
-            if (hleft) { hleft = false; ua = base; ub = left_node; }
-            else if (Ev) { int i = mctz(Ev); Ev &= Ev - 1; ua = base + run_start(S, i); ub = base - TW + run_start(Su, i); }
-            else if (DL) { int i = mctz(DL); DL &= DL - 1; ua = base + run_start(S, i); ub = up_left_node(i); }
-            else { int i = mctz(DR); DR &= DR - 1; ua = base + run_start(S, i); ub = up_right_node(i); }
-            TUN;
-            lds_union(parent, ua, ub TCNT_PASS);
-        }
-    }
-    TU(3);
-    __syncthreads();
-    TU(4);
-    for (int i = tid * 16; i < TH * TW; i += KNT * 16) *reinterpret_cast<uint4 *>(size8 + i) = make_uint4(0, 0, 0, 0); // pools -> sizes
+    __syncthreads(); // the list is complete; the image scratch is dead from here on: it becomes the parent array
     TPROF(3);
-#ifdef CK_TILE_PROFILE
-    {   // [8] unions, [9] find2 iterations summed over lanes, [10] per-wave maximum of a lane's find2 iterations
-        uint32_t su = tun, sc = tcnt, mx = tcnt;
-        for (int o = 32; o; o >>= 1) { su += __shfl_xor(su, o); sc += __shfl_xor(sc, o); mx = max(mx, (uint32_t)__shfl_xor(mx, o)); }
-        if ((tid & 63) == 0) { atomicAdd(&g_tile_prof[8], su); atomicAdd(&g_tile_prof[9], sc); atomicAdd(&g_tile_prof[10], mx); }
-    }
-    uint32_t wruns = 0, whops = 0, wit = 0;
-#endif
+    if (stop_after == 3) return; // diagnostics (CK_TILE_STOP_AFTER)
 
-    __syncthreads(); // halving stores must land before the owners publish final roots
-    if (stop_after == 6) return; // diagnostics (CK_TILE_STOP_AFTER)
-    // ---- P6: flatten run starts, accumulate sizes and ring flags at the roots ---------------------------------------
-    {
-        const bool ring_row = (r == 0 && ty0 > 0) || (r == TH - 1 && ty0 + TH < h);
-        mask_t St = S;
-        // consecutive runs of a segment usually end at the same root (in a noisy tile nearly every white run belongs to
-        // the one spanning component): their pixels are summed in registers and flushed once per change of root
-        uint32_t acc_root = 0xFFFFFFFFu, acc_add = 0;
-        bool acc_ring = false;
-#ifdef CK_TILE_PROFILE
-        unsigned long long tq0 = __builtin_readcyclecounter(), tq_ext = 0, tq_walk = 0, tq_tail = 0;
-#define TQ(acc) do { unsigned long long t_ = __builtin_readcyclecounter(); acc += t_ - tq0; tq0 = t_; } while (0)
-#else
-#define TQ(acc)
-#endif
-        while (St) { // four runs per round: their root walks proceed in lockstep
-            uint32_t node[4], root[4], add[4];
-            bool ring[4], live[4];
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                live[q] = St != 0;
-                node[q] = base; add[q] = 0; ring[q] = false;
-                if (live[q]) {
-                    const mask_t low = St & ((mask_t)0 - St); // this run's start bit
-                    const int i = mctz(low);
-                    St ^= low;
-                    const mask_t span = (St & ((mask_t)0 - St)) - low; // up to the next start (or to the top: 0 - low)
-                    mask_t run = M & span;
-                    node[q] = base + i;
-                    add[q] = (uint32_t)mpopc(run);
-                    ring[q] = ring_row || (s == 0 && tx0 > 0 && (run & MONE)) || (s == NSEG - 1 && tx0 + TW < w && (run >> (SEGW - 1)));
-                }
-                root[q] = node[q];
+    // ---- P5a: adoption.  One lane per run: its first link to an earlier run becomes its parent with a plain store (only the
+    // owner writes the entry, nothing reads parent[] in this phase: no find, no atomic; the target has a smaller index, which
+    // keeps the forest invariant parent <= self).  The other links go to the pool.
+    uint32_t *pool = size32;
+    for (uint32_t j0 = 0; j0 < nruns; j0 += KNT) {
+        const uint32_t j = j0 + (uint32_t)tid;
+        const bool live = j < nruns;
+        RunView v = view_run(mk, list[live ? j : 0u], tx0, w); // (a lane past the end looks at run 0 and writes nothing)
+        const uint32_t nl = links_left(v);
+        const uint32_t first = take_link(v, v.p);
+        if (live) parent[v.p] = (uint16_t)first;
+        uint32_t extra = (live && nl) ? nl - 1u : 0u;
+        const uint32_t incl = wave_scan_u32(extra);
+        const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        if (total) { // one reservation per wave and round
+            uint32_t wb = 0;
+            if ((tid & 63) == 63) wb = atomicAdd(&misc[5], total);
+            wb = (uint32_t)__builtin_amdgcn_readlane((int)wb, 63);
+            uint32_t pos = wb + incl - extra;
+            while (extra) {
+                const uint32_t t = take_link(v, v.p);
+                if (pos < (uint32_t)POOL_CAP) pool[pos] = v.p | (t << 16);
+                pos++; extra--;
             }
-            TQ(tq_ext);
-            // plain loads behind a compiler barrier: the four reads of a step are independent and go out together (as volatile
-            // reads each one was waited for before the next was issued: four LDS round trips per step instead of one)
-            const uint16_t *vp = parent;
-            for (int it = 0; it < 8192; it++) {
-                __asm__ volatile("" ::: "memory");
-                uint32_t n0 = vp[root[0]], n1 = vp[root[1]], n2 = vp[root[2]], n3 = vp[root[3]];
-#ifdef CK_TILE_PROFILE
-                wit++; whops += (n0 != root[0]) + (n1 != root[1]) + (n2 != root[2]) + (n3 != root[3]);
-#endif
-                if (n0 == root[0] && n1 == root[1] && n2 == root[2] && n3 == root[3]) break;
-                root[0] = n0; root[1] = n1; root[2] = n2; root[3] = n3;
-            }
-            TQ(tq_walk);
-#pragma unroll
-            for (int q = 0; q < 4; q++)
-                if (live[q]) {
-#ifdef CK_TILE_PROFILE
-                    wruns++;
-#endif
-                    parent[node[q]] = (uint16_t)root[q];
-                    if (root[q] == acc_root) { acc_add += add[q]; acc_ring = acc_ring || ring[q]; }
-                    else {
-                        if (acc_root != 0xFFFFFFFFu) lds_size_add(size8, acc_root, acc_add, acc_ring);
-                        acc_root = root[q]; acc_add = add[q]; acc_ring = ring[q];
-                    }
-                }
-            TQ(tq_tail);
         }
-        if (acc_root != 0xFFFFFFFFu) lds_size_add(size8, acc_root, acc_add, acc_ring);
-#ifdef CK_TILE_PROFILE
-        if (tid == 0) { atomicAdd(&g_tile_prof[14], tq_ext); atomicAdd(&g_tile_prof[15], tq_walk); atomicAdd(&g_tile_prof[7], tq_tail); }
-#endif
     }
     __syncthreads();
     TPROF(4);
-#ifdef CK_TILE_PROFILE
-    {   // [11] runs, [12] hops summed over lanes, [13] per-wave maximum of a lane's walk iterations
-        uint32_t sr = wruns, sh = whops, mx = wit;
-        for (int o = 32; o; o >>= 1) { sr += __shfl_xor(sr, o); sh += __shfl_xor(sh, o); mx = max(mx, (uint32_t)__shfl_xor(mx, o)); }
-        if ((tid & 63) == 0) { atomicAdd(&g_tile_prof[11], sr); atomicAdd(&g_tile_prof[12], sh); atomicAdd(&g_tile_prof[13], mx); }
+    if (stop_after == 4) return; // diagnostics (CK_TILE_STOP_AFTER)
+    // ---- P5b: one pointer-jumping sweep over the (static) adoption forest, in scan order: a run's parent lies in an earlier
+    // row (or earlier in its own), which the sweep has usually flattened by the time the run is reached, so the chains
+    // down a tag edge (one hop per row) collapse before the finds of the next two phases walk them
+    for (uint32_t j = (uint32_t)tid; j < nruns; j += KNT) {
+        const uint32_t p = list[j] & 0xFFFu;
+        const uint32_t q = parent[p];
+        const uint32_t g = parent[q];
+        if (g != q) parent[p] = (uint16_t)g;
     }
-#endif
+    __syncthreads();
+    TPROF(5);
+    if (stop_after == 5) return; // diagnostics (CK_TILE_STOP_AFTER)
+    // ---- P5c: the pooled links, one lane per link, through the atomic union ------------------------------------------
+    const uint32_t npool = misc[5];
+    {
+        const uint32_t pooled = npool < (uint32_t)POOL_CAP ? npool : (uint32_t)POOL_CAP;
+        for (uint32_t j = (uint32_t)tid; j < pooled; j += KNT) {
+            const uint32_t e = pool[j];
+            lds_union(parent, e & 0xFFFFu, e >> 16);
+        }
+        if (npool > (uint32_t)POOL_CAP) // more links than the pool holds (pathological maps): every run joins all its links again
+            for (uint32_t j = (uint32_t)tid; j < nruns; j += KNT) {
+                RunView v = view_run(mk, list[j], tx0, w);
+                for (uint32_t nl = links_left(v); nl; nl--) lds_union(parent, v.p, take_link(v, v.p));
+            }
+    }
+    __syncthreads(); // halving stores must land before the owners publish final roots; the pool is dead
+    TCOUNT(9, nruns); TCOUNT(10, npool);
+    TPROF(6);
+    if (stop_after == 6) return; // diagnostics (CK_TILE_STOP_AFTER)
+    for (int i = tid * 4; i < TH * TW / 2; i += KNT * 4) *reinterpret_cast<uint4 *>(size32 + i) = make_uint4(0, 0, 0, 0); // pool -> sizes
+    __syncthreads();
+    // ---- P6: flatten the runs' entries and add their pixels (and ring flags) at the roots; two runs per lane and round so
+    // that two root walks are in flight (a lane past the end walks run 0 again and writes nothing)
+    for (uint32_t j0 = 0; j0 < nruns; j0 += 2 * KNT) {
+        uint32_t node[2], root[2], add[2];
+        bool live[2];
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const uint32_t j = j0 + (uint32_t)(q * KNT + tid);
+            live[q] = j < nruns;
+            const uint32_t e = list[live[q] ? j : 0u];
+            const uint32_t p = e & 0xFFFu, c = e >> 12;
+            const int r = (int)(p >> 7), wd = (int)(p >> 5) & 3, i = (int)(p & 31u);
+            const uint32_t M = mk[(int)((p >> 5) << 1) + (int)c];
+            const uint32_t R = ck_run_bits32(M, ck_starts32(M, ck_origin32(tx0 + 32 * wd, w)), i);
+            const bool ring = ((r == 0) & (ty0 > 0)) | ((r == TH - 1) & (ty0 + TH < h)) | ((wd == 0) & (tx0 > 0) & ((R & 1u) != 0)) |
+                              ((wd == NWD - 1) & (tx0 + TW < w) & ((R >> 31) != 0));
+            node[q] = p; root[q] = p;
+            add[q] = (uint32_t)__popc(R) | (ring ? 0x8000u : 0u);
+        }
+        for (int it = 0; it < TH * TW; it++) { // plain loads behind a compiler barrier: the two reads of a step go out together
+            __asm__ volatile("" ::: "memory");
+            const uint32_t n0 = parent[root[0]], n1 = parent[root[1]];
+            if (n0 == root[0] && n1 == root[1]) break;
+            root[0] = n0; root[1] = n1;
+        }
+#pragma unroll
+        for (int q = 0; q < 2; q++)
+            if (live[q]) {
+                parent[node[q]] = (uint16_t)root[q];
+                // one add carries the count and the ring bit: counts stay below 2^15 (a tile has 4096 pixels) ... but the ring bit
+                // must be OR-ed, not added (several ring runs of one component)
+                const uint32_t sh = (root[q] & 1u) * 16u;
+                atomicAdd(&size32[root[q] >> 1], (add[q] & 0x7FFFu) << sh);
+                if (add[q] & 0x8000u) atomicOr(&size32[root[q] >> 1], 0x8000u << sh);
+            }
+    }
+    __syncthreads();
+    } // tile_has_runs
+    TPROF(7);
 
     if (stop_after == 7) return; // diagnostics (CK_TILE_STOP_AFTER)
-    // ---- P7: write label words (16 pixels per item) -------------------------------------------------------------------
-    const uint32_t nitems = TH * 8;
-    for (uint32_t item0 = 0; item0 < nitems; item0 += KNT) { // uniform trip count: the ring-root append below votes per wave
-        const int item = (int)item0 + tid;
-        int rr = item >> 3, c = item & 7;
-        int gy = ty0 + rr, gx = tx0 + 16 * c;
-        uint32_t nroots = 0;
-        uint32_t roots_mask = 0;
-        uint32_t outw[16];
-        const bool inside = gy < h && gx < w;
-        int seg = c / MPIECES, piece = c % MPIECES;
-        uint32_t sbase = (uint32_t)(rr * TW + SEGW * seg);
-        if (inside) {
-            mask_t Wm = masks[(rr * NSEG + seg) * 2], Bm = masks[(rr * NSEG + seg) * 2 + 1];
-            mask_t Oo = origin_mask(tx0 + SEGW * seg, w);
-            mask_t SW = Wm & ~((Wm << 1) & Oo), SB = Bm & ~((Bm << 1) & Oo);
-            // everything below works on the 16 bits of this chunk with compile-time shifts (the kernel is bound by
-            // instruction issue): colour bits, run-start bits, and for each colour the node of the run that is already
-            // open when the chunk begins
-            const int sh = 16 * piece;
-            const uint32_t w16 = (uint32_t)(Wm >> sh) & 0xFFFFu, b16 = (uint32_t)(Bm >> sh) & 0xFFFFu;
-            const uint32_t sw16 = (uint32_t)(SW >> sh) & 0xFFFFu, sb16 = (uint32_t)(SB >> sh) & 0xFFFFu;
-            const mask_t lowmask = (MONE << sh) - MONE; // sh <= SEGW - 16
-            const mask_t lw = SW & lowmask, lb = SB & lowmask;
-            const uint32_t carryW = sbase + (lw ? (uint32_t)(SEGW - 1 - mclz(lw)) : 0u);
-            const uint32_t carryB = sbase + (lb ? (uint32_t)(SEGW - 1 - mclz(lb)) : 0u);
-            const uint32_t cbase = sbase + (uint32_t)sh;
-            const uint32_t gbase = (uint32_t)ty0 * (uint32_t)w + (uint32_t)tx0;
-            // Straight-line code, no exec-mask regions: a pixel's run starts at the nearest start bit of EITHER colour at or
-            // below it (a start of the other colour cannot lie inside a run), or before the chunk (then the run has the colour
-            // of pixel 0 and the carried node of that colour).  Uncoloured pixels look up a harmless in-range node.
-            const uint32_t any16 = w16 | b16, st16 = sw16 | sb16;
-            uint32_t cur = (w16 & 1u) ? carryW : carryB;
-            uint32_t nodev[16], rootv[16], sizev[16];
+    // ---- P7: write label words.  Four passes; in pass q lane L owns the 4-pixel group q*256 + L of the tile's 1024, so that a
+    // wave's store instruction covers 1 KiB of contiguous label words and its LDS lookups spread over the banks
+    uint32_t roots_all = 0; // 4 bits per pass: which pixels of the lane's group are ring-touching roots
 #pragma unroll
-            for (int k = 0; k < 16; k++) {
-                cur = ((st16 >> k) & 1u) ? cbase + (uint32_t)k : cur;
+    for (int q = 0; q < 4; q++) {
+        const int gi = q * KNT + tid, rr = gi >> 5, g = gi & 31, wd = g >> 3, sh = 4 * (g & 7);
+        const int gy = ty0 + rr, gx = tx0 + 4 * g;
+        if (gy >= h || gx >= w) continue;
+        const uint32_t wbase = (uint32_t)(rr * TW + 32 * wd), cbase = wbase + (uint32_t)sh;
+        const uint2 wb = *reinterpret_cast<const uint2 *>(&mk[(rr * NWD + wd) * 2]);
+        const uint32_t Wm = wb.x, Bm = wb.y;
+        const uint32_t w4 = (Wm >> sh) & 15u, b4 = (Bm >> sh) & 15u, any4 = w4 | b4;
+        uint32_t outw[4] = {CK_LBL_INVALID, CK_LBL_INVALID, CK_LBL_INVALID, CK_LBL_INVALID};
+        if (any4) {
+            const uint32_t Oo = ck_origin32(tx0 + 32 * wd, w);
+            const uint32_t SW = ck_starts32(Wm, Oo), SB = ck_starts32(Bm, Oo);
+            const uint32_t st4 = ((SW | SB) >> sh) & 15u;
+            // the run that is already open when the group begins: nearest start below it in the word, per colour
+            const uint32_t below = (1u << sh) - 1u;
+            const uint32_t carryW = wbase + (uint32_t)ck_last_start32(SW & below), carryB = wbase + (uint32_t)ck_last_start32(SB & below);
+            // a pixel's run starts at the nearest start bit of EITHER colour at or below it (a start of the other colour cannot lie
+            // inside a run), or before the group (then the run has the colour of pixel 0 and the carried node of that colour).
+            // An uncoloured pixel looks up a harmless in-range node.
+            uint32_t cur = (w4 & 1u) ? carryW : carryB;
+            uint32_t nodev[4], rootv[4], sizev[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                cur = ((st4 >> k) & 1u) ? cbase + (uint32_t)k : cur;
                 nodev[k] = cur;
             }
 #pragma unroll
-            for (int k = 0; k < 16; k++) rootv[k] = parent[nodev[k]];
+            for (int k = 0; k < 4; k++) rootv[k] = parent[nodev[k]] & (uint32_t)(TH * TW - 1); // (an uncoloured pixel's node is no run start: its entry is undefined)
 #pragma unroll
-            for (int k = 0; k < 16; k++) sizev[k] = size8[rootv[k]];
+            for (int k = 0; k < 4; k++) sizev[k] = size16[rootv[k]];
+            const uint32_t gbase = (uint32_t)ty0 * (uint32_t)w + (uint32_t)tx0;
+            uint32_t rm = 0;
 #pragma unroll
-            for (int k = 0; k < 16; k++) {
+            for (int k = 0; k < 4; k++) {
                 const uint32_t root = rootv[k], sw = sizev[k];
                 const uint32_t gidx = gbase + (root >> 7) * (uint32_t)w + (root & (TW - 1));
-                const uint32_t cls = (sw & 0x80u) ? CK_LBL_BORDER : ((int)(sw & 0x7Fu) < min_comp ? CK_LBL_SMALL : 0u);
-                outw[k] = ((any16 >> k) & 1u) ? (gidx | cls) : CK_LBL_INVALID;
-                // a ring-touching root: a run start whose label word points at itself
-                roots_mask |= ((sw & 0x80u) && root == cbase + (uint32_t)k) ? (1u << k) : 0u; // roots are run starts: never an uncoloured pixel
+                const uint32_t cls = (sw & 0x8000u) ? CK_LBL_BORDER : ((int)(sw & 0x7FFFu) < min_comp ? CK_LBL_SMALL : 0u);
+                const bool col = (any4 >> k) & 1u;
+                outw[k] = col ? (gidx | cls) : CK_LBL_INVALID;
+                // a ring-touching root: a run start whose entry points at itself
+                rm |= (col && (sw & 0x8000u) && root == cbase + (uint32_t)k) ? (1u << k) : 0u;
             }
-            uint32_t *dst = labels + fbase + (size_t)gy * w + gx;
-#pragma unroll
-            for (int q = 0; q < 4; q++)
-                if (gx + 4 * q < w)
-                    *reinterpret_cast<uint4 *>(dst + 4 * q) = make_uint4(outw[4 * q], outw[4 * q + 1], outw[4 * q + 2], outw[4 * q + 3]);
-            nroots = (uint32_t)__popc(roots_mask);
+            roots_all |= rm << (4 * q);
         }
-        // ---- P8: ring-touching roots go to the frame's list: one global reservation per wave and round -----------------
+        uint32_t *dst = labels + fbase + (size_t)gy * w + gx;
+        if (packed_rows) *reinterpret_cast<uint4 *>(dst) = make_uint4(outw[0], outw[1], outw[2], outw[3]);
+        else {
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                if (gx + k < w) dst[k] = outw[k];
+        }
+    }
+    if (stop_after == 8) return; // diagnostics (CK_TILE_STOP_AFTER)
+    // ---- P8: ring-touching roots go to the tile's slice of the frame's list (no global atomic: the slice has room for one root
+    // per ring pixel, and the tile's count goes out next to it).  A root's place in the slice is its tile-local id in the merge
+    // stage; it is remembered in the (now dead) run list, node -> id.
+    {
+        const uint32_t nroots = (uint32_t)__popc(roots_all);
         const uint32_t incl = wave_scan_u32(nroots);
         const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
         if (total) {
-            uint32_t wbase = 0;
-            if ((tid & 63) == 63) wbase = atomicAdd(&broot_count[frame], total);
-            wbase = (uint32_t)__builtin_amdgcn_readlane((int)wbase, 63);
-            uint32_t pos = wbase + incl - nroots;
-            while (roots_mask) {
-                int k = __builtin_ctz(roots_mask);
-                roots_mask &= roots_mask - 1;
-                if (pos < (uint32_t)broot_cap) {
-                    uint32_t node = sbase + (uint32_t)(16 * piece + k);
-                    ck_border_root br;
-                    br.root = (uint32_t)gy * (uint32_t)w + (uint32_t)(tx0 + SEGW * seg + 16 * piece + k);
-                    br.size = size8[node] & 0x7Fu;
-                    broots[(size_t)frame * broot_cap + pos] = br;
-                    csize[fbase + br.root] = 0; // k_roots accumulates the parts of a component at its global root
-                }
+            uint32_t wb = 0;
+            if ((tid & 63) == 63) wb = atomicAdd(&misc[6], total);
+            wb = (uint32_t)__builtin_amdgcn_readlane((int)wb, 63);
+            uint32_t pos = wb + incl - nroots;
+            ck_border_root *slice = broots + ((size_t)frame * 2 * tiles + tile) * RING_CAP; // [frame][slices | packed copy]
+            while (roots_all) {
+                const int b = __builtin_ctz(roots_all);
+                roots_all &= roots_all - 1;
+                const int gi = (b >> 2) * KNT + tid, rr = gi >> 5, g = gi & 31, k = b & 3;
+                const uint32_t node = (uint32_t)(rr * TW + 4 * g + k);
+                ck_border_root br;
+                br.root = (uint32_t)(ty0 + rr) * (uint32_t)w + (uint32_t)(tx0 + 4 * g + k);
+                br.size = size16[node] & 0x7FFFu;
+                slice[pos] = br; // pos < RING_CAP: a ring-touching root owns at least one ring pixel
+                if (!write_ring) csize[fbase + br.root] = 0; // k_roots accumulates the parts of a component at its global root
+                list[node] = (uint16_t)pos;
                 pos++;
             }
         }
     }
-
-    TPROF(5);
-    TPROF(6);
+    __syncthreads();
+    if (tid == 0) tile_count[(size_t)frame * tiles + tile] = misc[6];
+    if (!write_ring || stop_after == 9) return;
+    // ---- P9: the ids of the components along the tile's four edges, for the merge stage ------------------------------------
+    {
+        uint16_t *fr = ring + (size_t)frame * ring_len;
+        const size_t o_ht = 0, o_hb = (size_t)tiles_y * w, o_vl = 2 * (size_t)tiles_y * w, o_vr = o_vl + (size_t)tiles_x * h;
+        for (int item = tid; item < 2 * TW + 2 * TH; item += KNT) {
+            int rr, xx;
+            size_t dst;
+            if (item < TW) { rr = 0; xx = item; dst = o_ht + (size_t)ty * w + (size_t)(tx0 + xx); }
+            else if (item < 2 * TW) { rr = TH - 1; xx = item - TW; dst = o_hb + (size_t)ty * w + (size_t)(tx0 + xx); }
+            else if (item < 2 * TW + TH) { rr = item - 2 * TW; xx = 0; dst = o_vl + (size_t)tx * h + (size_t)(ty0 + rr); }
+            else { rr = item - 2 * TW - TH; xx = TW - 1; dst = o_vr + (size_t)tx * h + (size_t)(ty0 + rr); }
+            if (ty0 + rr >= h || tx0 + xx >= w) continue;
+            const int wd = xx >> 5, i = xx & 31;
+            uint32_t val = 0xFFFFu;
+            if (tile_has_runs) {
+                const uint32_t Wm = mk[(rr * NWD + wd) * 2], Bm = mk[(rr * NWD + wd) * 2 + 1];
+                const uint32_t white = (Wm >> i) & 1u, any = ((Wm | Bm) >> i) & 1u;
+                if (any) {
+                    const uint32_t M = white ? Wm : Bm;
+                    const uint32_t S = ck_starts32(M, ck_origin32(tx0 + 32 * wd, w));
+                    const uint32_t node = (uint32_t)(rr * TW + 32 * wd + ck_run_start32(S, i));
+                    const uint32_t root = parent[node]; // flat since P6
+                    val = (uint32_t)list[root] | (white << 15);
+                }
+            }
+            fr[dst] = (uint16_t)val;
+        }
+    }
+    TPROF(8);
 }
 
 #ifdef CK_TILE_PROFILE
@@ -614,16 +579,11 @@ extern "C" int ck_tile_profile_read(unsigned long long *out, int reset) {
     if (reset && hipMemcpyToSymbol(HIP_SYMBOL(g_tile_prof), z, sizeof z) != hipSuccess) return -1;
     return 0;
 }
-extern "C" int ck_tile_profile2_read(unsigned long long *out, int reset) {
-    unsigned long long z[8] = {};
-    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tile_prof2), sizeof z) != hipSuccess) return -1;
-    if (reset && hipMemcpyToSymbol(HIP_SYMBOL(g_tile_prof2), z, sizeof z) != hipSuccess) return -1;
-    return 0;
-}
 namespace {
 #endif
 
 // ---- cross-tile merge ----------------------------------------------------------------------------------------------------
+constexpr uint32_t CSIZE_LARGE = 0x3FFFFFFFu; // csize[] value meaning "at least min_component_px": later adds of small parts cannot wrap it
 __device__ __forceinline__ uint32_t g_load(const uint32_t *L, uint32_t i) {
     return __hip_atomic_load(&L[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & CK_LBL_IDX_MASK;
 }
@@ -724,17 +684,225 @@ __global__ __launch_bounds__(NT) void k_merge(const uint8_t *__restrict__ thresh
 // the answer with a plain store (thousands of parts of one frame-spanning component would otherwise queue on one address).
 __global__ __launch_bounds__(NT) void k_roots(uint32_t *__restrict__ labels, uint32_t *__restrict__ csize,
                                               const ck_border_root *__restrict__ broots,
-                                              const uint32_t *__restrict__ broot_count, int broot_cap, size_t npix, int min_comp) {
+                                              const uint32_t *__restrict__ tile_count, int tiles, size_t npix, int min_comp) {
     const int frame = blockIdx.y;
-    uint32_t n = min(broot_count[frame], (uint32_t)broot_cap);
     uint32_t *L = labels + (size_t)frame * npix;
     uint32_t *C = csize + (size_t)frame * npix;
-    for (uint32_t k = blockIdx.x * NT + threadIdx.x; k < n; k += gridDim.x * NT) {
-        ck_border_root br = broots[(size_t)frame * broot_cap + k];
+    const uint32_t slots = (uint32_t)tiles * RING_CAP;
+    for (uint32_t k = blockIdx.x * NT + threadIdx.x; k < slots; k += gridDim.x * NT) {
+        const uint32_t t = k / RING_CAP, l = k - t * RING_CAP;
+        if (l >= tile_count[(size_t)frame * tiles + t]) continue;
+        ck_border_root br = broots[(size_t)frame * 2 * slots + k];
         uint32_t g = g_find_ro(L, br.root);
         if (g != br.root) L[br.root] = g | CK_LBL_BORDER; // still a valid ancestor for concurrent finds
-        if ((int)br.size >= min_comp) __hip_atomic_store(&C[g], SIZE_SAT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((int)br.size >= min_comp) __hip_atomic_store(&C[g], CSIZE_LARGE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         else atomicAdd(&C[g], br.size);
+    }
+}
+
+// ---- cross-tile merge, one workgroup per frame, in LDS ------------------------------------------------------------------------------
+// k_tile left, for every frame: the list of ring-touching tile-local roots (broots: pixel index + pixel count; a root's list
+// index is its id) and, along every tile boundary, the id and colour of the component each boundary pixel belongs to (ring).
+// A frame's workgroup replays the connectivity rule across the boundaries as unions over ids in LDS — no label, threshold or
+// csize word is read, and every find is an LDS walk — then writes, for every id, the frame-level root into the tile-local
+// root's label word and, at the frame-level roots, the component size into csize[].  The frame-level root must be the
+// component's smallest pixel index (the canonical label), so the union hooks the root with the larger PIXEL under the other;
+// pixel indices live in broots (global memory, read once per union that actually joins two trees).
+constexpr int FM_NT = 1024;
+constexpr int FM_CAP = 32767;                 // ids fit 15 bits (bit 15 of a ring entry is the colour)
+constexpr int FM_LDS = 2 * (FM_CAP + 1) * 2;  // parent u16[FM_CAP + 1] + size u16[FM_CAP + 1]
+
+__device__ __forceinline__ uint32_t fm_find(uint16_t *p, uint32_t a) { // path halving, same argument as lds_find2
+    for (;;) {
+        const uint32_t n = p[a];
+        if (n == a) return a;
+        const uint32_t g = p[n];
+        if (g == n) return n;
+        p[a] = (uint16_t)g;
+        a = g;
+    }
+}
+// swaps parent[idx] from `expect` to `val` (u16 entry inside a 32-bit word); false when the entry no longer holds `expect`
+__device__ __forceinline__ bool fm_cas16(uint16_t *p, uint32_t idx, uint32_t expect, uint32_t val) {
+    uint32_t *wp = reinterpret_cast<uint32_t *>(p) + (idx >> 1);
+    const uint32_t sh = (idx & 1u) * 16u;
+    uint32_t wv = *reinterpret_cast<volatile uint32_t *>(wp);
+    for (;;) {
+        if (((wv >> sh) & 0xFFFFu) != expect) return false;
+        const uint32_t prev = atomicCAS(wp, wv, (wv & ~(0xFFFFu << sh)) | (val << sh));
+        if (prev == wv) return true;
+        wv = prev; // the other half changed (a halving store or another hook): try again
+    }
+}
+__device__ __forceinline__ void fm_union(uint16_t *p, const ck_border_root *__restrict__ br, uint32_t a, uint32_t b) {
+    for (;;) {
+        a = fm_find(p, a); b = fm_find(p, b);
+        if (a == b) return;
+        const uint32_t pa = br[a].root, pb = br[b].root; // both are roots right now; a root's pixel never changes
+        const uint32_t hi = pa > pb ? a : b, lo = pa > pb ? b : a;
+        if (fm_cas16(p, hi, hi, lo)) return;   // hooked while still a root: parent pixel < child pixel, so no cycle can form
+    }
+}
+// saturating add on a u16 entry: the sum is only ever compared with min_component_px (<= 32767)
+__device__ __forceinline__ void fm_size_add(uint16_t *sz, uint32_t idx, uint32_t add, uint32_t enough) {
+    uint32_t *wp = reinterpret_cast<uint32_t *>(sz) + (idx >> 1);
+    const uint32_t sh = (idx & 1u) * 16u;
+    uint32_t wv = *reinterpret_cast<volatile uint32_t *>(wp);
+    for (;;) {
+        const uint32_t cur = (wv >> sh) & 0xFFFFu;
+        if (cur >= enough) return;                       // already "large": nothing a further part could change
+        uint32_t nv = cur + add;
+        nv = nv > 0x7FFFu ? 0x7FFFu : nv;
+        const uint32_t prev = atomicCAS(wp, wv, (wv & ~(0xFFFFu << sh)) | (nv << sh));
+        if (prev == wv) return;
+        wv = prev;
+    }
+}
+
+// Global-memory variant for a frame with more ring-touching roots than LDS holds (pathological maps): the components are
+// joined through the label words of the tile-local roots, the way k_merge + k_roots do it, by this one workgroup.
+__device__ __forceinline__ void fm_link(uint32_t *L, const uint8_t *T, uint32_t p, uint32_t q) {
+    if (T[p] != T[q]) return;
+    const uint32_t a = g_load(L, p), b = g_load(L, q);
+    if (a != b) g_union_roots(L, a, b);
+}
+__device__ void fm_global_path(uint32_t *L, uint32_t *C, const uint8_t *T, const ck_border_root *__restrict__ br, uint32_t n, int w, int h,
+                               int tiles_x, int tiles_y, int min_comp) {
+    const int tid = threadIdx.x;
+    for (uint32_t i = tid; i < n; i += FM_NT) C[br[i].root] = 0;
+    // every origin pixel on a tile's top row / left column / right column replays its cross-tile links
+    const int per_tile = TW + 2 * (TH - 1);
+    for (int item = tid; item < tiles_x * tiles_y * per_tile; item += FM_NT) {
+        const int tile = item / per_tile, k = item - tile * per_tile;
+        const int tyi = tile / tiles_x, txi = tile - tyi * tiles_x;
+        const int tx0 = txi * TW, ty0 = tyi * TH;
+        int x, y, kind;
+        if (k < TW) { x = tx0 + k; y = ty0; kind = 0; }
+        else if (k < TW + TH - 1) { x = tx0; y = ty0 + 1 + (k - TW); kind = 1; }
+        else { x = tx0 + TW - 1; y = ty0 + 1 + (k - TW - (TH - 1)); kind = 2; }
+        if (x >= w || y >= h || x < 1 || x > w - 2) continue;
+        const uint32_t p = (uint32_t)y * (uint32_t)w + (uint32_t)x;
+        const uint8_t v = T[p];
+        if (v == 127) continue;
+        if (kind == 0) {
+            if (x == tx0 && tx0 > 0) fm_link(L, T, p, p - 1);
+            if (y >= 1) {
+                fm_link(L, T, p, p - w);
+                if (v == 255) { fm_link(L, T, p, p - w - 1); fm_link(L, T, p, p - w + 1); }
+            }
+        } else if (kind == 1) {
+            if (tx0 > 0) { fm_link(L, T, p, p - 1); if (v == 255) fm_link(L, T, p, p - w - 1); }
+        } else if (v == 255 && x + 1 < w) fm_link(L, T, p, p - w + 1);
+    }
+    __threadfence();
+    __syncthreads();
+    for (uint32_t i = tid; i < n; i += FM_NT) {
+        const uint32_t g = g_find_ro(L, br[i].root);
+        if (g != br[i].root) L[br[i].root] = g | CK_LBL_BORDER;
+        if ((int)br[i].size >= min_comp) __hip_atomic_store(&C[g], CSIZE_LARGE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else atomicAdd(&C[g], br[i].size);
+    }
+}
+
+constexpr int FM_MAX_TILES = 320; // frames with more tiles use k_merge + k_roots (ck_create decides)
+__global__ __launch_bounds__(FM_NT) void k_fmerge(uint32_t *__restrict__ labels, uint32_t *__restrict__ csize,
+                                                  ck_border_root *__restrict__ broots, const uint32_t *__restrict__ tile_count,
+                                                  const uint16_t *__restrict__ ring, size_t ring_len, const uint8_t *__restrict__ thresh,
+                                                  size_t npix, int w, int h, int tiles_x, int tiles_y, int min_comp, int lds_cap) {
+    __shared__ __attribute__((aligned(16))) uint8_t fm_lds[FM_LDS]; // 128 KB: one workgroup per CU
+    __shared__ uint32_t base[FM_MAX_TILES + 1];
+    __shared__ uint32_t wsum[FM_NT / 64];
+    const int frame = blockIdx.x, tid = threadIdx.x;
+    const int tiles = tiles_x * tiles_y;
+    uint32_t *L = labels + (size_t)frame * npix;
+    uint32_t *C = csize + (size_t)frame * npix;
+    const size_t slots = (size_t)tiles * RING_CAP;
+    const ck_border_root *slice = broots + (size_t)frame * 2 * slots;
+    ck_border_root *br = broots + (size_t)frame * 2 * slots + slots; // the same entries packed: a root's index here is its id
+    const uint16_t *fr = ring + (size_t)frame * ring_len;
+    // ids: the tiles' counts, scanned (tiles <= FM_MAX_TILES <= FM_NT: one count per thread)
+    {
+        const uint32_t cnt = tid < tiles ? tile_count[(size_t)frame * tiles + tid] : 0u;
+        const uint32_t incl = wave_scan_u32(cnt);
+        if ((tid & 63) == 63) wsum[tid >> 6] = incl;
+        __syncthreads();
+        uint32_t off = incl - cnt;
+        for (int k = 0; k < (tid >> 6); k++) off += wsum[k];
+        if (tid < tiles) base[tid] = off;
+        if (tid == tiles - 1) base[tiles] = off + cnt;
+        __syncthreads();
+    }
+    const uint32_t n = base[tiles];
+    if (n == 0) return;
+    for (uint32_t k = tid; k < (uint32_t)slots; k += FM_NT) { // pack (coalesced reads of the slices' used prefixes)
+        const uint32_t t = k / RING_CAP, l = k - t * RING_CAP;
+        if (l < base[t + 1] - base[t]) br[base[t] + l] = slice[k];
+    }
+    __syncthreads(); // the packed list was written by this workgroup: visible to it after the barrier
+    if (n > (uint32_t)lds_cap) { fm_global_path(L, C, thresh + (size_t)frame * npix, br, n, w, h, tiles_x, tiles_y, min_comp); return; }
+    uint16_t *parent = reinterpret_cast<uint16_t *>(fm_lds);
+    uint16_t *size16 = parent + ((n + 1u) & ~1u);
+    for (uint32_t i = tid; i < n; i += FM_NT) { parent[i] = (uint16_t)i; size16[i] = 0; }
+    __syncthreads();
+    const uint16_t *HT = fr, *HB = fr + (size_t)tiles_y * w, *VL = fr + 2 * (size_t)tiles_y * w, *VR = VL + (size_t)tiles_x * h;
+    // a ring entry = tile-local id | colour << 15; its frame-level id adds the tile's base
+#define FM_ID(e, tile) (base[tile] + ((e) & 0x7FFFu))
+    // horizontal boundaries: the top row of tile row ty against the bottom row of tile row ty - 1 (up, and for white up-left / up-right)
+    const int nh = (tiles_y - 1) * w;
+    for (int item = tid; item < nh; item += FM_NT) {
+        const int tyi = item / w + 1, x = item - (tyi - 1) * w;
+        if (x < 1 || x > w - 2) continue;                  // not an origin column
+        const uint32_t p = HT[(size_t)tyi * w + x];
+        if (p == 0xFFFFu) continue;
+        const uint16_t *up = HB + (size_t)(tyi - 1) * w;
+        const uint32_t q1 = up[x], q0 = up[x - 1], q2 = up[x + 1];
+        const int trow = (tyi - 1) * tiles_x;
+        const uint32_t ip = FM_ID(p, trow + tiles_x + (x >> 7));
+        if (q1 != 0xFFFFu && ((q1 ^ p) & 0x8000u) == 0) fm_union(parent, br, ip, FM_ID(q1, trow + (x >> 7)));
+        if (p & 0x8000u) { // white
+            if ((q0 & 0x8000u) && q0 != 0xFFFFu) fm_union(parent, br, ip, FM_ID(q0, trow + ((x - 1) >> 7)));
+            if ((q2 & 0x8000u) && q2 != 0xFFFFu) fm_union(parent, br, ip, FM_ID(q2, trow + ((x + 1) >> 7)));
+        }
+    }
+    // vertical boundaries: the left column of tile column tx against the right column of tile column tx - 1
+    const int nv = (tiles_x - 1) * h;
+    for (int item = tid; item < nv; item += FM_NT) {
+        const int txi = item / h + 1, y = item - (txi - 1) * h;
+        const int x = txi * TW;                            // >= 1; an origin unless it is the frame's last column
+        const uint32_t p = VL[(size_t)txi * h + y];         // pixel (x, y)
+        const uint16_t *lf = VR + (size_t)(txi - 1) * h;
+        const uint32_t q = lf[y];                           // pixel (x - 1, y): always an origin column (1 <= x - 1 <= w - 2)
+        const int tp = (y / TH) * tiles_x + txi;           // tile of (x, y); (x - 1, y) lies in tp - 1
+        if (p != 0xFFFFu && x <= w - 2) {
+            if (q != 0xFFFFu && ((q ^ p) & 0x8000u) == 0) fm_union(parent, br, FM_ID(p, tp), FM_ID(q, tp - 1));
+            if ((p & 0x8000u) && y > 0) {                  // white: up-left
+                const uint32_t ql = lf[y - 1];
+                if ((ql & 0x8000u) && ql != 0xFFFFu) fm_union(parent, br, FM_ID(p, tp), FM_ID(ql, ((y - 1) / TH) * tiles_x + txi - 1));
+            }
+        }
+        if (q != 0xFFFFu && (q & 0x8000u) && y > 0) {     // white pixel (x - 1, y): up-right is (x, y - 1)
+            const uint32_t pu = VL[(size_t)txi * h + y - 1];
+            if ((pu & 0x8000u) && pu != 0xFFFFu) fm_union(parent, br, FM_ID(q, tp - 1), FM_ID(pu, ((y - 1) / TH) * tiles_x + txi));
+        }
+    }
+#undef FM_ID
+    __syncthreads();
+    for (uint32_t i = tid; i < n; i += FM_NT) { // flatten (walks only read: other lanes' entries may still be mid-chain)
+        uint32_t r = i;
+        for (;;) { const uint32_t nx = parent[r]; if (nx == r) break; r = nx; }
+        if (r != i) parent[i] = (uint16_t)r; // a non-root entry: rewriting it with its root keeps every other walk valid
+    }
+    __syncthreads();
+    const uint32_t enough = (uint32_t)min_comp;
+    for (uint32_t i = tid; i < n; i += FM_NT) {
+        const uint32_t sz = br[i].size;
+        fm_size_add(size16, parent[i], sz > 0x7FFFu ? 0x7FFFu : sz, enough);
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < n; i += FM_NT) {
+        const uint32_t r = parent[i], pix = br[i].root;
+        if (r != i) L[pix] = br[r].root | CK_LBL_BORDER;   // the tile-local root's word now names the frame-level root
+        else C[pix] = size16[i];                           // exact while below min_component_px, else any value >= it
     }
 }
 
@@ -779,22 +947,32 @@ __global__ __launch_bounds__(NT) void k_decimate(const uint8_t *__restrict__ src
 int ck_launch_threshold_segment(ck_handle *h, const uint8_t *frames, int stride, size_t frame_pitch, int n, bool precomputed) {
     const int tiles = h->tiles_x * h->tiles_y;
     static const int stop_after = getenv("CK_TILE_STOP_AFTER") ? atoi(getenv("CK_TILE_STOP_AFTER")) : 99;
-    CK_HIP(hipMemsetAsync(h->d_broot_count, 0, sizeof(uint32_t) * (size_t)n, h->stream));
+    // frames dealt to XCDs (a frame's tiles share one L2): worth it once there are frames for all eight (CK_TILE_XCD=0/1 forces it)
+    static const int xcd_env = getenv("CK_TILE_XCD") ? atoi(getenv("CK_TILE_XCD")) : -1;
+    const int xcd_map = xcd_env >= 0 ? xcd_env : (n >= 16 ? 1 : 0);
+    const unsigned grid = xcd_map ? (unsigned)(((n + 7) / 8) * 8 * tiles) : (unsigned)(tiles * n);
     if (precomputed)
-        hipLaunchKernelGGL(k_tile<true>, dim3((unsigned)(tiles * n)), dim3(KNT), 0, h->stream, frames, frame_pitch, stride, h->qw, h->qh,
-                           h->tiles_x, h->tiles_y, h->cfg.min_white_black_diff, h->cfg.min_component_px, h->d_thresh, h->d_labels,
-                           h->d_broots, h->d_broot_count, h->broot_cap, h->d_csize, stop_after);
+        hipLaunchKernelGGL(k_tile<true>, dim3(grid), dim3(KNT), 0, h->stream, frames, frame_pitch, stride, h->qw, h->qh,
+                           h->tiles_x, h->tiles_y, n, xcd_map, h->cfg.min_white_black_diff, h->cfg.min_component_px, h->d_thresh, h->d_labels,
+                           h->d_broots, h->d_tile_count, h->d_csize, h->d_ring, h->ring_len, h->lds_merge ? 1 : 0, stop_after);
     else
-        hipLaunchKernelGGL(k_tile<false>, dim3((unsigned)(tiles * n)), dim3(KNT), 0, h->stream, frames, frame_pitch, stride, h->qw, h->qh,
-                           h->tiles_x, h->tiles_y, h->cfg.min_white_black_diff, h->cfg.min_component_px, h->d_thresh, h->d_labels,
-                           h->d_broots, h->d_broot_count, h->broot_cap, h->d_csize, stop_after);
-    hipLaunchKernelGGL(k_merge, dim3((unsigned)(tiles * n)), dim3(NT), 0, h->stream, h->d_thresh, h->d_labels, h->qw, h->qh,
-                       h->tiles_x, h->tiles_y);
-    int bx = (h->broot_cap + NT * 8 - 1) / (NT * 8);
-    if (bx < 1) bx = 1;
-    if (bx > 64) bx = 64;
-    hipLaunchKernelGGL(k_roots, dim3((unsigned)bx, (unsigned)n), dim3(NT), 0, h->stream, h->d_labels, h->d_csize, h->d_broots,
-                       h->d_broot_count, h->broot_cap, h->npix, h->cfg.min_component_px);
+        hipLaunchKernelGGL(k_tile<false>, dim3(grid), dim3(KNT), 0, h->stream, frames, frame_pitch, stride, h->qw, h->qh,
+                           h->tiles_x, h->tiles_y, n, xcd_map, h->cfg.min_white_black_diff, h->cfg.min_component_px, h->d_thresh, h->d_labels,
+                           h->d_broots, h->d_tile_count, h->d_csize, h->d_ring, h->ring_len, h->lds_merge ? 1 : 0, stop_after);
+    if (h->lds_merge) {
+        const char *cap_env = getenv("CK_FMERGE_CAP"); // tests force the global-memory path with a small value (read per call)
+        const int cap = (cap_env && atoi(cap_env) < FM_CAP) ? atoi(cap_env) : FM_CAP;
+        hipLaunchKernelGGL(k_fmerge, dim3((unsigned)n), dim3(FM_NT), 0, h->stream, h->d_labels, h->d_csize, h->d_broots, h->d_tile_count,
+                           h->d_ring, h->ring_len, h->d_thresh, h->npix, h->qw, h->qh, h->tiles_x, h->tiles_y, h->cfg.min_component_px, cap);
+    } else {
+        hipLaunchKernelGGL(k_merge, dim3((unsigned)(tiles * n)), dim3(NT), 0, h->stream, h->d_thresh, h->d_labels, h->qw, h->qh,
+                           h->tiles_x, h->tiles_y);
+        int bx = (h->broot_cap + NT * 8 - 1) / (NT * 8);
+        if (bx < 1) bx = 1;
+        if (bx > 64) bx = 64;
+        hipLaunchKernelGGL(k_roots, dim3((unsigned)bx, (unsigned)n), dim3(NT), 0, h->stream, h->d_labels, h->d_csize, h->d_broots,
+                           h->d_tile_count, tiles, h->npix, h->cfg.min_component_px);
+    }
     CK_HIP(hipGetLastError());
     return CK_OK;
 }

@@ -1,0 +1,141 @@
+// links_check.cpp — CPU check of chalkydri_amd/csrc/ck_links.h, the bit-level statement of the segmentation stage's
+// connectivity rule that k_tile (k_ccl.hip) executes on the GPU.
+//
+// For random tri-state maps (and the shapes that stress the rule: single columns, widths around word boundaries, frame
+// edges, checkerboards, long diagonals) it cuts every row into 32-pixel words exactly as the kernel does, takes the links
+// ck_links_of_run() reports for every run, replays them through a sequential union-find over run nodes, and compares the
+// resulting partition (canonical label = smallest pixel index, size per pixel) with the oracle's ora_segment().  The tile
+// is the whole image here (any width, any height): what is checked is the completeness and soundness of the link rule,
+// not the kernel's parallel machinery — the -m gpu parity tests do that.
+//
+// Build / run: tests/test_links_host.py (g++ -O2, links with oracle/libck_oracle.so).
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <vector>
+
+#include "../../chalkydri_amd/csrc/ck_links.h"
+#include "../../oracle/ck_oracle.h"
+
+static uint64_t rng_state = 0x9E3779B97F4A7C15ull;
+static uint32_t rnd() {
+    rng_state ^= rng_state >> 12; rng_state ^= rng_state << 25; rng_state ^= rng_state >> 27;
+    return (uint32_t)((rng_state * 0x2545F4914F6CDD1Dull) >> 32);
+}
+
+static uint32_t uf_find(std::vector<uint32_t> &p, uint32_t a) {
+    while (p[a] != a) { p[a] = p[p[a]]; a = p[a]; }
+    return a;
+}
+static void uf_union(std::vector<uint32_t> &p, uint32_t a, uint32_t b) {
+    a = uf_find(p, a); b = uf_find(p, b);
+    if (a == b) return;
+    if (a < b) p[b] = a; else p[a] = b;
+}
+
+static int check(const std::vector<uint8_t> &t, int w, int h, const char *what) {
+    const int nw = (w + 31) / 32;
+    // per row, per word, per colour (0 white, 1 black)
+    std::vector<uint32_t> m((size_t)h * nw * 2, 0u);
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            uint8_t v = t[(size_t)y * w + x];
+            if (v == 255) m[((size_t)y * nw + x / 32) * 2 + 0] |= 1u << (x & 31);
+            if (v == 0) m[((size_t)y * nw + x / 32) * 2 + 1] |= 1u << (x & 31);
+        }
+    std::vector<uint32_t> parent((size_t)w * h);
+    for (size_t i = 0; i < parent.size(); i++) parent[i] = (uint32_t)i;
+    size_t n_links = 0, n_runs = 0;
+    for (int y = 0; y < h; y++)
+        for (int wd = 0; wd < nw; wd++)
+            for (int c = 0; c < 2; c++) {
+                const uint32_t M = m[((size_t)y * nw + wd) * 2 + c];
+                const uint32_t O = ck_origin32(wd * 32, w);
+                const uint32_t U = y > 0 ? m[((size_t)(y - 1) * nw + wd) * 2 + c] : 0u;
+                const uint32_t Su = ck_starts32(U, O);
+                uint32_t S = ck_starts32(M, O);
+                const bool mp31 = wd > 0 && (m[((size_t)y * nw + wd - 1) * 2 + c] >> 31);
+                const bool up31 = y > 0 && wd > 0 && (m[((size_t)(y - 1) * nw + wd - 1) * 2 + c] >> 31);
+                const bool un0 = y > 0 && wd < nw - 1 && (m[((size_t)(y - 1) * nw + wd + 1) * 2 + c] & 1u);
+                const bool on0 = wd < nw - 1 && (ck_origin32((wd + 1) * 32, w) & 1u);
+                while (S) {
+                    const int i = ck_ctz32(S);
+                    S &= S - 1;
+                    n_runs++;
+                    const ck_run_links L = ck_links_of_run(c == 0, M, U, O, i, mp31, up31, un0, on0);
+                    const uint32_t node = (uint32_t)(y * w + wd * 32 + i);
+                    // the pixels of the run hang on its node
+                    for (uint32_t R = L.R; R; R &= R - 1) parent[(size_t)y * w + wd * 32 + ck_ctz32(R)] = node;
+                    if (L.flags & CK_LINK_HLEFT) {
+                        const uint32_t Mp = m[((size_t)y * nw + wd - 1) * 2 + c];
+                        const uint32_t Sp = ck_starts32(Mp, ck_origin32((wd - 1) * 32, w));
+                        uf_union(parent, node, (uint32_t)(y * w + (wd - 1) * 32 + ck_last_start32(Sp)));
+                        n_links++;
+                    }
+                    for (uint32_t G = L.G; G; G &= G - 1) {
+                        const int j = ck_ctz32(G);
+                        uf_union(parent, node, (uint32_t)((y - 1) * w + wd * 32 + ck_run_start32(Su, j)));
+                        n_links++;
+                    }
+                    if (L.flags & CK_LINK_CROSS_L) {
+                        const uint32_t Up = m[((size_t)(y - 1) * nw + wd - 1) * 2 + c];
+                        const uint32_t Sp = ck_starts32(Up, ck_origin32((wd - 1) * 32, w));
+                        uf_union(parent, node, (uint32_t)((y - 1) * w + (wd - 1) * 32 + ck_last_start32(Sp)));
+                        n_links++;
+                    }
+                    if (L.flags & CK_LINK_CROSS_R) {
+                        uf_union(parent, node, (uint32_t)((y - 1) * w + (wd + 1) * 32));
+                        n_links++;
+                    }
+                }
+            }
+    std::vector<uint32_t> lab((size_t)w * h), sz((size_t)w * h), cnt((size_t)w * h, 0u);
+    ora_segment(t.data(), w, h, lab.data(), sz.data());
+    for (size_t i = 0; i < lab.size(); i++) {
+        uint32_t mine = t[i] == 127 ? 0xFFFFFFFFu : uf_find(parent, (uint32_t)i);
+        if (mine != lab[i]) {
+            fprintf(stderr, "FAIL %s %dx%d: pixel (%d,%d) label %u, oracle %u\n", what, w, h, (int)(i % w), (int)(i / w), mine, lab[i]);
+            return 1;
+        }
+        if (mine != 0xFFFFFFFFu) cnt[mine]++;
+    }
+    for (size_t i = 0; i < lab.size(); i++)
+        if (lab[i] != 0xFFFFFFFFu && cnt[lab[i]] != sz[i]) { fprintf(stderr, "FAIL %s: size\n", what); return 1; }
+    // soundness of the economy: never more links than runs + upper runs touched would justify (every run at most one link
+    // per distinct earlier run); a gross over-count would mean duplicated links, i.e. wasted unions on the GPU
+    if (n_links > 2 * n_runs + 8) { fprintf(stderr, "FAIL %s: %zu links for %zu runs\n", what, n_links, n_runs); return 1; }
+    return 0;
+}
+
+int main(int argc, char **argv) {
+    int rounds = argc > 1 ? atoi(argv[1]) : 300;
+    int fails = 0, cases = 0;
+    const int widths[] = {1, 2, 3, 5, 31, 32, 33, 34, 63, 64, 65, 66, 95, 96, 97, 127, 128, 129, 130, 160, 161, 255, 257, 300};
+    for (int r = 0; r < rounds && !fails; r++) {
+        int w = widths[rnd() % (sizeof widths / sizeof widths[0])], h = 1 + (int)(rnd() % 40);
+        std::vector<uint8_t> t((size_t)w * h);
+        int kind = (int)(rnd() % 8);
+        uint32_t pw = rnd() % 100, pb = rnd() % (101 - pw);           // colour probabilities in per cent
+        for (int y = 0; y < h; y++)
+            for (int x = 0; x < w; x++) {
+                uint8_t v;
+                switch (kind) {
+                case 0: v = ((x + y) & 1) ? 255 : 0; break;                           // checkerboard: every pixel its own run
+                case 1: v = ((x - y) % 3 == 0) ? 255 : ((rnd() & 1) ? 0 : 127); break; // white diagonals down-right
+                case 2: v = ((x + y) % 3 == 0) ? 255 : ((rnd() & 1) ? 0 : 127); break; // white diagonals down-left
+                case 3: v = (rnd() & 1) ? 255 : 0; break;                             // dense binary noise
+                case 4: v = (y & 1) ? 255 : 0; break;                                 // stripes
+                case 5: v = (x & 1) ? 255 : 0; break;                                 // columns
+                default: { uint32_t q = rnd() % 100; v = q < pw ? 255 : (q < pw + pb ? 0 : 127); } break;
+                }
+                t[(size_t)y * w + x] = v;
+            }
+        fails += check(t, w, h, "random");
+        cases++;
+    }
+    if (fails) return 1;
+    printf("OK %d maps\n", cases);
+    return 0;
+}

@@ -90,10 +90,16 @@ def test_create_validates_before_touching_a_device(built):
         cfg = default_config(size[0], size[1], **kw)
         return L.ck_create(C.byref(cfg), C.byref(h))
     assert rc(size=(8, 8)) == A.CK_EINVAL                       # smaller than the 16-pixel minimum
-    assert rc(size=(642, 480)) == A.CK_EUNSUPPORTED             # the width must be a multiple of 4
-    assert rc(size=(640, 450)) == A.CK_EUNSUPPORTED             # 450 = 7 * 64 + 2: the two leftover rows would start a tile of their own
+    assert rc(size=(5000, 480)) == A.CK_EINVAL                  # boundary points carry 13-bit half-pixel coordinates
     assert rc(quad_decimate=3) == A.CK_EUNSUPPORTED
-    assert rc(min_component_px=200) == A.CK_EUNSUPPORTED        # tile-local sizes saturate at 127
+    assert rc(min_component_px=0) == A.CK_EINVAL
+    # any image_u8_t the reference accepts (crates/apriltags/src/lib.rs:204-209) is a valid geometry: widths that are not
+    # multiples of 4, heights that leave 1..3 rows for the last tile row, large component thresholds
+    for kw in ({"size": (642, 480)}, {"size": (641, 450)}, {"size": (640, 450)}, {"size": (130, 33)}, {"min_component_px": 200}):
+        assert rc(**kw) in (A.CK_OK, A.CK_ENODEVICE), kw
+        if h.value:
+            L.ck_destroy(h)
+            h.value = None
     assert rc() in (A.CK_OK, A.CK_ENODEVICE)                    # a valid config fails only for lack of a device
     if h.value:
         L.ck_destroy(h)

@@ -42,7 +42,9 @@ def _frames(kind, w, h, n, seed):
     raise ValueError(kind)
 
 
-@pytest.mark.parametrize("w,h", [(640, 480), (272, 200), (128, 64), (132, 68), (1280, 800)])
+# ragged sizes: widths that are not multiples of 4 / 16 / 32, a last tile column of 1..3 pixels (129, 131), a last tile row of
+# 1..3 rows (33, 35, 450 = 14 * 32 + 2): any image_u8_t geometry the reference accepts (crates/apriltags/src/lib.rs:204-209)
+@pytest.mark.parametrize("w,h", [(640, 480), (272, 200), (128, 64), (132, 68), (1280, 800), (129, 33), (131, 35), (641, 450), (258, 98), (61, 47)])
 @pytest.mark.parametrize("kind", ["synth", "noise", "flat", "stripes", "blobs", "spiral", "checker1", "vstripes1"])
 def test_threshold_segment_bit_exact(oracle, w, h, kind):
     from chalkydri_amd.detector import AprilTagDetector
@@ -58,6 +60,35 @@ def test_threshold_segment_bit_exact(oracle, w, h, kind):
         bad = np.count_nonzero(labels[i] != ol)
         assert bad == 0, f"{bad} label words differ"
         assert np.array_equal(sizes[i], osz)
+    det.close()
+
+
+@pytest.mark.parametrize("kind", ["noise", "blobs", "spiral", "checker1"])
+def test_merge_global_memory_path(oracle, kind, monkeypatch):
+    """A frame with more ring-touching roots than the merge kernel's LDS holds takes its global-memory path: forced here with a
+    tiny capacity (CK_FMERGE_CAP), on maps whose components span many tiles."""
+    from chalkydri_amd.detector import AprilTagDetector
+    monkeypatch.setenv("CK_FMERGE_CAP", "64")
+    w, h, n = 640, 480, 2
+    frames = _frames(kind, w, h, n, 5)
+    det = AprilTagDetector(w, h, max_batch=n)
+    labels, sizes = det.segment(frames)
+    for i in range(n):
+        ol, osz = oracle.segment(oracle.threshold(frames[i]))
+        assert np.array_equal(labels[i], ol) and np.array_equal(sizes[i], osz)
+    det.close()
+
+
+def test_large_frames_use_the_tile_parallel_merge(oracle):
+    """Frames with more than 320 tiles (here 1920x1080: 510) keep k_merge + k_roots."""
+    from chalkydri_amd.detector import AprilTagDetector
+    w, h = 1920, 1080
+    frames = _frames("noise", w, h, 1, 7)
+    frames[0, 200:900, 300:1500] = _frames("blobs", 1200, 700, 1, 8)[0]
+    det = AprilTagDetector(w, h, max_batch=1)
+    labels, sizes = det.segment(frames)
+    ol, osz = oracle.segment(oracle.threshold(frames[0]))
+    assert np.array_equal(labels[0], ol) and np.array_equal(sizes[0], osz)
     det.close()
 
 

@@ -1,5 +1,12 @@
 #!/bin/bash
-# cumulative cost of the k_tile phases (threshold+segment stage time with the tile kernel cut short after phase k)
-for k in 0 1 2 3 4 5 6 7 8 99; do
-  CK_TILE_STOP_AFTER=$k python tools/bench_thrseg.py 1280 800 256 ${1:-synth} 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('stop_after', $k, 'ms', d['ms_per_batch'])"
+# Where k_tile's time goes: threshold+segment timed with the kernel cut short after phase N (CK_TILE_STOP_AFTER), dense-noise and
+# low-noise batches.  usage: tools/ablate_tile.sh <outdir> [stops...]
+out=${1:-gpurun_out/ablate}; shift
+stops=${@:-0 1 2 3 4 5 6 7 99}
+mkdir -p "$out"
+for kind in synth clean; do
+  for s in $stops; do
+    CK_TILE_STOP_AFTER=$s python tools/bench_thrseg.py 1280 800 256 $kind 2>/dev/null | tail -n 1 | sed "s/^/stop=$s /" >> "$out/$kind.log"
+  done
 done
+cat "$out"/synth.log "$out"/clean.log
