@@ -40,10 +40,7 @@ extern "C" int ck_create(const ck_config_t *cfg, ck_handle_t **out) {
     h->npix = (size_t)qw * qh;
     h->tiles_x = (qw + CK_TW - 1) / CK_TW; h->tiles_y = (qh + CK_TH - 1) / CK_TH;
     h->broot_cap = h->tiles_x * h->tiles_y * CK_RING_CAP;
-    h->ring_len = 2 * ((size_t)h->tiles_y * qw + (size_t)h->tiles_x * qh);
-    // k_fmerge keeps a frame's ring-touching roots in LDS (at most 32767 of them; dense noise gives about 90 per tile, and a
-    // frame that has more falls back to global memory inside the kernel); larger frames use the tile-parallel kernels
-    h->lds_merge = h->tiles_x * h->tiles_y <= 320 && cfg->min_component_px <= 32767; // 320 = FM_MAX_TILES (k_ccl.hip)
+    h->ring_len = (2 * ((size_t)h->tiles_y * qw + (size_t)h->tiles_x * qh) + 3) & ~(size_t)3; // frames stay 8-byte aligned
     h->frame_stride = round_up(cfg->width, 16);
     h->frame_pitch = (size_t)h->frame_stride * cfg->height;
     const size_t nb = (size_t)cfg->max_batch;
@@ -70,7 +67,9 @@ extern "C" int ck_create(const ck_config_t *cfg, ck_handle_t **out) {
     if (cfg->quad_decimate > 1) CK_TRY(hipMalloc(&h->d_qframes, (size_t)round_up(qw, 16) * qh * nb));
     CK_TRY(hipMalloc(&h->d_thresh, h->npix * nb));
     CK_TRY(hipMalloc(&h->d_labels, h->npix * nb * sizeof(uint32_t)));
-    CK_TRY(hipMalloc(&h->d_csize, h->npix * nb * sizeof(uint32_t)));
+    CK_TRY(hipMalloc(&h->d_groot, (size_t)h->broot_cap * nb * sizeof(uint32_t)));
+    CK_TRY(hipMalloc(&h->d_gsize, (size_t)h->broot_cap * nb * sizeof(uint32_t)));
+    CK_TRY(hipMalloc(&h->d_gscratch, 2 * (size_t)h->broot_cap * nb * sizeof(uint32_t)));
     CK_TRY(hipMalloc(&h->d_broots, 2 * (size_t)h->broot_cap * nb * sizeof(ck_border_root)));
     CK_TRY(hipMalloc(&h->d_tile_count, (size_t)h->tiles_x * h->tiles_y * nb * sizeof(uint32_t)));
     CK_TRY(hipMalloc(&h->d_ring, h->ring_len * nb * sizeof(uint16_t)));
@@ -89,7 +88,7 @@ extern "C" void ck_destroy(ck_handle_t *h) {
     for (auto &st : h->fit_stream) if (st) (void)hipStreamSynchronize(st);
     ck_stage_free(h);
     (void)hipFree(h->d_frames); (void)hipFree(h->d_qframes); (void)hipFree(h->d_thresh); (void)hipFree(h->d_labels);
-    (void)hipFree(h->d_csize); (void)hipFree(h->d_broots); (void)hipFree(h->d_tile_count); (void)hipFree(h->d_ring);
+    (void)hipFree(h->d_groot); (void)hipFree(h->d_gsize); (void)hipFree(h->d_gscratch); (void)hipFree(h->d_broots); (void)hipFree(h->d_tile_count); (void)hipFree(h->d_ring);
     for (auto &e : h->ev) if (e) (void)hipEventDestroy(e);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);

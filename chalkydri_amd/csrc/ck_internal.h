@@ -9,10 +9,11 @@
 #include "chalkydri_hip.h"
 
 // ---- label word format (segment stage output; DESIGN.md §Data layout) --------------------------------
-// bits 0..25  pixel index (y*width+x) of the component root the pixel points at
+// bits 0..25  pixel index (y*width+x) of the component root the pixel points at, or, with CK_LBL_BORDER, a slot
 // bit  30     CK_LBL_BORDER: the tile-local component touches its tile's outer ring, so it may continue in a
-//             neighbouring tile; resolve with one extra hop through the root's own (flattened) entry and
-//             take the size from csize[]
+//             neighbouring tile; bits 0..25 are its SLOT (tile index * CK_RING_CAP + tile-local id) in the frame's
+//             tables: groot[slot] = pixel index of the frame-level root, gsize[slot] = the component's pixel count
+//             (exact while below min_component_px) — two independent reads
 // bit  31     CK_LBL_SMALL : tile-interior component with fewer than min_component_px pixels (final)
 // 0xFFFFFFFF  pixel thresholded to 127 (no component)
 #define CK_LBL_IDX_MASK 0x03FFFFFFu
@@ -127,7 +128,9 @@ struct ck_handle {
     uint8_t *d_qframes;  // decimated copy (== d_frames when quad_decimate == 1)
     uint8_t *d_thresh;   // [n][qh][qw]
     uint32_t *d_labels;  // [n][qh][qw] label words
-    uint32_t *d_csize;   // [n][qh][qw] sparse: valid at roots of BORDER components
+    uint32_t *d_groot;   // [n][broot_cap] slot table: frame-level root (pixel index) of every ring-touching tile-local component
+    uint32_t *d_gsize;   // [n][broot_cap] slot table: its pixel count (exact while below min_component_px)
+    uint32_t *d_gscratch; // [n][2][broot_cap] parents and sizes of k_fmerge's global-memory path
     ck_border_root *d_broots; // [n][2][broot_cap]: per tile a slice of CK_RING_CAP entries (k_tile), then the same entries packed (k_fmerge)
     uint32_t *d_tile_count;   // [n][tiles]: entries used in every tile's slice
     int broot_cap;            // tiles * CK_RING_CAP
@@ -136,7 +139,6 @@ struct ck_handle {
     // an entry = index into the frame's d_broots list | colour << 15 (1 = white), 0xFFFF = no colour
     uint16_t *d_ring;         // [n][ring_len]
     size_t ring_len;
-    bool lds_merge;           // frames small enough for the one-workgroup-per-frame merge in LDS (k_fmerge); else k_merge + k_roots
     // later stages
     ck_stage_ws ws;      // workspace of clusters / quads / decode
     ck_stage_ms_t last_ms;

@@ -83,4 +83,34 @@ CK_HD ck_run_links ck_links_of_run(bool white, uint32_t M, uint32_t U, uint32_t 
     return L;
 }
 
+// The same links for ALL runs of one word at once, keyed by the LOWER pixel that carries the link (what k_tile's adoption pass
+// uses: one lane per word walks its runs with everything in registers):
+//   Ev  pixel x joins the run that holds pixel x of the row above; one bit per pair of vertically overlapping runs (the first
+//       column of the overlap)
+//   DL  white pixel x joins the run that holds pixel x - 1 of the row above, which no vertical link of its run implies
+//       (pixel -1 = pixel 31 of the upper-left word)
+//   DR  white pixel x joins the run that STARTS at pixel x + 1 of the row above (pixel 32 = pixel 0 of the upper-right word)
+//   hleft  pixel 0 continues the last run of the word on the left
+// Every bit lies inside the run it belongs to; a run may carry several.  The sets are complete and free of duplicates
+// (tests/cpp/links_check.cpp replays them against the oracle, too).
+struct ck_word_links {
+    uint32_t Ev, DL, DR;
+    bool hleft;
+};
+CK_HD ck_word_links ck_links_of_word(bool white, uint32_t M, uint32_t U, uint32_t O, bool m_prev31, bool u_prev31, bool u_next0,
+                                     bool o_next0) {
+    ck_word_links L;
+    const uint32_t MO = M & O, wm = white ? 0xFFFFFFFFu : 0u;
+    const uint32_t V = MO & U;
+    L.Ev = V & ~(V << 1);
+    // up-left: the pixel above-left is set, the pixel above is not (else the vertical link — or, for a run start, the upper run
+    // itself — already covers it), and the left neighbour is not an origin pixel of this run (else ITS vertical link does)
+    L.DL = MO & ((U << 1) | (u_prev31 ? 1u : 0u)) & ~U & ~(MO << 1) & wm;
+    // up-right: the pixel above-right is set and not already joined to a set pixel above (that needs the pixel above-right to be
+    // an origin), and the right neighbour is not an origin pixel of this run
+    L.DR = MO & ((U >> 1) | (u_next0 ? 0x80000000u : 0u)) & ~(U & ((O >> 1) | (o_next0 ? 0x80000000u : 0u))) & ~(MO >> 1) & wm;
+    L.hleft = ((MO & 1u) != 0) & m_prev31;
+    return L;
+}
+
 #endif

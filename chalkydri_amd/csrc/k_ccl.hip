@@ -15,11 +15,11 @@
 //            in LDS, one lane per link, through an atomic-min union; (d) flatten + exact sizes (ds_add on u16 halves);
 //            (e) label words written once (64 B/lane), ring-touching roots appended per wave.  25.7 KB of LDS: six
 //            workgroups per CU.  HBM traffic 1.4 R + 1 W + 4 W bytes per pixel.
-//   k_merge  one thread per tile-ring pixel: links reduced to pairs of tile-local roots, de-duplicated per tile in an
-//            LDS hash set, joined with atomicMin on the label words of the roots involved.
-//   k_roots  flattens the entries of ring-touching roots and accumulates their sizes into csize[].
-// No full-frame relabel pass exists: interior components are final when k_tile writes them; ring-touching
-// ones are resolved by consumers with one extra hop (label word format in ck_internal.h).
+//   k_fmerge one workgroup per frame: the ring-touching roots of the frame's tiles are joined across the tile boundaries in LDS
+//            (ids and colours along the boundaries come from k_tile; no label or threshold word is read) and the frame's
+//            slot tables get every such component's frame-level root and size.
+// No full-frame relabel pass exists: interior components are final when k_tile writes them; the label words of ring-touching
+// ones carry a slot, which consumers resolve with two independent table reads (label word format in ck_internal.h).
 #include <stdlib.h>
 
 #include "ck_internal.h"
@@ -175,8 +175,7 @@ __global__ __launch_bounds__(KNT) void k_tile(const uint8_t *__restrict__ frames
                                              int w, int h, int tiles_x, int tiles_y, int n_frames, int xcd_map, int min_diff, int min_comp,
                                              uint8_t *__restrict__ thresh, uint32_t *__restrict__ labels,
                                              ck_border_root *__restrict__ broots, uint32_t *__restrict__ tile_count,
-                                             uint32_t *__restrict__ csize, uint16_t *__restrict__ ring, size_t ring_len, int write_ring,
-                                             int stop_after) {
+                                             uint16_t *__restrict__ ring, size_t ring_len, int stop_after) {
     __shared__ __attribute__((aligned(16))) uint8_t lds[LDS_BYTES];
     const int tid = threadIdx.x;
     const int tiles = tiles_x * tiles_y;
@@ -325,13 +324,56 @@ __global__ __launch_bounds__(KNT) void k_tile(const uint8_t *__restrict__ frames
     if (stop_after == 2) return; // diagnostics (CK_TILE_STOP_AFTER)
     uint32_t nruns = 0;
     if (tile_has_runs) {
-    // ---- P4: the tile's runs as a list, in scan order: thread = (row, word, colour) -----------------------------------
+    // ---- P4: thread = (row, word, colour).  (a) The word's runs go to the tile's run list, in scan order (the balanced phases
+    // P5b and P6 take one lane per run from it).  (b) Adoption: the lane walks its runs with the word's link masks in registers
+    // (ck_links_of_word) and gives every run ONE earlier run as parent with a plain store — only the owner writes the entry and
+    // nothing reads parent[] in this phase, so no find and no atomic is needed; the target has a smaller index, which keeps the
+    // forest invariant parent <= self.  (c) The links that are left over go to the pool for the atomic unions of P5c.
+    uint32_t *pool = size32;
     {
         const int r = tid >> 3, wd = (tid >> 1) & 3, c = tid & 1;
-        uint32_t S = ck_starts32(mk[tid], ck_origin32(tx0 + 32 * wd, w)); // mk index (r*NWD + wd)*2 + c == tid
+        const bool has_l = wd > 0, has_u = r > 0, has_r = wd < NWD - 1, white = c == 0;
+        const int x0 = tx0 + 32 * wd;
+        const uint32_t O = ck_origin32(x0, w), Op = ck_origin32(x0 - 32, w);
+        const uint32_t M = mk[tid]; // mk index (r*NWD + wd)*2 + c == tid
+        uint32_t Mp = mk[has_l ? tid - 2 : tid], U = mk[has_u ? tid - 2 * NWD : tid];
+        uint32_t Up = mk[(has_u && has_l) ? tid - 2 * NWD - 2 : tid], Un = mk[(has_u && has_r) ? tid - 2 * NWD + 2 : tid];
+        Mp = has_l ? Mp : 0u; U = has_u ? U : 0u;
+        Up = (has_u && has_l && white) ? Up : 0u; Un = (has_u && has_r && white) ? Un : 0u;
+        const bool on0 = (x0 + 32 >= 1) && (x0 + 32 <= w - 2);
+        const uint32_t S = ck_starts32(M, O), Su = ck_starts32(U, O);
+        ck_word_links K = ck_links_of_word(white, M, U, O, (Mp >> 31) != 0, (Up >> 31) != 0, (Un & 1u) != 0, on0);
+        const uint32_t wbase = (uint32_t)(r * TW + 32 * wd), upbase = wbase - (uint32_t)TW;
+        const uint32_t left = wbase - 32u + (uint32_t)ck_last_start32(ck_starts32(Mp, Op));       // last run of the word on the left
+        const uint32_t up_l = upbase - 32u + (uint32_t)ck_last_start32(ck_starts32(Up, Op));      // last run of the upper-left word
+        // (a) the list
         const uint32_t cnt = (uint32_t)__popc(S);
         const uint32_t incl = wave_scan_u32(cnt);
         if ((tid & 63) == 63) misc[tid >> 6] = incl;
+        if (tid == 0) misc[5] = 0;
+        // (b) adoption, meanwhile
+        uint32_t Ev = K.Ev, DL = K.DL, DR = K.DR, hl = K.hleft ? 1u : 0u;
+        for (uint32_t St = S; St;) {
+            const uint32_t low = St & (0u - St);
+            const int i = __builtin_ctz(low);
+            St ^= low;
+            const uint32_t span = ((St & (0u - St)) - 1u) & ~(low - 1u); // the run's pixels-to-be: bit i up to the next start
+            const uint32_t e = (Ev | DL | DR) & span;
+            const int x = __builtin_ctz(e | 0x80000000u);
+            const uint32_t bit = 1u << x;
+            const bool is_ev = (Ev & bit) != 0, is_dl = (DL & bit) != 0;
+            const uint32_t t_ev = upbase + (uint32_t)ck_run_start32(Su, x);
+            const uint32_t t_dl = x > 0 ? upbase + (uint32_t)ck_run_start32(Su, x - 1) : up_l;
+            const uint32_t t_dr = upbase + (uint32_t)x + 1u;
+            const bool use_left = !e && i == 0 && hl;
+            const uint32_t tgt = e ? (is_ev ? t_ev : (is_dl ? t_dl : t_dr)) : (use_left ? left : wbase + (uint32_t)i);
+            const uint32_t clr = e ? ~bit : 0xFFFFFFFFu;
+            Ev &= is_ev ? clr : 0xFFFFFFFFu;
+            DL &= (!is_ev && is_dl) ? clr : 0xFFFFFFFFu;
+            DR &= (!is_ev && !is_dl) ? clr : 0xFFFFFFFFu;
+            hl = use_left ? 0u : hl;
+            parent[wbase + (uint32_t)i] = (uint16_t)tgt;
+        }
         __syncthreads();
         uint32_t off = incl - cnt;
         const int wv = tid >> 6;
@@ -339,39 +381,24 @@ __global__ __launch_bounds__(KNT) void k_tile(const uint8_t *__restrict__ frames
         if (wv > 1) off += misc[1];
         if (wv > 2) off += misc[2];
         nruns = misc[0] + misc[1] + misc[2] + misc[3];
-        const uint32_t base = (uint32_t)(r * TW + 32 * wd) | ((uint32_t)c << 12);
-        while (S) {
-            list[off++] = (uint16_t)(base + (uint32_t)__builtin_ctz(S));
-            S &= S - 1u;
-        }
-        if (tid == 0) misc[5] = 0;
-    }
-    __syncthreads(); // the list is complete; the image scratch is dead from here on: it becomes the parent array
-    TPROF(3);
-    if (stop_after == 3) return; // diagnostics (CK_TILE_STOP_AFTER)
-
-    // ---- P5a: adoption.  One lane per run: its first link to an earlier run becomes its parent with a plain store (only the
-    // owner writes the entry, nothing reads parent[] in this phase: no find, no atomic; the target has a smaller index, which
-    // keeps the forest invariant parent <= self).  The other links go to the pool.
-    uint32_t *pool = size32;
-    for (uint32_t j0 = 0; j0 < nruns; j0 += KNT) {
-        const uint32_t j = j0 + (uint32_t)tid;
-        const bool live = j < nruns;
-        RunView v = view_run(mk, list[live ? j : 0u], tx0, w); // (a lane past the end looks at run 0 and writes nothing)
-        const uint32_t nl = links_left(v);
-        const uint32_t first = take_link(v, v.p);
-        if (live) parent[v.p] = (uint16_t)first;
-        uint32_t extra = (live && nl) ? nl - 1u : 0u;
-        const uint32_t incl = wave_scan_u32(extra);
-        const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-        if (total) { // one reservation per wave and round
+        const uint32_t ebase = wbase | ((uint32_t)c << 12);
+        for (uint32_t St = S; St; St &= St - 1u) list[off++] = (uint16_t)(ebase + (uint32_t)__builtin_ctz(St));
+        // (c) the links that are left: one reservation per wave
+        uint32_t extra = (uint32_t)__popc(Ev) + (uint32_t)__popc(DL) + (uint32_t)__popc(DR) + hl;
+        const uint32_t xincl = wave_scan_u32(extra);
+        const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)xincl, 63);
+        if (total) {
             uint32_t wb = 0;
             if ((tid & 63) == 63) wb = atomicAdd(&misc[5], total);
             wb = (uint32_t)__builtin_amdgcn_readlane((int)wb, 63);
-            uint32_t pos = wb + incl - extra;
+            uint32_t pos = wb + xincl - extra;
             while (extra) {
-                const uint32_t t = take_link(v, v.p);
-                if (pos < (uint32_t)POOL_CAP) pool[pos] = v.p | (t << 16);
+                uint32_t a_, b_;
+                if (Ev) { const int x = __builtin_ctz(Ev); Ev &= Ev - 1u; a_ = wbase + (uint32_t)ck_run_start32(S, x); b_ = upbase + (uint32_t)ck_run_start32(Su, x); }
+                else if (DL) { const int x = __builtin_ctz(DL); DL &= DL - 1u; a_ = wbase + (uint32_t)ck_run_start32(S, x); b_ = x > 0 ? upbase + (uint32_t)ck_run_start32(Su, x - 1) : up_l; }
+                else if (DR) { const int x = __builtin_ctz(DR); DR &= DR - 1u; a_ = wbase + (uint32_t)ck_run_start32(S, x); b_ = upbase + (uint32_t)x + 1u; }
+                else { hl = 0; a_ = wbase; b_ = left; }
+                if (pos < (uint32_t)POOL_CAP) pool[pos] = a_ | (b_ << 16);
                 pos++; extra--;
             }
         }
@@ -448,13 +475,52 @@ __global__ __launch_bounds__(KNT) void k_tile(const uint8_t *__restrict__ frames
             }
     }
     __syncthreads();
+    // ---- P6b: the roots whose component touches the tile ring get their tile-local id (= place in the tile's slice of the
+    // frame's list, which takes the root's pixel and the component's pixel count); the id replaces the count in the size array
+    // (bit 15 stays set): that is what the label pass and the ring pass look up.  No global atomic: the slice has room for one
+    // root per ring pixel.
+    {
+        ck_border_root *slice = broots + ((size_t)frame * 2 * tiles + tile) * RING_CAP; // [frame][slices | packed copy]
+        for (uint32_t j0 = 0; j0 < nruns; j0 += KNT) {
+            const uint32_t j = j0 + (uint32_t)tid;
+            const uint32_t p = list[j < nruns ? j : 0u] & 0xFFFu;
+            const uint32_t sw = size16[p];
+            const bool is = j < nruns && parent[p] == p && (sw & 0x8000u);
+            const unsigned long long bal = __ballot(is);
+            if (bal) {
+                uint32_t wb = 0;
+                if ((tid & 63) == 0) wb = atomicAdd(&misc[6], (uint32_t)__popcll(bal));
+                wb = (uint32_t)__builtin_amdgcn_readfirstlane((int)wb);
+                if (is) {
+                    const uint32_t id = wb + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+                    ck_border_root br;
+                    br.root = (uint32_t)(ty0 + (int)(p >> 7)) * (uint32_t)w + (uint32_t)(tx0 + (int)(p & (TW - 1)));
+                    br.size = sw & 0x7FFFu;
+                    slice[id] = br; // id < RING_CAP: a ring-touching root owns at least one ring pixel
+                    size16[p] = (uint16_t)(0x8000u | id);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // ---- P6c: every run's entry becomes the 16-bit code of its component, which the label pass expands per pixel with ONE lookup:
+    // ring-touching: 0x8000 | id; interior: root node | 0x4000 when smaller than min_component_px.  (A run reads its own entry —
+    // flat since P6 — and its root's size entry, and rewrites only its own: no other run reads it any more.)
+    for (uint32_t j = (uint32_t)tid; j < nruns; j += KNT) {
+        const uint32_t p = list[j] & 0xFFFu;
+        const uint32_t root = parent[p];
+        const uint32_t sw = size16[root];
+        parent[p] = (uint16_t)((sw & 0x8000u) ? sw : (root | ((int)sw < min_comp ? 0x4000u : 0u)));
+    }
+    __syncthreads();
     } // tile_has_runs
+    if (tid == 0) tile_count[(size_t)frame * tiles + tile] = misc[6];
     TPROF(7);
 
     if (stop_after == 7) return; // diagnostics (CK_TILE_STOP_AFTER)
+    uint16_t *ring_f = ring + (size_t)frame * ring_len;
     // ---- P7: write label words.  Four passes; in pass q lane L owns the 4-pixel group q*256 + L of the tile's 1024, so that a
     // wave's store instruction covers 1 KiB of contiguous label words and its LDS lookups spread over the banks
-    uint32_t roots_all = 0; // 4 bits per pass: which pixels of the lane's group are ring-touching roots
 #pragma unroll
     for (int q = 0; q < 4; q++) {
         const int gi = q * KNT + tid, rr = gi >> 5, g = gi & 31, wd = g >> 3, sh = 4 * (g & 7);
@@ -465,6 +531,7 @@ __global__ __launch_bounds__(KNT) void k_tile(const uint8_t *__restrict__ frames
         const uint32_t Wm = wb.x, Bm = wb.y;
         const uint32_t w4 = (Wm >> sh) & 15u, b4 = (Bm >> sh) & 15u, any4 = w4 | b4;
         uint32_t outw[4] = {CK_LBL_INVALID, CK_LBL_INVALID, CK_LBL_INVALID, CK_LBL_INVALID};
+        uint32_t ringv[4] = {0, 0, 0, 0};
         if (any4) {
             const uint32_t Oo = ck_origin32(tx0 + 32 * wd, w);
             const uint32_t SW = ck_starts32(Wm, Oo), SB = ck_starts32(Bm, Oo);
@@ -476,29 +543,40 @@ __global__ __launch_bounds__(KNT) void k_tile(const uint8_t *__restrict__ frames
             // inside a run), or before the group (then the run has the colour of pixel 0 and the carried node of that colour).
             // An uncoloured pixel looks up a harmless in-range node.
             uint32_t cur = (w4 & 1u) ? carryW : carryB;
-            uint32_t nodev[4], rootv[4], sizev[4];
+            uint32_t codev[4];
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 cur = ((st4 >> k) & 1u) ? cbase + (uint32_t)k : cur;
-                nodev[k] = cur;
+                codev[k] = cur;
             }
 #pragma unroll
-            for (int k = 0; k < 4; k++) rootv[k] = parent[nodev[k]] & (uint32_t)(TH * TW - 1); // (an uncoloured pixel's node is no run start: its entry is undefined)
-#pragma unroll
-            for (int k = 0; k < 4; k++) sizev[k] = size16[rootv[k]];
+            for (int k = 0; k < 4; k++) codev[k] = parent[codev[k]]; // the component's code (P6c); undefined for an uncoloured pixel, whose word is not used
             const uint32_t gbase = (uint32_t)ty0 * (uint32_t)w + (uint32_t)tx0;
-            uint32_t rm = 0;
+            const uint32_t slot0 = CK_LBL_BORDER | ((uint32_t)tile * RING_CAP);
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                const uint32_t root = rootv[k], sw = sizev[k];
-                const uint32_t gidx = gbase + (root >> 7) * (uint32_t)w + (root & (TW - 1));
-                const uint32_t cls = (sw & 0x8000u) ? CK_LBL_BORDER : ((int)(sw & 0x7FFFu) < min_comp ? CK_LBL_SMALL : 0u);
-                const bool col = (any4 >> k) & 1u;
-                outw[k] = col ? (gidx | cls) : CK_LBL_INVALID;
-                // a ring-touching root: a run start whose entry points at itself
-                rm |= (col && (sw & 0x8000u) && root == cbase + (uint32_t)k) ? (1u << k) : 0u;
+                const uint32_t c = codev[k], node = c & 0xFFFu;
+                // interior component: the root's pixel index, final; ring-touching: the component's slot in the frame's tables
+                const uint32_t word = (c & 0x8000u) ? slot0 + (c & 0x7FFFu) : ((gbase + (node >> 7) * (uint32_t)w + (node & (TW - 1))) | ((c & 0x4000u) << 17));
+                outw[k] = ((any4 >> k) & 1u) ? word : CK_LBL_INVALID;
+                ringv[k] = c;
             }
-            roots_all |= rm << (4 * q);
+        }
+        // the lanes on the tile's edges also leave the ids (and colours) of their pixels' components for the merge stage
+        // (a component that owns a ring pixel is ring-touching wherever a neighbouring tile exists: its size entry holds the id)
+        if (rr == 0 || rr == TH - 1 || g == 0 || g == 31) {
+            uint32_t rv[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) rv[k] = ((any4 >> k) & 1u) ? ((ringv[k] & 0x7FFFu) | (((w4 >> k) & 1u) << 15)) : 0xFFFFu;
+            if (rr == 0 || rr == TH - 1) {
+                uint16_t *dr = ring_f + (rr == 0 ? (size_t)0 : (size_t)tiles_y * w) + (size_t)ty * w + (size_t)gx;
+                if (gx + 4 <= w && (w & 3) == 0) *reinterpret_cast<uint2 *>(dr) = make_uint2(rv[0] | (rv[1] << 16), rv[2] | (rv[3] << 16));
+                else
+                    for (int k = 0; k < 4; k++)
+                        if (gx + k < w) dr[k] = (uint16_t)rv[k];
+            }
+            if (g == 0) ring_f[2 * (size_t)tiles_y * w + (size_t)tx * h + (size_t)gy] = (uint16_t)rv[0];
+            if (g == 31) ring_f[2 * (size_t)tiles_y * w + (size_t)tiles_x * h + (size_t)tx * h + (size_t)gy] = (uint16_t)rv[3];
         }
         uint32_t *dst = labels + fbase + (size_t)gy * w + gx;
         if (packed_rows) *reinterpret_cast<uint4 *>(dst) = make_uint4(outw[0], outw[1], outw[2], outw[3]);
@@ -506,66 +584,6 @@ __global__ __launch_bounds__(KNT) void k_tile(const uint8_t *__restrict__ frames
 #pragma unroll
             for (int k = 0; k < 4; k++)
                 if (gx + k < w) dst[k] = outw[k];
-        }
-    }
-    if (stop_after == 8) return; // diagnostics (CK_TILE_STOP_AFTER)
-    // ---- P8: ring-touching roots go to the tile's slice of the frame's list (no global atomic: the slice has room for one root
-    // per ring pixel, and the tile's count goes out next to it).  A root's place in the slice is its tile-local id in the merge
-    // stage; it is remembered in the (now dead) run list, node -> id.
-    {
-        const uint32_t nroots = (uint32_t)__popc(roots_all);
-        const uint32_t incl = wave_scan_u32(nroots);
-        const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-        if (total) {
-            uint32_t wb = 0;
-            if ((tid & 63) == 63) wb = atomicAdd(&misc[6], total);
-            wb = (uint32_t)__builtin_amdgcn_readlane((int)wb, 63);
-            uint32_t pos = wb + incl - nroots;
-            ck_border_root *slice = broots + ((size_t)frame * 2 * tiles + tile) * RING_CAP; // [frame][slices | packed copy]
-            while (roots_all) {
-                const int b = __builtin_ctz(roots_all);
-                roots_all &= roots_all - 1;
-                const int gi = (b >> 2) * KNT + tid, rr = gi >> 5, g = gi & 31, k = b & 3;
-                const uint32_t node = (uint32_t)(rr * TW + 4 * g + k);
-                ck_border_root br;
-                br.root = (uint32_t)(ty0 + rr) * (uint32_t)w + (uint32_t)(tx0 + 4 * g + k);
-                br.size = size16[node] & 0x7FFFu;
-                slice[pos] = br; // pos < RING_CAP: a ring-touching root owns at least one ring pixel
-                if (!write_ring) csize[fbase + br.root] = 0; // k_roots accumulates the parts of a component at its global root
-                list[node] = (uint16_t)pos;
-                pos++;
-            }
-        }
-    }
-    __syncthreads();
-    if (tid == 0) tile_count[(size_t)frame * tiles + tile] = misc[6];
-    if (!write_ring || stop_after == 9) return;
-    // ---- P9: the ids of the components along the tile's four edges, for the merge stage ------------------------------------
-    {
-        uint16_t *fr = ring + (size_t)frame * ring_len;
-        const size_t o_ht = 0, o_hb = (size_t)tiles_y * w, o_vl = 2 * (size_t)tiles_y * w, o_vr = o_vl + (size_t)tiles_x * h;
-        for (int item = tid; item < 2 * TW + 2 * TH; item += KNT) {
-            int rr, xx;
-            size_t dst;
-            if (item < TW) { rr = 0; xx = item; dst = o_ht + (size_t)ty * w + (size_t)(tx0 + xx); }
-            else if (item < 2 * TW) { rr = TH - 1; xx = item - TW; dst = o_hb + (size_t)ty * w + (size_t)(tx0 + xx); }
-            else if (item < 2 * TW + TH) { rr = item - 2 * TW; xx = 0; dst = o_vl + (size_t)tx * h + (size_t)(ty0 + rr); }
-            else { rr = item - 2 * TW - TH; xx = TW - 1; dst = o_vr + (size_t)tx * h + (size_t)(ty0 + rr); }
-            if (ty0 + rr >= h || tx0 + xx >= w) continue;
-            const int wd = xx >> 5, i = xx & 31;
-            uint32_t val = 0xFFFFu;
-            if (tile_has_runs) {
-                const uint32_t Wm = mk[(rr * NWD + wd) * 2], Bm = mk[(rr * NWD + wd) * 2 + 1];
-                const uint32_t white = (Wm >> i) & 1u, any = ((Wm | Bm) >> i) & 1u;
-                if (any) {
-                    const uint32_t M = white ? Wm : Bm;
-                    const uint32_t S = ck_starts32(M, ck_origin32(tx0 + 32 * wd, w));
-                    const uint32_t node = (uint32_t)(rr * TW + 32 * wd + ck_run_start32(S, i));
-                    const uint32_t root = parent[node]; // flat since P6
-                    val = (uint32_t)list[root] | (white << 15);
-                }
-            }
-            fr[dst] = (uint16_t)val;
         }
     }
     TPROF(8);
@@ -582,135 +600,93 @@ extern "C" int ck_tile_profile_read(unsigned long long *out, int reset) {
 namespace {
 #endif
 
-// ---- cross-tile merge ----------------------------------------------------------------------------------------------------
-constexpr uint32_t CSIZE_LARGE = 0x3FFFFFFFu; // csize[] value meaning "at least min_component_px": later adds of small parts cannot wrap it
-__device__ __forceinline__ uint32_t g_load(const uint32_t *L, uint32_t i) {
-    return __hip_atomic_load(&L[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & CK_LBL_IDX_MASK;
-}
-// find over the root entries of ring-touching components, with path halving (same argument as lds_find)
-__device__ __forceinline__ uint32_t g_find(uint32_t *L, uint32_t r) {
-    for (;;) {
-        uint32_t n = g_load(L, r);
-        if (n == r) return r;
-        uint32_t g = g_load(L, n);
-        if (g == n) return n;
-        __hip_atomic_store(&L[r], g | CK_LBL_BORDER, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        r = g;
-    }
-}
-__device__ __forceinline__ uint32_t g_find_ro(const uint32_t *L, uint32_t r) {
-    for (;;) {
-        uint32_t n = g_load(L, r);
-        if (n == r) return r;
-        r = n;
-    }
-}
-// union of the components whose tile-local roots are a and b (both ring-touching, so their entries carry CK_LBL_BORDER)
-__device__ __forceinline__ void g_union_roots(uint32_t *L, uint32_t a, uint32_t b) {
-    for (;;) {
-        a = g_find(L, a);
-        b = g_find(L, b);
-        if (a == b) return;
-        if (a < b) { uint32_t t = a; a = b; b = t; }
-        uint32_t old = atomicMin(&L[a], b | CK_LBL_BORDER) & CK_LBL_IDX_MASK;
-        if (old == a) return;
-        a = old;
-    }
-}
+// ---- cross-tile merge: one workgroup per frame ------------------------------------------------------------------------------------
+// k_tile left, for every frame: per tile the list of its ring-touching roots (broots slices: pixel index + pixel count; a
+// root's place in its tile's slice is its tile-local id, slice * CK_RING_CAP + id its SLOT) and, along every tile boundary, the
+// id and colour of the component each boundary pixel belongs to (ring).  A frame's workgroup numbers the roots consecutively
+// (scan of the tiles' counts), replays the connectivity rule across the boundaries as unions over those numbers, and fills
+// the frame's two tables, indexed by slot: groot[slot] = pixel index of the component's frame-level root (its smallest pixel:
+// the canonical label), gsize[slot] = the component's pixel count (exact while below min_component_px).  The label words of
+// ring-touching components carry the slot (ck_internal.h), so a consumer resolves one with two independent table reads.
+// No label, threshold or per-pixel size word is read or written here.
+//
+// The unions run in LDS (u16 parents: up to FM_CAP roots per frame; dense noise at 1280x800 has about 22 000); a frame with
+// more takes the same steps in global memory (fm_global_path).  The frame-level root must be the component's smallest
+// pixel, so a union hooks the root with the larger PIXEL under the other one (compare-and-swap on the root's own entry).
+constexpr int FM_NT = 1024;
+constexpr int FM_CAP = 28672;                 // roots per frame the LDS path holds
+constexpr int FM_LDS = 2 * FM_CAP * 2;        // parent u16[FM_CAP] + size / key u16[FM_CAP]
+constexpr int FM_WQ = 384;                    // joins a wave's queue holds (one round of boundary pixels adds at most 192)
+constexpr int FM_MAX_TILES = 4096;            // 4095 x 4095 pixels at most (ck_create)
+constexpr uint32_t NOJ = 0xFFFFFFFFu;         // "no join"
 
-// One workgroup per tile, one thread per pixel of the tile's top row / left column / right column.  Every link that
-// crosses a tile boundary is reduced to the pair of tile-local roots it joins; a small LDS hash set keeps one thread
-// per distinct pair (a large component crosses an edge at dozens of places), and only those run the global union.
-constexpr int MSET = 1024;
-__device__ __forceinline__ void merge_link(uint32_t *L, unsigned long long *set, uint32_t p, uint32_t q) {
-    uint32_t a = L[p] & CK_LBL_IDX_MASK, b = L[q] & CK_LBL_IDX_MASK; // written by k_tile, read-only until a root entry is hooked
-    if (a == b) return;
-    unsigned long long key = a < b ? ((unsigned long long)a << 32) | b : ((unsigned long long)b << 32) | a;
-    uint32_t hsh = (uint32_t)((key >> 32) ^ key) * 2654435761u;
-    uint32_t slot = (hsh >> 12) & (MSET - 1);
-    for (int probe = 0; probe < 16; probe++) {
-        unsigned long long prev = atomicCAS(&set[slot], 0ull, key);
-        if (prev == key) return;          // another thread of this tile already owns the pair
-        if (prev == 0ull) break;          // inserted: this thread does the union
-        slot = (slot + 1) & (MSET - 1);
-    }                                     // table crowded: fall through and union without de-duplication
-    g_union_roots(L, a, b);
-}
-
-__global__ __launch_bounds__(NT) void k_merge(const uint8_t *__restrict__ thresh, uint32_t *__restrict__ labels, int w, int h,
-                                              int tiles_x, int tiles_y) {
-    __shared__ unsigned long long sSet[MSET];
-    const int tid = threadIdx.x;
-    const int tiles = tiles_x * tiles_y;
-    const int frame = blockIdx.x / tiles, tile = blockIdx.x - frame * tiles;
-    const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
-    const int tx0 = tx * TW, ty0 = ty * TH;
-    const size_t fbase = (size_t)frame * (size_t)w * (size_t)h;
-    const uint8_t *T = thresh + fbase;
-    uint32_t *L = labels + fbase;
-    for (int i = tid; i < MSET; i += NT) sSet[i] = 0ull;
-    __syncthreads();
-    int x, y, kind;
-    if (tid < TW) { x = tx0 + tid; y = ty0; kind = 0; }
-    else if (tid < TW + TH) { x = tx0; y = ty0 + 1 + (tid - TW); kind = 1; }
-    else { x = tx0 + TW - 1; y = ty0 + 1 + (tid - TW - TH); kind = 2; }
-    if (y >= ty0 + TH || x >= w || y >= h) return;
-    if (x < 1 || x > w - 2) return; // not an origin column
-    const uint32_t p = (uint32_t)y * (uint32_t)w + (uint32_t)x;
-    const uint8_t v = T[p];
-    if (v == 127) return;
-    if (kind == 0) {
-        if (x == tx0 && tx0 > 0 && T[p - 1] == v) merge_link(L, sSet, p, p - 1);
-        if (y >= 1) {
-            if (T[p - w] == v) merge_link(L, sSet, p, p - w);
-            if (v == 255) {
-                if (T[p - w - 1] == 255) merge_link(L, sSet, p, p - w - 1);
-                if (T[p - w + 1] == 255) merge_link(L, sSet, p, p - w + 1);
+struct FmFrame {
+    const uint16_t *HT, *HB, *VL, *VR; // ring entries: tile-local id | colour << 15 (1 = white), 0xFFFF = no colour
+    const uint32_t *base;              // first number of every tile's roots (LDS)
+    int w, h, tiles_x, tiles_y;
+};
+// Calls emit(j0, j1, j2) once per boundary pixel slot and lane (uniformly: every lane of the workgroup makes the same number of
+// calls); a join is number | number << 16 when numbers fit 16 bits (LDS path) — the global path passes WIDE = true and gets
+// the two numbers in separate calls of emit2.
+template <typename Emit>
+__device__ __forceinline__ void fm_boundaries(const FmFrame &f, int tid, Emit &&emit) {
+    const int w = f.w, h = f.h, tiles_x = f.tiles_x;
+    // horizontal boundaries: the top row of tile row ty against the bottom row of tile row ty - 1 (up, and for white up-left / up-right)
+    const int nh = (f.tiles_y - 1) * w;
+    for (int item0 = 0; item0 < nh; item0 += FM_NT) {
+        const int item = item0 + tid;
+        uint32_t a0 = NOJ, b0 = NOJ, b1 = NOJ, b2 = NOJ;
+        if (item < nh) {
+            const int tyi = item / w + 1, x = item - (tyi - 1) * w;
+            if (x >= 1 && x <= w - 2) {                    // an origin column
+                const uint16_t *up = f.HB + (size_t)(tyi - 1) * w;
+                const uint32_t p = f.HT[(size_t)tyi * w + x], q1 = up[x], q0 = up[x - 1], q2 = up[x + 1], pl = f.HT[(size_t)tyi * w + x - 1];
+                // the pixel on the left made the same joins when it is the same component over the same component (and, for
+                // white, the new diagonal neighbour up-right is that component again): nothing to add
+                // (ring entries are tile-local ids: comparable inside one tile column only)
+                const bool same = x > 1 && (x & (TW - 1)) != 0 && (x & (TW - 1)) != TW - 1 && pl == p && q0 == q1 && (q2 == q1 || !(p & 0x8000u));
+                if (p != 0xFFFFu && !same) {
+                    const int trow = (tyi - 1) * tiles_x;
+                    a0 = f.base[trow + tiles_x + (x >> 7)] + (p & 0x7FFFu);
+                    if (q1 != 0xFFFFu && ((q1 ^ p) & 0x8000u) == 0) b0 = f.base[trow + (x >> 7)] + (q1 & 0x7FFFu);
+                    if (p & 0x8000u) { // white
+                        if ((q0 & 0x8000u) && q0 != 0xFFFFu && q0 != q1) b1 = f.base[trow + ((x - 1) >> 7)] + (q0 & 0x7FFFu);
+                        if ((q2 & 0x8000u) && q2 != 0xFFFFu && q2 != q1) b2 = f.base[trow + ((x + 1) >> 7)] + (q2 & 0x7FFFu);
+                    }
+                }
             }
         }
-    } else if (kind == 1) {
-        if (tx0 > 0) {
-            if (T[p - 1] == v) merge_link(L, sSet, p, p - 1);
-            if (v == 255 && T[p - w - 1] == 255) merge_link(L, sSet, p, p - w - 1);
+        emit(a0, b0, a0, b1, a0, b2);
+    }
+    // vertical boundaries: the left column of tile column tx against the right column of tile column tx - 1
+    const int nv = (tiles_x - 1) * h;
+    for (int item0 = 0; item0 < nv; item0 += FM_NT) {
+        const int item = item0 + tid;
+        uint32_t ap = NOJ, aq = NOJ, b0 = NOJ, b1 = NOJ, b2 = NOJ;
+        if (item < nv) {
+            const int txi = item / h + 1, y = item - (txi - 1) * h;
+            const int x = txi * TW;                        // >= 1; an origin unless it is the frame's last column
+            const uint32_t p = f.VL[(size_t)txi * h + y];   // pixel (x, y)
+            const uint16_t *lf = f.VR + (size_t)(txi - 1) * h;
+            const uint32_t q = lf[y];                       // pixel (x - 1, y): always an origin column (1 <= x - 1 <= w - 2)
+            const int tp = (y / TH) * tiles_x + txi;       // tile of (x, y); (x - 1, y) lies in tp - 1
+            if (p != 0xFFFFu) ap = f.base[tp] + (p & 0x7FFFu);
+            if (q != 0xFFFFu) aq = f.base[tp - 1] + (q & 0x7FFFu);
+            if (p != 0xFFFFu && x <= w - 2) {
+                if (q != 0xFFFFu && ((q ^ p) & 0x8000u) == 0) b0 = aq;
+                if ((p & 0x8000u) && y > 0) {              // white: up-left
+                    const uint32_t ql = lf[y - 1];
+                    if ((ql & 0x8000u) && ql != 0xFFFFu) b1 = f.base[((y - 1) / TH) * tiles_x + txi - 1] + (ql & 0x7FFFu);
+                }
+            }
+            if (q != 0xFFFFu && (q & 0x8000u) && y > 0) { // white pixel (x - 1, y): up-right is (x, y - 1)
+                const uint32_t pu = f.VL[(size_t)txi * h + y - 1];
+                if ((pu & 0x8000u) && pu != 0xFFFFu) b2 = f.base[((y - 1) / TH) * tiles_x + txi] + (pu & 0x7FFFu);
+            }
         }
-    } else {
-        if (v == 255 && T[p - w + 1] == 255) merge_link(L, sSet, p, p - w + 1);
+        emit(ap, b0, ap, b1, aq, b2);
     }
 }
-
-// ---- ring-touching roots: flatten their entries and accumulate sizes at the global roots ---------------------------------------
-// csize[] was zeroed at every ring-touching root by k_tile, so all parts of a component (the global root's own included)
-// simply add up there.  csize[] is only ever compared with min_component_px: a part that is large enough on its own settles
-// the answer with a plain store (thousands of parts of one frame-spanning component would otherwise queue on one address).
-__global__ __launch_bounds__(NT) void k_roots(uint32_t *__restrict__ labels, uint32_t *__restrict__ csize,
-                                              const ck_border_root *__restrict__ broots,
-                                              const uint32_t *__restrict__ tile_count, int tiles, size_t npix, int min_comp) {
-    const int frame = blockIdx.y;
-    uint32_t *L = labels + (size_t)frame * npix;
-    uint32_t *C = csize + (size_t)frame * npix;
-    const uint32_t slots = (uint32_t)tiles * RING_CAP;
-    for (uint32_t k = blockIdx.x * NT + threadIdx.x; k < slots; k += gridDim.x * NT) {
-        const uint32_t t = k / RING_CAP, l = k - t * RING_CAP;
-        if (l >= tile_count[(size_t)frame * tiles + t]) continue;
-        ck_border_root br = broots[(size_t)frame * 2 * slots + k];
-        uint32_t g = g_find_ro(L, br.root);
-        if (g != br.root) L[br.root] = g | CK_LBL_BORDER; // still a valid ancestor for concurrent finds
-        if ((int)br.size >= min_comp) __hip_atomic_store(&C[g], CSIZE_LARGE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        else atomicAdd(&C[g], br.size);
-    }
-}
-
-// ---- cross-tile merge, one workgroup per frame, in LDS ------------------------------------------------------------------------------
-// k_tile left, for every frame: the list of ring-touching tile-local roots (broots: pixel index + pixel count; a root's list
-// index is its id) and, along every tile boundary, the id and colour of the component each boundary pixel belongs to (ring).
-// A frame's workgroup replays the connectivity rule across the boundaries as unions over ids in LDS — no label, threshold or
-// csize word is read, and every find is an LDS walk — then writes, for every id, the frame-level root into the tile-local
-// root's label word and, at the frame-level roots, the component size into csize[].  The frame-level root must be the
-// component's smallest pixel index (the canonical label), so the union hooks the root with the larger PIXEL under the other;
-// pixel indices live in broots (global memory, read once per union that actually joins two trees).
-constexpr int FM_NT = 1024;
-constexpr int FM_CAP = 32767;                 // ids fit 15 bits (bit 15 of a ring entry is the colour)
-constexpr int FM_LDS = 2 * (FM_CAP + 1) * 2;  // parent u16[FM_CAP + 1] + size u16[FM_CAP + 1]
 
 __device__ __forceinline__ uint32_t fm_find(uint16_t *p, uint32_t a) { // path halving, same argument as lds_find2
     for (;;) {
@@ -734,16 +710,24 @@ __device__ __forceinline__ bool fm_cas16(uint16_t *p, uint32_t idx, uint32_t exp
         wv = prev; // the other half changed (a halving store or another hook): try again
     }
 }
-__device__ __forceinline__ void fm_union(uint16_t *p, const ck_border_root *__restrict__ br, uint32_t a, uint32_t b) {
+// key[] holds the top 16 bits of every root's pixel index (LDS): nearly every comparison is settled there, only two roots in the
+// same key bucket read their exact pixels from the list in global memory
+__device__ __forceinline__ void fm_union(uint16_t *p, const uint16_t *key, const ck_border_root *__restrict__ br, uint32_t a0, uint32_t b0) {
+    uint32_t a = a0, b = b0;
     for (;;) {
         a = fm_find(p, a); b = fm_find(p, b);
-        if (a == b) return;
-        const uint32_t pa = br[a].root, pb = br[b].root; // both are roots right now; a root's pixel never changes
+        if (a == b) break;
+        uint32_t pa = key[a], pb = key[b]; // both are roots right now; a root's pixel never changes
+        if (pa == pb) { pa = br[a].root; pb = br[b].root; }
         const uint32_t hi = pa > pb ? a : b, lo = pa > pb ? b : a;
-        if (fm_cas16(p, hi, hi, lo)) return;   // hooked while still a root: parent pixel < child pixel, so no cycle can form
+        if (fm_cas16(p, hi, hi, lo)) { a = lo; break; } // hooked while still a root: parent pixel < child pixel, so no cycle can form
     }
+    // the two ends now know an ancestor that is (or just was) the root: point them at it, so that the next join of the same
+    // pair of components — boundaries cross a large component at many places — finds it in one step
+    if (a0 != a && p[a0] != a) p[a0] = (uint16_t)a;
+    if (b0 != a && p[b0] != a) p[b0] = (uint16_t)a;
 }
-// saturating add on a u16 entry: the sum is only ever compared with min_component_px (<= 32767)
+// saturating add on a u16 entry: the sum is only ever compared with min_component_px (<= 32767 on this path)
 __device__ __forceinline__ void fm_size_add(uint16_t *sz, uint32_t idx, uint32_t add, uint32_t enough) {
     uint32_t *wp = reinterpret_cast<uint32_t *>(sz) + (idx >> 1);
     const uint32_t sh = (idx & 1u) * 16u;
@@ -759,77 +743,91 @@ __device__ __forceinline__ void fm_size_add(uint16_t *sz, uint32_t idx, uint32_t
     }
 }
 
-// Global-memory variant for a frame with more ring-touching roots than LDS holds (pathological maps): the components are
-// joined through the label words of the tile-local roots, the way k_merge + k_roots do it, by this one workgroup.
-__device__ __forceinline__ void fm_link(uint32_t *L, const uint8_t *T, uint32_t p, uint32_t q) {
-    if (T[p] != T[q]) return;
-    const uint32_t a = g_load(L, p), b = g_load(L, q);
-    if (a != b) g_union_roots(L, a, b);
-}
-__device__ void fm_global_path(uint32_t *L, uint32_t *C, const uint8_t *T, const ck_border_root *__restrict__ br, uint32_t n, int w, int h,
-                               int tiles_x, int tiles_y, int min_comp) {
-    const int tid = threadIdx.x;
-    for (uint32_t i = tid; i < n; i += FM_NT) C[br[i].root] = 0;
-    // every origin pixel on a tile's top row / left column / right column replays its cross-tile links
-    const int per_tile = TW + 2 * (TH - 1);
-    for (int item = tid; item < tiles_x * tiles_y * per_tile; item += FM_NT) {
-        const int tile = item / per_tile, k = item - tile * per_tile;
-        const int tyi = tile / tiles_x, txi = tile - tyi * tiles_x;
-        const int tx0 = txi * TW, ty0 = tyi * TH;
-        int x, y, kind;
-        if (k < TW) { x = tx0 + k; y = ty0; kind = 0; }
-        else if (k < TW + TH - 1) { x = tx0; y = ty0 + 1 + (k - TW); kind = 1; }
-        else { x = tx0 + TW - 1; y = ty0 + 1 + (k - TW - (TH - 1)); kind = 2; }
-        if (x >= w || y >= h || x < 1 || x > w - 2) continue;
-        const uint32_t p = (uint32_t)y * (uint32_t)w + (uint32_t)x;
-        const uint8_t v = T[p];
-        if (v == 127) continue;
-        if (kind == 0) {
-            if (x == tx0 && tx0 > 0) fm_link(L, T, p, p - 1);
-            if (y >= 1) {
-                fm_link(L, T, p, p - w);
-                if (v == 255) { fm_link(L, T, p, p - w - 1); fm_link(L, T, p, p - w + 1); }
-            }
-        } else if (kind == 1) {
-            if (tx0 > 0) { fm_link(L, T, p, p - 1); if (v == 255) fm_link(L, T, p, p - w - 1); }
-        } else if (v == 255 && x + 1 < w) fm_link(L, T, p, p - w + 1);
+// ---- the same steps in global memory, for a frame with more roots than LDS holds (large frames, pathological maps) ----------------
+__device__ __forceinline__ uint32_t gm_load(const uint32_t *a, uint32_t i) { return __hip_atomic_load(&a[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ uint32_t gm_find(uint32_t *p, uint32_t a) {
+    for (;;) {
+        const uint32_t n = gm_load(p, a);
+        if (n == a) return a;
+        const uint32_t g = gm_load(p, n);
+        if (g == n) return n;
+        __hip_atomic_store(&p[a], g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        a = g;
     }
+}
+__device__ __forceinline__ void gm_union(uint32_t *p, const ck_border_root *__restrict__ br, uint32_t a, uint32_t b) {
+    if (a == NOJ || b == NOJ) return;
+    for (;;) {
+        a = gm_find(p, a); b = gm_find(p, b);
+        if (a == b) return;
+        const uint32_t pa = br[a].root, pb = br[b].root;
+        const uint32_t hi = pa > pb ? a : b, lo = pa > pb ? b : a;
+        if (atomicCAS(&p[hi], hi, lo) == hi) return;
+    }
+}
+__device__ void fm_global_path(const FmFrame &f, const ck_border_root *__restrict__ br, uint32_t n, uint32_t *gparent, uint32_t *gsz,
+                               uint32_t *groot, uint32_t *gsize, int tiles) {
+    const int tid = threadIdx.x;
+    for (uint32_t i = tid; i < n; i += FM_NT) { gparent[i] = i; gsz[i] = 0; }
+    __threadfence();
+    __syncthreads();
+    fm_boundaries(f, tid, [&](uint32_t a0, uint32_t b0, uint32_t a1, uint32_t b1, uint32_t a2, uint32_t b2) {
+        gm_union(gparent, br, a0, b0); gm_union(gparent, br, a1, b1); gm_union(gparent, br, a2, b2);
+    });
     __threadfence();
     __syncthreads();
     for (uint32_t i = tid; i < n; i += FM_NT) {
-        const uint32_t g = g_find_ro(L, br[i].root);
-        if (g != br[i].root) L[br[i].root] = g | CK_LBL_BORDER;
-        if ((int)br[i].size >= min_comp) __hip_atomic_store(&C[g], CSIZE_LARGE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        else atomicAdd(&C[g], br[i].size);
+        uint32_t r = i;
+        for (;;) { const uint32_t nx = gm_load(gparent, r); if (nx == r) break; r = nx; }
+        if (r != i) __hip_atomic_store(&gparent[i], r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        atomicAdd(&gsz[r], br[i].size);
+    }
+    __threadfence();
+    __syncthreads();
+    for (uint32_t k = tid; k < (uint32_t)tiles * RING_CAP; k += FM_NT) {
+        const uint32_t t = k / RING_CAP, l = k - t * RING_CAP;
+        if (l >= f.base[t + 1] - f.base[t]) continue;
+        const uint32_t r = gm_load(gparent, f.base[t] + l);
+        groot[k] = br[r].root;
+        gsize[k] = gm_load(gsz, r);
     }
 }
 
-constexpr int FM_MAX_TILES = 320; // frames with more tiles use k_merge + k_roots (ck_create decides)
-__global__ __launch_bounds__(FM_NT) void k_fmerge(uint32_t *__restrict__ labels, uint32_t *__restrict__ csize,
-                                                  ck_border_root *__restrict__ broots, const uint32_t *__restrict__ tile_count,
-                                                  const uint16_t *__restrict__ ring, size_t ring_len, const uint8_t *__restrict__ thresh,
-                                                  size_t npix, int w, int h, int tiles_x, int tiles_y, int min_comp, int lds_cap) {
-    __shared__ __attribute__((aligned(16))) uint8_t fm_lds[FM_LDS]; // 128 KB: one workgroup per CU
+__global__ __launch_bounds__(FM_NT) void k_fmerge(ck_border_root *__restrict__ broots, const uint32_t *__restrict__ tile_count,
+                                                  const uint16_t *__restrict__ ring, size_t ring_len, uint32_t *__restrict__ groot_all,
+                                                  uint32_t *__restrict__ gsize_all, uint32_t *__restrict__ gscratch, size_t npix, int w, int h,
+                                                  int tiles_x, int tiles_y, int min_comp, int lds_cap, int stop_after) {
+    __shared__ __attribute__((aligned(16))) uint8_t fm_lds[FM_LDS]; // 112 KB: one workgroup per CU
     __shared__ uint32_t base[FM_MAX_TILES + 1];
     __shared__ uint32_t wsum[FM_NT / 64];
+    __shared__ uint32_t queue[(FM_NT / 64) * FM_WQ]; // per wave: joins waiting to be worked off
     const int frame = blockIdx.x, tid = threadIdx.x;
     const int tiles = tiles_x * tiles_y;
-    uint32_t *L = labels + (size_t)frame * npix;
-    uint32_t *C = csize + (size_t)frame * npix;
     const size_t slots = (size_t)tiles * RING_CAP;
     const ck_border_root *slice = broots + (size_t)frame * 2 * slots;
-    ck_border_root *br = broots + (size_t)frame * 2 * slots + slots; // the same entries packed: a root's index here is its id
+    ck_border_root *br = broots + (size_t)frame * 2 * slots + slots; // the same entries packed: a root's index here is its number
+    uint32_t *groot = groot_all + (size_t)frame * slots, *gsize = gsize_all + (size_t)frame * slots;
     const uint16_t *fr = ring + (size_t)frame * ring_len;
-    // ids: the tiles' counts, scanned (tiles <= FM_MAX_TILES <= FM_NT: one count per thread)
+    // numbers: the tiles' counts, scanned (up to four tiles per thread)
     {
-        const uint32_t cnt = tid < tiles ? tile_count[(size_t)frame * tiles + tid] : 0u;
-        const uint32_t incl = wave_scan_u32(cnt);
+        const int per = (tiles + FM_NT - 1) / FM_NT; // <= 4
+        uint32_t c[4] = {0, 0, 0, 0}, sum = 0;
+        for (int k = 0; k < per; k++) {
+            const int t = tid * per + k;
+            c[k] = t < tiles ? tile_count[(size_t)frame * tiles + t] : 0u;
+            sum += c[k];
+        }
+        const uint32_t incl = wave_scan_u32(sum);
         if ((tid & 63) == 63) wsum[tid >> 6] = incl;
         __syncthreads();
-        uint32_t off = incl - cnt;
+        uint32_t off = incl - sum;
         for (int k = 0; k < (tid >> 6); k++) off += wsum[k];
-        if (tid < tiles) base[tid] = off;
-        if (tid == tiles - 1) base[tiles] = off + cnt;
+        for (int k = 0; k < per; k++) {
+            const int t = tid * per + k;
+            if (t < tiles) base[t] = off;
+            off += c[k];
+            if (t == tiles - 1) base[tiles] = off;
+        }
         __syncthreads();
     }
     const uint32_t n = base[tiles];
@@ -839,83 +837,89 @@ __global__ __launch_bounds__(FM_NT) void k_fmerge(uint32_t *__restrict__ labels,
         if (l < base[t + 1] - base[t]) br[base[t] + l] = slice[k];
     }
     __syncthreads(); // the packed list was written by this workgroup: visible to it after the barrier
-    if (n > (uint32_t)lds_cap) { fm_global_path(L, C, thresh + (size_t)frame * npix, br, n, w, h, tiles_x, tiles_y, min_comp); return; }
+    if (stop_after == 0) return; // diagnostics (CK_FMERGE_STOP_AFTER)
+    FmFrame f;
+    f.HT = fr; f.HB = fr + (size_t)tiles_y * w; f.VL = fr + 2 * (size_t)tiles_y * w; f.VR = f.VL + (size_t)tiles_x * h;
+    f.base = base; f.w = w; f.h = h; f.tiles_x = tiles_x; f.tiles_y = tiles_y;
+    if (n > (uint32_t)lds_cap || min_comp > 0x7FFF) {
+        uint32_t *sc = gscratch + (size_t)frame * 2 * slots;
+        fm_global_path(f, br, n, sc, sc + slots, groot, gsize, tiles);
+        return;
+    }
     uint16_t *parent = reinterpret_cast<uint16_t *>(fm_lds);
     uint16_t *size16 = parent + ((n + 1u) & ~1u);
-    for (uint32_t i = tid; i < n; i += FM_NT) { parent[i] = (uint16_t)i; size16[i] = 0; }
+    // while the unions run, the size array holds the roots' pixel keys: pixel index >> key_shift, 16 bits
+    int key_shift = 0;
+    while ((npix - 1) >> key_shift > 0xFFFFu) key_shift++;
+    for (uint32_t i = tid; i < n; i += FM_NT) { parent[i] = (uint16_t)i; size16[i] = (uint16_t)(br[i].root >> key_shift); }
     __syncthreads();
-    const uint16_t *HT = fr, *HB = fr + (size_t)tiles_y * w, *VL = fr + 2 * (size_t)tiles_y * w, *VR = VL + (size_t)tiles_x * h;
-    // a ring entry = tile-local id | colour << 15; its frame-level id adds the tile's base
-#define FM_ID(e, tile) (base[tile] + ((e) & 0x7FFFu))
-    // horizontal boundaries: the top row of tile row ty against the bottom row of tile row ty - 1 (up, and for white up-left / up-right)
-    const int nh = (tiles_y - 1) * w;
-    for (int item = tid; item < nh; item += FM_NT) {
-        const int tyi = item / w + 1, x = item - (tyi - 1) * w;
-        if (x < 1 || x > w - 2) continue;                  // not an origin column
-        const uint32_t p = HT[(size_t)tyi * w + x];
-        if (p == 0xFFFFu) continue;
-        const uint16_t *up = HB + (size_t)(tyi - 1) * w;
-        const uint32_t q1 = up[x], q0 = up[x - 1], q2 = up[x + 1];
-        const int trow = (tyi - 1) * tiles_x;
-        const uint32_t ip = FM_ID(p, trow + tiles_x + (x >> 7));
-        if (q1 != 0xFFFFu && ((q1 ^ p) & 0x8000u) == 0) fm_union(parent, br, ip, FM_ID(q1, trow + (x >> 7)));
-        if (p & 0x8000u) { // white
-            if ((q0 & 0x8000u) && q0 != 0xFFFFu) fm_union(parent, br, ip, FM_ID(q0, trow + ((x - 1) >> 7)));
-            if ((q2 & 0x8000u) && q2 != 0xFFFFu) fm_union(parent, br, ip, FM_ID(q2, trow + ((x + 1) >> 7)));
+    const uint16_t *key = size16;
+    // Every boundary pixel yields up to three joins; most lanes have fewer, and a join is a chain of dependent LDS reads.  So the
+    // joins of a wave are queued in LDS (wave prefix sums) and then worked off one per lane, all lanes busy, instead of every
+    // lane running its own zero to three joins while the others wait.
+    uint32_t *wq = queue + (tid >> 6) * FM_WQ;
+    const int lane = tid & 63;
+    uint32_t qn = 0; // joins waiting in the wave's queue (wave-uniform)
+    auto drain = [&]() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (uint32_t j = (uint32_t)lane; j < qn; j += 64) {
+            const uint32_t e = wq[j];
+            fm_union(parent, key, br, e & 0xFFFFu, e >> 16);
         }
-    }
-    // vertical boundaries: the left column of tile column tx against the right column of tile column tx - 1
-    const int nv = (tiles_x - 1) * h;
-    for (int item = tid; item < nv; item += FM_NT) {
-        const int txi = item / h + 1, y = item - (txi - 1) * h;
-        const int x = txi * TW;                            // >= 1; an origin unless it is the frame's last column
-        const uint32_t p = VL[(size_t)txi * h + y];         // pixel (x, y)
-        const uint16_t *lf = VR + (size_t)(txi - 1) * h;
-        const uint32_t q = lf[y];                           // pixel (x - 1, y): always an origin column (1 <= x - 1 <= w - 2)
-        const int tp = (y / TH) * tiles_x + txi;           // tile of (x, y); (x - 1, y) lies in tp - 1
-        if (p != 0xFFFFu && x <= w - 2) {
-            if (q != 0xFFFFu && ((q ^ p) & 0x8000u) == 0) fm_union(parent, br, FM_ID(p, tp), FM_ID(q, tp - 1));
-            if ((p & 0x8000u) && y > 0) {                  // white: up-left
-                const uint32_t ql = lf[y - 1];
-                if ((ql & 0x8000u) && ql != 0xFFFFu) fm_union(parent, br, FM_ID(p, tp), FM_ID(ql, ((y - 1) / TH) * tiles_x + txi - 1));
-            }
-        }
-        if (q != 0xFFFFu && (q & 0x8000u) && y > 0) {     // white pixel (x - 1, y): up-right is (x, y - 1)
-            const uint32_t pu = VL[(size_t)txi * h + y - 1];
-            if ((pu & 0x8000u) && pu != 0xFFFFu) fm_union(parent, br, FM_ID(q, tp - 1), FM_ID(pu, ((y - 1) / TH) * tiles_x + txi));
-        }
-    }
-#undef FM_ID
+        __builtin_amdgcn_wave_barrier();
+        qn = 0;
+    };
+    fm_boundaries(f, tid, [&](uint32_t a0, uint32_t b0, uint32_t a1, uint32_t b1, uint32_t a2, uint32_t b2) {
+        const bool v0 = a0 != NOJ && b0 != NOJ, v1 = a1 != NOJ && b1 != NOJ, v2 = a2 != NOJ && b2 != NOJ;
+        const uint32_t cnt = (uint32_t)v0 + (uint32_t)v1 + (uint32_t)v2;
+        const uint32_t incl = wave_scan_u32(cnt);
+        uint32_t pos = qn + incl - cnt;
+        if (v0) wq[pos++] = a0 | (b0 << 16);
+        if (v1) wq[pos++] = a1 | (b1 << 16);
+        if (v2) wq[pos++] = a2 | (b2 << 16);
+        qn += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        if (qn > FM_WQ - 192) drain();
+    });
+    drain();
     __syncthreads();
+    if (stop_after == 1) return;
     for (uint32_t i = tid; i < n; i += FM_NT) { // flatten (walks only read: other lanes' entries may still be mid-chain)
         uint32_t r = i;
         for (;;) { const uint32_t nx = parent[r]; if (nx == r) break; r = nx; }
         if (r != i) parent[i] = (uint16_t)r; // a non-root entry: rewriting it with its root keeps every other walk valid
+        size16[i] = 0;                       // the keys are dead: the array becomes the sizes
     }
     __syncthreads();
+    if (stop_after == 2) return;
     const uint32_t enough = (uint32_t)min_comp;
     for (uint32_t i = tid; i < n; i += FM_NT) {
         const uint32_t sz = br[i].size;
         fm_size_add(size16, parent[i], sz > 0x7FFFu ? 0x7FFFu : sz, enough);
     }
     __syncthreads();
-    for (uint32_t i = tid; i < n; i += FM_NT) {
-        const uint32_t r = parent[i], pix = br[i].root;
-        if (r != i) L[pix] = br[r].root | CK_LBL_BORDER;   // the tile-local root's word now names the frame-level root
-        else C[pix] = size16[i];                           // exact while below min_component_px, else any value >= it
+    if (stop_after == 3) return;
+    // the tables, slot by slot (a tile's used slots are consecutive, so the writes are too)
+    for (uint32_t k = tid; k < (uint32_t)slots; k += FM_NT) {
+        const uint32_t t = k / RING_CAP, l = k - t * RING_CAP;
+        if (l >= base[t + 1] - base[t]) continue;
+        const uint32_t r = parent[base[t] + l];
+        groot[k] = br[r].root;
+        gsize[k] = size16[r];
     }
 }
 
 // ---- parity / test path: canonical labels and exact sizes ---------------------------------------------------------------------
-__global__ __launch_bounds__(NT) void k_canon(const uint32_t *__restrict__ labels, uint32_t *__restrict__ out, size_t npix, size_t total) {
+__global__ __launch_bounds__(NT) void k_canon(const uint32_t *__restrict__ labels, const uint32_t *__restrict__ groot, size_t slots,
+                                              uint32_t *__restrict__ out, size_t npix, size_t total) {
     size_t i = (size_t)blockIdx.x * NT + threadIdx.x;
     if (i >= total) return;
-    size_t fb = (i / npix) * npix;
     uint32_t l = labels[i];
     uint32_t g = CK_LBL_INVALID;
     if (l != CK_LBL_INVALID) {
         g = l & CK_LBL_IDX_MASK;
-        if (l & CK_LBL_BORDER) g = labels[fb + g] & CK_LBL_IDX_MASK;
+        if (l & CK_LBL_BORDER) g = groot[(i / npix) * slots + g]; // a ring-touching component: the word carries its slot
     }
     out[i] = g;
 }
@@ -954,24 +958,18 @@ int ck_launch_threshold_segment(ck_handle *h, const uint8_t *frames, int stride,
     if (precomputed)
         hipLaunchKernelGGL(k_tile<true>, dim3(grid), dim3(KNT), 0, h->stream, frames, frame_pitch, stride, h->qw, h->qh,
                            h->tiles_x, h->tiles_y, n, xcd_map, h->cfg.min_white_black_diff, h->cfg.min_component_px, h->d_thresh, h->d_labels,
-                           h->d_broots, h->d_tile_count, h->d_csize, h->d_ring, h->ring_len, h->lds_merge ? 1 : 0, stop_after);
+                           h->d_broots, h->d_tile_count, h->d_ring, h->ring_len, stop_after);
     else
         hipLaunchKernelGGL(k_tile<false>, dim3(grid), dim3(KNT), 0, h->stream, frames, frame_pitch, stride, h->qw, h->qh,
                            h->tiles_x, h->tiles_y, n, xcd_map, h->cfg.min_white_black_diff, h->cfg.min_component_px, h->d_thresh, h->d_labels,
-                           h->d_broots, h->d_tile_count, h->d_csize, h->d_ring, h->ring_len, h->lds_merge ? 1 : 0, stop_after);
-    if (h->lds_merge) {
+                           h->d_broots, h->d_tile_count, h->d_ring, h->ring_len, stop_after);
+    {
+        static const int fm_stop = getenv("CK_FMERGE_STOP_AFTER") ? atoi(getenv("CK_FMERGE_STOP_AFTER")) : 99;
         const char *cap_env = getenv("CK_FMERGE_CAP"); // tests force the global-memory path with a small value (read per call)
         const int cap = (cap_env && atoi(cap_env) < FM_CAP) ? atoi(cap_env) : FM_CAP;
-        hipLaunchKernelGGL(k_fmerge, dim3((unsigned)n), dim3(FM_NT), 0, h->stream, h->d_labels, h->d_csize, h->d_broots, h->d_tile_count,
-                           h->d_ring, h->ring_len, h->d_thresh, h->npix, h->qw, h->qh, h->tiles_x, h->tiles_y, h->cfg.min_component_px, cap);
-    } else {
-        hipLaunchKernelGGL(k_merge, dim3((unsigned)(tiles * n)), dim3(NT), 0, h->stream, h->d_thresh, h->d_labels, h->qw, h->qh,
-                           h->tiles_x, h->tiles_y);
-        int bx = (h->broot_cap + NT * 8 - 1) / (NT * 8);
-        if (bx < 1) bx = 1;
-        if (bx > 64) bx = 64;
-        hipLaunchKernelGGL(k_roots, dim3((unsigned)bx, (unsigned)n), dim3(NT), 0, h->stream, h->d_labels, h->d_csize, h->d_broots,
-                           h->d_tile_count, tiles, h->npix, h->cfg.min_component_px);
+        hipLaunchKernelGGL(k_fmerge, dim3((unsigned)n), dim3(FM_NT), 0, h->stream, h->d_broots, h->d_tile_count, h->d_ring, h->ring_len,
+                           h->d_groot, h->d_gsize, h->d_gscratch, h->npix, h->qw, h->qh, h->tiles_x, h->tiles_y, h->cfg.min_component_px, cap,
+                           fm_stop);
     }
     CK_HIP(hipGetLastError());
     return CK_OK;
@@ -980,7 +978,7 @@ int ck_launch_threshold_segment(ck_handle *h, const uint8_t *frames, int stride,
 int ck_launch_canonical_labels(ck_handle *h, int n, uint32_t *d_out, uint32_t *d_sizes) {
     size_t total = h->npix * (size_t)n;
     unsigned blocks = (unsigned)((total + NT - 1) / NT);
-    hipLaunchKernelGGL(k_canon, dim3(blocks), dim3(NT), 0, h->stream, h->d_labels, d_out, h->npix, total);
+    hipLaunchKernelGGL(k_canon, dim3(blocks), dim3(NT), 0, h->stream, h->d_labels, h->d_groot, (size_t)h->broot_cap, d_out, h->npix, total);
     if (d_sizes) {
         // exact sizes by counting: test path only (the pipeline uses the SMALL flag / csize[] instead)
         uint32_t *cnt = nullptr;

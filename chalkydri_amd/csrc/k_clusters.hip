@@ -31,7 +31,8 @@ __device__ __forceinline__ uint32_t key_hash(unsigned long long k) {
 struct EmitArgs {
     const uint8_t *thresh;
     const uint32_t *labels;
-    const uint32_t *csize;
+    const uint32_t *groot, *gsize; // slot tables of the ring-touching components (k_ccl.hip: k_fmerge)
+    size_t slots;
     int w, h, tiles_x, tiles_y, min_comp;
     int stop_after; // diagnostics (CK_EMIT_STOP_AFTER): 0 staging only, 1 +count, 2 +reserve; 99 = everything
     ck_stage_ws ws;
@@ -52,7 +53,7 @@ __global__ __launch_bounds__(NT) void k_emit(EmitArgs a) {
     const size_t npix = (size_t)w * h;
     const uint8_t *T = a.thresh + (size_t)frame * npix;
     const uint32_t *L = a.labels + (size_t)frame * npix;
-    const uint32_t *C = a.csize + (size_t)frame * npix;
+    const uint32_t *GR = a.groot + (size_t)frame * a.slots, *GS = a.gsize + (size_t)frame * a.slots;
     const ck_stage_ws &ws = a.ws;
     unsigned long long *gkeys = ws.d_ht_keys + (size_t)frame * ws.ht_size;
     uint32_t *gcount = ws.d_ht_count + (size_t)frame * ws.ht_size;
@@ -78,12 +79,11 @@ __global__ __launch_bounds__(NT) void k_emit(EmitArgs a) {
             }
         }
 #pragma unroll
-        for (int q = 0; q < SPT; q++) { // ring-touching components: the tile-local root's word holds the frame-level root
+        for (int q = 0; q < SPT; q++) { // ring-touching components: the word holds a slot; root and size come from the frame's tables
             const bool two = tv[q] != 127 && !(lab[q] & CK_LBL_SMALL) && (lab[q] & CK_LBL_BORDER);
-            hop[q] = two ? L[lab[q] & CK_LBL_IDX_MASK] : CK_LBL_INVALID;
+            hop[q] = two ? GR[lab[q] & CK_LBL_IDX_MASK] : CK_LBL_INVALID;
+            csz[q] = two ? GS[lab[q] & CK_LBL_IDX_MASK] : 0u;
         }
-#pragma unroll
-        for (int q = 0; q < SPT; q++) csz[q] = (hop[q] != CK_LBL_INVALID) ? C[hop[q] & CK_LBL_IDX_MASK] : 0u;
 #pragma unroll
         for (int q = 0; q < SPT; q++) {
             const int i = tid + q * NT;
@@ -395,7 +395,7 @@ int ck_launch_clusters(ck_handle *h, int n) {
                            (uint32_t)(CK_CNT_STRIDE * n), fl.list_counts, 16u, fl.cand_count, (uint32_t)n);
     }
     EmitArgs a;
-    a.thresh = h->d_thresh; a.labels = h->d_labels; a.csize = h->d_csize;
+    a.thresh = h->d_thresh; a.labels = h->d_labels; a.groot = h->d_groot; a.gsize = h->d_gsize; a.slots = (size_t)h->broot_cap;
     a.w = h->qw; a.h = h->qh; a.tiles_x = (h->qw + ETW - 1) / ETW; a.tiles_y = (h->qh + ETH - 1) / ETH;
     a.min_comp = h->cfg.min_component_px; a.ws = ws;
     { static const int stop_after = getenv("CK_EMIT_STOP_AFTER") ? atoi(getenv("CK_EMIT_STOP_AFTER")) : 99; a.stop_after = stop_after; }

@@ -91,8 +91,51 @@ static int check(const std::vector<uint8_t> &t, int w, int h, const char *what) 
                     }
                 }
             }
+    // the word-level statement of the same links (ck_links_of_word): replayed into a second forest, which must give the same partition
+    std::vector<uint32_t> parent2((size_t)w * h);
+    for (size_t i = 0; i < parent2.size(); i++) parent2[i] = (uint32_t)i;
+    size_t n_links2 = 0;
+    for (int y = 0; y < h; y++)
+        for (int wd = 0; wd < nw; wd++)
+            for (int c = 0; c < 2; c++) {
+                const uint32_t M = m[((size_t)y * nw + wd) * 2 + c];
+                if (!M) continue;
+                const uint32_t O = ck_origin32(wd * 32, w);
+                const uint32_t U = y > 0 ? m[((size_t)(y - 1) * nw + wd) * 2 + c] : 0u;
+                const uint32_t S = ck_starts32(M, O), Su = ck_starts32(U, O);
+                const uint32_t Mp = wd > 0 ? m[((size_t)y * nw + wd - 1) * 2 + c] : 0u;
+                const uint32_t Up = (y > 0 && wd > 0) ? m[((size_t)(y - 1) * nw + wd - 1) * 2 + c] : 0u;
+                const bool un0 = y > 0 && wd < nw - 1 && (m[((size_t)(y - 1) * nw + wd + 1) * 2 + c] & 1u);
+                const bool on0 = wd < nw - 1 && (ck_origin32((wd + 1) * 32, w) & 1u);
+                const ck_word_links L = ck_links_of_word(c == 0, M, U, O, (Mp >> 31) != 0, (Up >> 31) != 0, un0, on0);
+                const uint32_t rowb = (uint32_t)(y * w + wd * 32), upb = (uint32_t)((y - 1) * w + wd * 32);
+                for (uint32_t R = M; R; R &= R - 1) { const int x = ck_ctz32(R); parent2[rowb + x] = rowb + ck_run_start32(S, x); }
+                const uint32_t Opv = wd > 0 ? ck_origin32((wd - 1) * 32, w) : 0u;
+                if (L.hleft) { uf_union(parent2, rowb, rowb - 32 + ck_last_start32(ck_starts32(Mp, Opv))); n_links2++; }
+                for (uint32_t E = L.Ev; E; E &= E - 1) {
+                    const int x = ck_ctz32(E);
+                    uf_union(parent2, rowb + ck_run_start32(S, x), upb + ck_run_start32(Su, x)); n_links2++;
+                }
+                for (uint32_t E = L.DL; E; E &= E - 1) {
+                    const int x = ck_ctz32(E);
+                    const uint32_t tgt = x > 0 ? upb + ck_run_start32(Su, x - 1) : upb - 32 + ck_last_start32(ck_starts32(Up, Opv));
+                    uf_union(parent2, rowb + ck_run_start32(S, x), tgt); n_links2++;
+                }
+                for (uint32_t E = L.DR; E; E &= E - 1) {
+                    const int x = ck_ctz32(E);
+                    uf_union(parent2, rowb + ck_run_start32(S, x), upb + x + 1); n_links2++;
+                }
+            }
     std::vector<uint32_t> lab((size_t)w * h), sz((size_t)w * h), cnt((size_t)w * h, 0u);
     ora_segment(t.data(), w, h, lab.data(), sz.data());
+    for (size_t i = 0; i < lab.size(); i++) {
+        uint32_t mine = t[i] == 127 ? 0xFFFFFFFFu : uf_find(parent2, (uint32_t)i);
+        if (mine != lab[i]) {
+            fprintf(stderr, "FAIL(word links) %s %dx%d: pixel (%d,%d) label %u, oracle %u\n", what, w, h, (int)(i % w), (int)(i / w), mine, lab[i]);
+            return 1;
+        }
+    }
+    if (n_links2 > 2 * n_runs + 8) { fprintf(stderr, "FAIL %s: %zu word links for %zu runs\n", what, n_links2, n_runs); return 1; }
     for (size_t i = 0; i < lab.size(); i++) {
         uint32_t mine = t[i] == 127 ? 0xFFFFFFFFu : uf_find(parent, (uint32_t)i);
         if (mine != lab[i]) {
