@@ -38,47 +38,55 @@ static_assert(TH * 8 == KNT, "threshold / label passes: one 16-pixel chunk per t
 static_assert(TH * TW <= 4096, "run list entries keep the node in 12 bits, the colour in bit 12");
 static_assert(TW == 128, "a node index splits with >> 7 / & 127");
 
-// LDS of k_tile, 25.7 KB, so that six workgroups (24 waves) share a CU:
-//   parent  u16[TH*TW]  tile-local node index of the parent (nodes = first pixels of runs); while the threshold is computed
-//                       the same bytes hold the staged image, the 4x4 min/max and the per-4x4 threshold words
-//   size    u16[TH*TW]  at the roots: exact pixel count in bits 0..14 (a tile has 4096 pixels) | bit 15 = touches the tile
-//                       ring; before that the same bytes are the pool of links that need an atomic union
+// LDS of k_tile, 19.6 KB, so that eight workgroups (32 waves: all a CU can hold) share a CU:
+//   parent  u16[TH*TW]  one entry per node (nodes = first pixels of runs):
+//                         non-root: tile-local index of the parent (bit 15 clear)
+//                         root:     CK_ROOT | pixel count of the component in bits 0..12 (a tile has 4096 pixels) | CK_RING when it
+//                                   touches the tile ring — the union-find's sizes live in the roots' own entries
+//                       after the flatten passes every entry is a component code that the label pass expands (P6c);
+//                       while the threshold is computed the same bytes hold the staged image, the 4x4 min/max and the
+//                       per-4x4 threshold words
 //   list    u16[TH*TW]  the tile's runs in scan order: node | colour << 12 (worst case one run per pixel)
+//   pool    u32[POOL_CAP]  links that need an atomic union (two u16 nodes each)
 //   masks   u32[TH][NWD][2]  colour bits of every row word (0 white, 1 black)
 constexpr int OFF_PARENT = 0;                              // u16[TH*TW] = 8192
 constexpr int OFF_IMG = 0;                                 // IMG_ROWS*IMG_PITCH = 6400
-constexpr int OFF_MINMAX = OFF_IMG + IMG_ROWS * IMG_PITCH; // u16[T4Y*T4X] = 700 -> 704
+constexpr int OFF_MINMAX = OFF_IMG + IMG_ROWS * IMG_PITCH; // u16[T4Y*T4X] = 680 -> 704
 constexpr int OFF_THR = OFF_MINMAX + 704;                  // u16[(TH/4)*(TW/4)] = 512
-constexpr int OFF_SIZE = TH * TW * 2;                      // u16[TH*TW] = 8192
-constexpr int OFF_LIST = OFF_SIZE + TH * TW * 2;           // u16[TH*TW] = 8192
-constexpr int OFF_MASK = OFF_LIST + TH * TW * 2;           // u32[TH][NWD][2] = 1024
+constexpr int OFF_LIST = TH * TW * 2;                      // u16[TH*TW] = 8192
+constexpr int POOL_CAP = 640;                              // dense binary noise leaves about 340 links per tile for the pool
+constexpr int OFF_POOL = OFF_LIST + TH * TW * 2;           // u32[POOL_CAP] = 2560
+constexpr int OFF_MASK = OFF_POOL + POOL_CAP * 4;          // u32[TH][NWD][2] = 1024
 constexpr int OFF_MISC = OFF_MASK + TH * NWD * 2 * 4;      // u32[16]
 constexpr int LDS_BYTES = OFF_MISC + 64;
-constexpr int POOL_CAP = TH * TW * 2 / 4;                  // links (two u16 nodes each) that fit the size array
 constexpr int RING_CAP = CK_RING_CAP;                      // ring-touching roots of a tile: at most one per ring pixel
+constexpr uint32_t CK_ROOT = 0x8000u, CK_RING = 0x4000u, CK_COUNT = 0x1FFFu;
 static_assert(T4Y * T4X * 2 <= 704, "min/max scratch size");
-static_assert(OFF_THR + (TH / 4) * (TW / 4) * 2 <= OFF_SIZE, "threshold scratch must fit in the parent array");
-static_assert(LDS_BYTES <= 27136, "keep six workgroups per CU");
+static_assert(OFF_THR + (TH / 4) * (TW / 4) * 2 <= OFF_LIST, "threshold scratch must fit in the parent array");
+static_assert(LDS_BYTES <= 20480, "keep eight workgroups per CU");
+static_assert(TH * TW <= CK_COUNT, "a component's pixel count fits below the flags of a root entry");
 
 // find with path halving.  Plain stores race with the min-hooks of lds_union, but every value ever written to p[a]
 // is an ancestor of a, so the forest stays valid (a lost hook is re-issued by its own union).
 // Two halving finds walked in lockstep: both chains have a read in flight at every step
 // (plain loads behind compiler barriers, not volatile ones: a volatile read is waited for before the next is issued, which
-// would put the two chains' reads one after the other)
+// would put the two chains' reads one after the other).  A root is an entry with CK_ROOT set.
 __device__ __forceinline__ void lds_find2(uint16_t *p, uint32_t &a, uint32_t &b) {
     for (;;) {
         __asm__ volatile("" ::: "memory");
-        uint32_t na = p[a], nb = p[b];
-        bool da = (na == a), db = (nb == b);
+        const uint32_t na = p[a], nb = p[b];
+        const bool da = (na & CK_ROOT) != 0, db = (nb & CK_ROOT) != 0;
         if (da && db) return;
+        const uint32_t ia = da ? a : na, ib = db ? b : nb; // the parents (or the roots themselves)
         __asm__ volatile("" ::: "memory");
-        uint32_t ga = p[na], gb = p[nb];
-        if (!da) { if (ga != na) p[a] = (uint16_t)ga; a = ga; }
-        if (!db) { if (gb != nb) p[b] = (uint16_t)gb; b = gb; }
+        const uint32_t ga = p[ia], gb = p[ib];
+        if (!da) { if (!(ga & CK_ROOT)) { p[a] = (uint16_t)ga; a = ga; } else a = ia; }
+        if (!db) { if (!(gb & CK_ROOT)) { p[b] = (uint16_t)gb; b = gb; } else b = ib; }
     }
 }
 // atomic min on one u16 entry (LDS has no 16-bit atomics): compare-and-swap on the word that holds it.  Returns the
-// entry's previous value.  A concurrent halving store to the other half only makes the swap fail and retry.
+// entry's previous value (a root's entry, CK_ROOT | ..., is larger than any index, so the min hooks it).  A concurrent halving
+// store to the other half only makes the swap fail and retry.
 __device__ __forceinline__ uint32_t lds_min16(uint16_t *p, uint32_t idx, uint32_t val) {
     uint32_t *wp = reinterpret_cast<uint32_t *>(p) + (idx >> 1);
     const uint32_t sh = (idx & 1u) * 16u;
@@ -91,15 +99,15 @@ __device__ __forceinline__ uint32_t lds_min16(uint16_t *p, uint32_t idx, uint32_
         wv = prev;
     }
 }
-// root = smaller index
+// root = smaller index (unions run before any size is accumulated: the roots' entries are bare CK_ROOT)
 __device__ __forceinline__ void lds_union(uint16_t *p, uint32_t a, uint32_t b) {
     for (;;) {
         lds_find2(p, a, b);
         if (a == b) return;
         if (a < b) { uint32_t t = a; a = b; b = t; }
-        uint32_t old = lds_min16(p, a, b);
-        if (old == a) return;
-        a = old;
+        const uint32_t old = lds_min16(p, a, b);
+        if (old & CK_ROOT) return; // a was still a root: hooked
+        a = old;                   // somebody hooked it first: go on from its parent
     }
 }
 // gathers bit 7 of each byte of v into a nibble (bit k = byte k)
@@ -175,7 +183,7 @@ __global__ __launch_bounds__(KNT) void k_tile(const uint8_t *__restrict__ frames
                                              int w, int h, int tiles_x, int tiles_y, int n_frames, int xcd_map, int min_diff, int min_comp,
                                              uint8_t *__restrict__ thresh, uint32_t *__restrict__ labels,
                                              ck_border_root *__restrict__ broots, uint32_t *__restrict__ tile_count,
-                                             uint16_t *__restrict__ ring, size_t ring_len, int stop_after) {
+                                             uint16_t *__restrict__ ring, size_t ring_len, int stop_after, int sweeps) {
     __shared__ __attribute__((aligned(16))) uint8_t lds[LDS_BYTES];
     const int tid = threadIdx.x;
     const int tiles = tiles_x * tiles_y;
@@ -191,8 +199,7 @@ __global__ __launch_bounds__(KNT) void k_tile(const uint8_t *__restrict__ frames
     const uint8_t *img = frames + (size_t)frame * frame_pitch;
     const size_t fbase = (size_t)frame * (size_t)w * (size_t)h;
     uint16_t *parent = reinterpret_cast<uint16_t *>(lds + OFF_PARENT);
-    uint16_t *size16 = reinterpret_cast<uint16_t *>(lds + OFF_SIZE);
-    uint32_t *size32 = reinterpret_cast<uint32_t *>(lds + OFF_SIZE);
+    uint32_t *parent32 = reinterpret_cast<uint32_t *>(lds + OFF_PARENT);
     uint16_t *list = reinterpret_cast<uint16_t *>(lds + OFF_LIST);
     uint32_t *mk = reinterpret_cast<uint32_t *>(lds + OFF_MASK);
     uint32_t *misc = reinterpret_cast<uint32_t *>(lds + OFF_MISC); // [0..3] wave run counts, [5] pooled links, [6] ring-touching roots
@@ -329,7 +336,7 @@ __global__ __launch_bounds__(KNT) void k_tile(const uint8_t *__restrict__ frames
     // (ck_links_of_word) and gives every run ONE earlier run as parent with a plain store — only the owner writes the entry and
     // nothing reads parent[] in this phase, so no find and no atomic is needed; the target has a smaller index, which keeps the
     // forest invariant parent <= self.  (c) The links that are left over go to the pool for the atomic unions of P5c.
-    uint32_t *pool = size32;
+    uint32_t *pool = reinterpret_cast<uint32_t *>(lds + OFF_POOL);
     {
         const int r = tid >> 3, wd = (tid >> 1) & 3, c = tid & 1;
         const bool has_l = wd > 0, has_u = r > 0, has_r = wd < NWD - 1, white = c == 0;
@@ -366,7 +373,7 @@ __global__ __launch_bounds__(KNT) void k_tile(const uint8_t *__restrict__ frames
             const uint32_t t_dl = x > 0 ? upbase + (uint32_t)ck_run_start32(Su, x - 1) : up_l;
             const uint32_t t_dr = upbase + (uint32_t)x + 1u;
             const bool use_left = !e && i == 0 && hl;
-            const uint32_t tgt = e ? (is_ev ? t_ev : (is_dl ? t_dl : t_dr)) : (use_left ? left : wbase + (uint32_t)i);
+            const uint32_t tgt = e ? (is_ev ? t_ev : (is_dl ? t_dl : t_dr)) : (use_left ? left : CK_ROOT); // no earlier run: a root (count 0 for now)
             const uint32_t clr = e ? ~bit : 0xFFFFFFFFu;
             Ev &= is_ev ? clr : 0xFFFFFFFFu;
             DL &= (!is_ev && is_dl) ? clr : 0xFFFFFFFFu;
@@ -409,11 +416,12 @@ __global__ __launch_bounds__(KNT) void k_tile(const uint8_t *__restrict__ frames
     // ---- P5b: one pointer-jumping sweep over the (static) adoption forest, in scan order: a run's parent lies in an earlier
     // row (or earlier in its own), which the sweep has usually flattened by the time the run is reached, so the chains
     // down a tag edge (one hop per row) collapse before the finds of the next two phases walk them
+    for (int sweep = 0; sweep < sweeps; sweep++)
     for (uint32_t j = (uint32_t)tid; j < nruns; j += KNT) {
         const uint32_t p = list[j] & 0xFFFu;
         const uint32_t q = parent[p];
-        const uint32_t g = parent[q];
-        if (g != q) parent[p] = (uint16_t)g;
+        const uint32_t g = parent[q & 0xFFFu]; // (a root's own entry has no parent to look at: the read is harmless, the result unused)
+        if (!(q & CK_ROOT) && !(g & CK_ROOT)) parent[p] = (uint16_t)g;
     }
     __syncthreads();
     TPROF(5);
@@ -436,10 +444,8 @@ __global__ __launch_bounds__(KNT) void k_tile(const uint8_t *__restrict__ frames
     TCOUNT(9, nruns); TCOUNT(10, npool);
     TPROF(6);
     if (stop_after == 6) return; // diagnostics (CK_TILE_STOP_AFTER)
-    for (int i = tid * 4; i < TH * TW / 2; i += KNT * 4) *reinterpret_cast<uint4 *>(size32 + i) = make_uint4(0, 0, 0, 0); // pool -> sizes
-    __syncthreads();
-    // ---- P6: flatten the runs' entries and add their pixels (and ring flags) at the roots; two runs per lane and round so
-    // that two root walks are in flight (a lane past the end walks run 0 again and writes nothing)
+    // ---- P6: flatten the runs' entries and add their pixels (and ring flags) into their roots' entries; two runs per lane and
+    // round so that two root walks are in flight (a lane past the end walks run 0 again and writes nothing)
     for (uint32_t j0 = 0; j0 < nruns; j0 += 2 * KNT) {
         uint32_t node[2], root[2], add[2];
         bool live[2];
@@ -455,37 +461,37 @@ __global__ __launch_bounds__(KNT) void k_tile(const uint8_t *__restrict__ frames
             const bool ring = ((r == 0) & (ty0 > 0)) | ((r == TH - 1) & (ty0 + TH < h)) | ((wd == 0) & (tx0 > 0) & ((R & 1u) != 0)) |
                               ((wd == NWD - 1) & (tx0 + TW < w) & ((R >> 31) != 0));
             node[q] = p; root[q] = p;
-            add[q] = (uint32_t)__popc(R) | (ring ? 0x8000u : 0u);
+            add[q] = (uint32_t)__popc(R) | (ring ? CK_RING : 0u);
         }
         for (int it = 0; it < TH * TW; it++) { // plain loads behind a compiler barrier: the two reads of a step go out together
             __asm__ volatile("" ::: "memory");
             const uint32_t n0 = parent[root[0]], n1 = parent[root[1]];
-            if (n0 == root[0] && n1 == root[1]) break;
-            root[0] = n0; root[1] = n1;
+            const bool d0 = (n0 & CK_ROOT) != 0, d1 = (n1 & CK_ROOT) != 0;
+            if (d0 && d1) break;
+            root[0] = d0 ? root[0] : n0; root[1] = d1 ? root[1] : n1;
         }
 #pragma unroll
         for (int q = 0; q < 2; q++)
             if (live[q]) {
-                parent[node[q]] = (uint16_t)root[q];
-                // one add carries the count and the ring bit: counts stay below 2^15 (a tile has 4096 pixels) ... but the ring bit
-                // must be OR-ed, not added (several ring runs of one component)
+                if (root[q] != node[q]) parent[node[q]] = (uint16_t)root[q];
+                // the root's own entry takes the count (bits 0..12: a tile has 4096 pixels, so no carry reaches the flags or the
+                // other half of the word); the ring bit must be OR-ed, not added (several ring runs of one component)
                 const uint32_t sh = (root[q] & 1u) * 16u;
-                atomicAdd(&size32[root[q] >> 1], (add[q] & 0x7FFFu) << sh);
-                if (add[q] & 0x8000u) atomicOr(&size32[root[q] >> 1], 0x8000u << sh);
+                atomicAdd(&parent32[root[q] >> 1], (add[q] & CK_COUNT) << sh);
+                if (add[q] & CK_RING) atomicOr(&parent32[root[q] >> 1], CK_RING << sh);
             }
     }
     __syncthreads();
     // ---- P6b: the roots whose component touches the tile ring get their tile-local id (= place in the tile's slice of the
-    // frame's list, which takes the root's pixel and the component's pixel count); the id replaces the count in the size array
-    // (bit 15 stays set): that is what the label pass and the ring pass look up.  No global atomic: the slice has room for one
-    // root per ring pixel.
+    // frame's list, which takes the root's pixel and the component's pixel count); the id replaces the count in the root's entry
+    // (the flags stay): that is what the label pass looks up.  No global atomic: the slice has room for one root per ring pixel.
     {
         ck_border_root *slice = broots + ((size_t)frame * 2 * tiles + tile) * RING_CAP; // [frame][slices | packed copy]
         for (uint32_t j0 = 0; j0 < nruns; j0 += KNT) {
             const uint32_t j = j0 + (uint32_t)tid;
             const uint32_t p = list[j < nruns ? j : 0u] & 0xFFFu;
-            const uint32_t sw = size16[p];
-            const bool is = j < nruns && parent[p] == p && (sw & 0x8000u);
+            const uint32_t sw = parent[p];
+            const bool is = j < nruns && (sw & (CK_ROOT | CK_RING)) == (CK_ROOT | CK_RING);
             const unsigned long long bal = __ballot(is);
             if (bal) {
                 uint32_t wb = 0;
@@ -495,22 +501,24 @@ __global__ __launch_bounds__(KNT) void k_tile(const uint8_t *__restrict__ frames
                     const uint32_t id = wb + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
                     ck_border_root br;
                     br.root = (uint32_t)(ty0 + (int)(p >> 7)) * (uint32_t)w + (uint32_t)(tx0 + (int)(p & (TW - 1)));
-                    br.size = sw & 0x7FFFu;
+                    br.size = sw & CK_COUNT;
                     slice[id] = br; // id < RING_CAP: a ring-touching root owns at least one ring pixel
-                    size16[p] = (uint16_t)(0x8000u | id);
+                    parent[p] = (uint16_t)(CK_ROOT | CK_RING | id);
                 }
             }
         }
     }
     __syncthreads();
-    // ---- P6c: every run's entry becomes the 16-bit code of its component, which the label pass expands per pixel with ONE lookup:
-    // ring-touching: 0x8000 | id; interior: root node | 0x4000 when smaller than min_component_px.  (A run reads its own entry —
-    // flat since P6 — and its root's size entry, and rewrites only its own: no other run reads it any more.)
+    // ---- P6c: every non-root run's entry becomes the 16-bit code of its component, which the label pass expands per pixel with
+    // ONE lookup: ring-touching: CK_RING | id; interior: root node | 0x2000 when smaller than min_component_px.  (A run reads
+    // its own entry — flat since P6 — and its root's entry, and rewrites only its own, which no other run reads any more; the
+    // roots keep their entries: CK_ROOT | CK_RING | id, or CK_ROOT | count.)
     for (uint32_t j = (uint32_t)tid; j < nruns; j += KNT) {
         const uint32_t p = list[j] & 0xFFFu;
         const uint32_t root = parent[p];
-        const uint32_t sw = size16[root];
-        parent[p] = (uint16_t)((sw & 0x8000u) ? sw : (root | ((int)sw < min_comp ? 0x4000u : 0u)));
+        if (root & CK_ROOT) continue;
+        const uint32_t sw = parent[root];
+        parent[p] = (uint16_t)((sw & CK_RING) ? (CK_RING | (sw & 0x1FFu)) : (root | ((int)(sw & CK_COUNT) < min_comp ? 0x2000u : 0u)));
     }
     __syncthreads();
     } // tile_has_runs
@@ -549,17 +557,21 @@ __global__ __launch_bounds__(KNT) void k_tile(const uint8_t *__restrict__ frames
                 cur = ((st4 >> k) & 1u) ? cbase + (uint32_t)k : cur;
                 codev[k] = cur;
             }
+            uint32_t nodev[4];
 #pragma unroll
-            for (int k = 0; k < 4; k++) codev[k] = parent[codev[k]]; // the component's code (P6c); undefined for an uncoloured pixel, whose word is not used
+            for (int k = 0; k < 4; k++) { nodev[k] = codev[k]; codev[k] = parent[codev[k]]; } // the component's code (P6c); undefined for an uncoloured pixel, whose word is not used
             const uint32_t gbase = (uint32_t)ty0 * (uint32_t)w + (uint32_t)tx0;
             const uint32_t slot0 = CK_LBL_BORDER | ((uint32_t)tile * RING_CAP);
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                const uint32_t c = codev[k], node = c & 0xFFFu;
+                const uint32_t c = codev[k];
+                const bool is_root = (c & CK_ROOT) != 0;
+                const uint32_t node = is_root ? nodev[k] : (c & 0xFFFu);                                   // the component's root node
+                const bool small = is_root ? (int)(c & CK_COUNT) < min_comp : (c & 0x2000u) != 0;
                 // interior component: the root's pixel index, final; ring-touching: the component's slot in the frame's tables
-                const uint32_t word = (c & 0x8000u) ? slot0 + (c & 0x7FFFu) : ((gbase + (node >> 7) * (uint32_t)w + (node & (TW - 1))) | ((c & 0x4000u) << 17));
+                const uint32_t word = (c & CK_RING) ? slot0 + (c & 0x1FFu) : ((gbase + (node >> 7) * (uint32_t)w + (node & (TW - 1))) | (small ? CK_LBL_SMALL : 0u));
                 outw[k] = ((any4 >> k) & 1u) ? word : CK_LBL_INVALID;
-                ringv[k] = c;
+                ringv[k] = c & 0x1FFu;
             }
         }
         // the lanes on the tile's edges also leave the ids (and colours) of their pixels' components for the merge stage
@@ -567,7 +579,7 @@ __global__ __launch_bounds__(KNT) void k_tile(const uint8_t *__restrict__ frames
         if (rr == 0 || rr == TH - 1 || g == 0 || g == 31) {
             uint32_t rv[4];
 #pragma unroll
-            for (int k = 0; k < 4; k++) rv[k] = ((any4 >> k) & 1u) ? ((ringv[k] & 0x7FFFu) | (((w4 >> k) & 1u) << 15)) : 0xFFFFu;
+            for (int k = 0; k < 4; k++) rv[k] = ((any4 >> k) & 1u) ? (ringv[k] | (((w4 >> k) & 1u) << 15)) : 0xFFFFu;
             if (rr == 0 || rr == TH - 1) {
                 uint16_t *dr = ring_f + (rr == 0 ? (size_t)0 : (size_t)tiles_y * w) + (size_t)ty * w + (size_t)gx;
                 if (gx + 4 <= w && (w & 3) == 0) *reinterpret_cast<uint2 *>(dr) = make_uint2(rv[0] | (rv[1] << 16), rv[2] | (rv[3] << 16));
@@ -638,7 +650,8 @@ __device__ __forceinline__ void fm_boundaries(const FmFrame &f, int tid, Emit &&
         uint32_t a0 = NOJ, b0 = NOJ, b1 = NOJ, b2 = NOJ;
         if (item < nh) {
             const int tyi = item / w + 1, x = item - (tyi - 1) * w;
-            if (x >= 1 && x <= w - 2) {                    // an origin column
+            const int tlow = (tyi - 1) * tiles_x + tiles_x + (x >> 7);
+            if (x >= 1 && x <= w - 2 && f.base[tlow + 1] != f.base[tlow]) { // an origin column of a tile that has ring-touching roots
                 const uint16_t *up = f.HB + (size_t)(tyi - 1) * w;
                 const uint32_t p = f.HT[(size_t)tyi * w + x], q1 = up[x], q0 = up[x - 1], q2 = up[x + 1], pl = f.HT[(size_t)tyi * w + x - 1];
                 // the pixel on the left made the same joins when it is the same component over the same component (and, for
@@ -666,10 +679,11 @@ __device__ __forceinline__ void fm_boundaries(const FmFrame &f, int tid, Emit &&
         if (item < nv) {
             const int txi = item / h + 1, y = item - (txi - 1) * h;
             const int x = txi * TW;                        // >= 1; an origin unless it is the frame's last column
-            const uint32_t p = f.VL[(size_t)txi * h + y];   // pixel (x, y)
-            const uint16_t *lf = f.VR + (size_t)(txi - 1) * h;
-            const uint32_t q = lf[y];                       // pixel (x - 1, y): always an origin column (1 <= x - 1 <= w - 2)
             const int tp = (y / TH) * tiles_x + txi;       // tile of (x, y); (x - 1, y) lies in tp - 1
+            const bool any = f.base[tp + 1] != f.base[tp - 1]; // either tile has ring-touching roots
+            const uint16_t *lf = f.VR + (size_t)(txi - 1) * h;
+            const uint32_t p = any ? f.VL[(size_t)txi * h + y] : 0xFFFFu; // pixel (x, y)
+            const uint32_t q = any ? lf[y] : 0xFFFFu;       // pixel (x - 1, y): always an origin column (1 <= x - 1 <= w - 2)
             if (p != 0xFFFFu) ap = f.base[tp] + (p & 0x7FFFu);
             if (q != 0xFFFFu) aq = f.base[tp - 1] + (q & 0x7FFFu);
             if (p != 0xFFFFu && x <= w - 2) {
@@ -832,9 +846,9 @@ __global__ __launch_bounds__(FM_NT) void k_fmerge(ck_border_root *__restrict__ b
     }
     const uint32_t n = base[tiles];
     if (n == 0) return;
-    for (uint32_t k = tid; k < (uint32_t)slots; k += FM_NT) { // pack (coalesced reads of the slices' used prefixes)
-        const uint32_t t = k / RING_CAP, l = k - t * RING_CAP;
-        if (l < base[t + 1] - base[t]) br[base[t] + l] = slice[k];
+    for (int t = tid >> 6; t < tiles; t += FM_NT / 64) { // pack: a wave per tile copies the used prefix of its slice
+        const uint32_t b0 = base[t], cnt = base[t + 1] - b0;
+        for (uint32_t l = (uint32_t)(tid & 63); l < cnt; l += 64) br[b0 + l] = slice[(size_t)t * RING_CAP + l];
     }
     __syncthreads(); // the packed list was written by this workgroup: visible to it after the barrier
     if (stop_after == 0) return; // diagnostics (CK_FMERGE_STOP_AFTER)
@@ -901,12 +915,13 @@ __global__ __launch_bounds__(FM_NT) void k_fmerge(ck_border_root *__restrict__ b
     __syncthreads();
     if (stop_after == 3) return;
     // the tables, slot by slot (a tile's used slots are consecutive, so the writes are too)
-    for (uint32_t k = tid; k < (uint32_t)slots; k += FM_NT) {
-        const uint32_t t = k / RING_CAP, l = k - t * RING_CAP;
-        if (l >= base[t + 1] - base[t]) continue;
-        const uint32_t r = parent[base[t] + l];
-        groot[k] = br[r].root;
-        gsize[k] = size16[r];
+    for (int t = tid >> 6; t < tiles; t += FM_NT / 64) {
+        const uint32_t b0 = base[t], cnt = base[t + 1] - b0;
+        for (uint32_t l = (uint32_t)(tid & 63); l < cnt; l += 64) {
+            const uint32_t r = parent[b0 + l];
+            groot[(size_t)t * RING_CAP + l] = br[r].root;
+            gsize[(size_t)t * RING_CAP + l] = size16[r];
+        }
     }
 }
 
@@ -951,6 +966,7 @@ __global__ __launch_bounds__(NT) void k_decimate(const uint8_t *__restrict__ src
 int ck_launch_threshold_segment(ck_handle *h, const uint8_t *frames, int stride, size_t frame_pitch, int n, bool precomputed) {
     const int tiles = h->tiles_x * h->tiles_y;
     static const int stop_after = getenv("CK_TILE_STOP_AFTER") ? atoi(getenv("CK_TILE_STOP_AFTER")) : 99;
+    static const int sweeps = getenv("CK_TILE_SWEEPS") ? atoi(getenv("CK_TILE_SWEEPS")) : 1;
     // frames dealt to XCDs (a frame's tiles share one L2): worth it once there are frames for all eight (CK_TILE_XCD=0/1 forces it)
     static const int xcd_env = getenv("CK_TILE_XCD") ? atoi(getenv("CK_TILE_XCD")) : -1;
     const int xcd_map = xcd_env >= 0 ? xcd_env : (n >= 16 ? 1 : 0);
@@ -958,11 +974,11 @@ int ck_launch_threshold_segment(ck_handle *h, const uint8_t *frames, int stride,
     if (precomputed)
         hipLaunchKernelGGL(k_tile<true>, dim3(grid), dim3(KNT), 0, h->stream, frames, frame_pitch, stride, h->qw, h->qh,
                            h->tiles_x, h->tiles_y, n, xcd_map, h->cfg.min_white_black_diff, h->cfg.min_component_px, h->d_thresh, h->d_labels,
-                           h->d_broots, h->d_tile_count, h->d_ring, h->ring_len, stop_after);
+                           h->d_broots, h->d_tile_count, h->d_ring, h->ring_len, stop_after, sweeps);
     else
         hipLaunchKernelGGL(k_tile<false>, dim3(grid), dim3(KNT), 0, h->stream, frames, frame_pitch, stride, h->qw, h->qh,
                            h->tiles_x, h->tiles_y, n, xcd_map, h->cfg.min_white_black_diff, h->cfg.min_component_px, h->d_thresh, h->d_labels,
-                           h->d_broots, h->d_tile_count, h->d_ring, h->ring_len, stop_after);
+                           h->d_broots, h->d_tile_count, h->d_ring, h->ring_len, stop_after, sweeps);
     {
         static const int fm_stop = getenv("CK_FMERGE_STOP_AFTER") ? atoi(getenv("CK_FMERGE_STOP_AFTER")) : 99;
         const char *cap_env = getenv("CK_FMERGE_CAP"); // tests force the global-memory path with a small value (read per call)
