@@ -7,7 +7,7 @@ Bytes are summed over the threshold+segment kernels and divided by the number of
 usage: traffic_from_pmc.py <fetch_dir> <write_dir> [out.json]"""
 import csv, glob, json, os, re, sys
 
-KERNELS = ("k_tile", "k_merge", "k_roots", "k_roots_a", "k_roots_b")
+KERNELS = ("k_tile", "k_fmerge")
 
 
 def per_launch(d, counter):
@@ -32,11 +32,19 @@ def main():
     out = sys.argv[3] if len(sys.argv) > 3 else os.path.join(os.path.dirname(__file__), "..", "profiles", "traffic_latest.json")
     f, nf = per_launch(fd, "FETCH_SIZE")
     w, nw = per_launch(wd, "WRITE_SIZE")
+    import subprocess
+    try:
+        commit = subprocess.check_output(["git", "-C", os.path.dirname(os.path.abspath(__file__)), "rev-parse", "--short", "HEAD"], text=True).strip()
+    except Exception:
+        commit = None
     rec = {"hbm_bytes_per_launch": 2.0 * f + w, "fetch_bytes_corrected": 2.0 * f, "write_bytes": w,
            "launches": [nf, nw],
-           "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), FETCH_SIZE doubled per MI355X_MICROARCH.md; "
-                     "kernels k_tile+k_merge+k_roots; bench.py --steps 2 --warmup 1 --no-cpu-baseline",
-           "round": 1}
+           "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes: tools/collect_profiles.sh); kernels k_tile + k_fmerge; "
+                     "bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras",
+           "note": "FETCH_SIZE is doubled for BOTH kernels (MI355X_MICROARCH.md: gfx950 tallies 128-byte requests at 64 bytes). That rule is "
+                   "calibrated for k_tile's reads (16 bytes per lane, streaming); k_fmerge reads 2-byte ring entries and 8-byte list entries, "
+                   "for which the counter is uncalibrated, so its share (a few per cent of the total) may be over-counted by up to 2x.",
+           "round": int(sys.argv[4]) if len(sys.argv) > 4 else 2, "commit": commit}
     json.dump(rec, open(out, "w"), indent=1)
     print(json.dumps(rec))
 
