@@ -39,9 +39,23 @@ def create_solver_camera_transform(fwd, left, up, roll_deg, pitch_deg, yaw_deg):
     return Rc.T, -Rc.T @ T
 
 
-def nearest_so3(r):  # lib.rs:42-59 (r column-major)
+def _random_orthogonal(rng, k):
+    q, rr = np.linalg.qr(rng.normal(size=(k, k)))
+    return q * np.sign(np.diag(rr))
+
+
+def nearest_so3(r, rng_basis=None):  # lib.rs:42-59 (r column-major)
     M = r.reshape(3, 3).T
-    U, _, Vt = np.linalg.svd(M)
+    U, sv, Vt = np.linalg.svd(M)
+    if rng_basis is not None:
+        # a singular value of (numerically) zero leaves its columns of U and V free: any SVD routine may return any
+        # orthonormal completion.  Draw one at random, independently for U and V.
+        null = sv <= 1e-12 * max(sv[0], 1e-300)
+        k = int(null.sum())
+        if k >= 1:
+            U = U.copy(); Vt = Vt.copy()
+            U[:, null] = U[:, null] @ _random_orthogonal(rng_basis, k)
+            Vt[null, :] = _random_orthogonal(rng_basis, k) @ Vt[null, :]
     R = U @ Vt
     if np.linalg.det(R) < 0:
         U[:, 2] *= -1
@@ -90,8 +104,12 @@ def build_linear_system(p3, p2):  # lib.rs:124-180
     return omega, q_tt_inv, q_rt
 
 
-def solve_robot_pose(tags, bearings, robot_to_cam, gyro, sign_change_error=600.0, max_iter=15, tol_sq=1e-16):
-    """tags: list of (R 3x3, t 3); bearings: (4n,3); robot_to_cam: (R,t).  Returns dict or None (lib.rs:297-377)."""
+def solve_robot_pose(tags, bearings, robot_to_cam, gyro, sign_change_error=600.0, max_iter=15, tol_sq=1e-16, rng_basis=None):
+    """tags: list of (R 3x3, t 3); bearings: (4n,3); robot_to_cam: (R,t).  Returns dict or None (lib.rs:297-377).
+    rng_basis: when given, every choice a linear-algebra library is free to make differently is drawn at random — the
+    orthonormal basis of each (numerically) degenerate eigenspace of Omega, the order of equal eigenvalues, the signs of
+    the eigenvectors, and the completion of rank-deficient SVDs in nearest_so3 — to test that the returned pose does not
+    depend on them (the reference uses nalgebra's symmetric_eigen / svd, chalkydri_sqpnp/src/lib.rs:45,398)."""
     Rrc, trc = robot_to_cam
     fwd = Rrc[:, 0]
     world = np.concatenate([(R @ CORNERS.T).T + t for R, t in tags])
@@ -101,10 +119,23 @@ def solve_robot_pose(tags, bearings, robot_to_cam, gyro, sign_change_error=600.0
     centroid = world.mean(0)
     omega, q_tt_inv, q_rt = build_linear_system(world - centroid, bearings)
     w, V = np.linalg.eigh(omega)
+    order = np.argsort(w, kind="stable")
+    if rng_basis is not None:
+        V = V * rng_basis.choice([-1.0, 1.0], size=9)
+        scale = max(abs(w).max(), 1e-300)
+        ws = w[order]
+        start = 0
+        for end in range(1, 10):                      # clusters of eigenvalues closer than 1e-9 of the spectrum's scale
+            if end == 9 or ws[end] - ws[end - 1] > 1e-9 * scale:
+                if end - start > 1:
+                    idx = order[start:end]
+                    V[:, idx] = V[:, idx] @ _random_orthogonal(rng_basis, end - start)
+                    order[start:end] = rng_basis.permutation(idx)
+                start = end
     cands = []
-    for i in np.argsort(w, kind="stable")[:3]:
+    for i in order[:3]:
         for sign in (-1.0, 1.0):
-            r, e = optimization(nearest_so3(V[:, i] * sign), omega, max_iter, tol_sq)
+            r, e = optimization(nearest_so3(V[:, i] * sign, rng_basis), omega, max_iter, tol_sq)
             fx, fy = r[0:3] @ fwd, r[3:6] @ fwd
             e += sign_change_error * max(0.0, 1.0 - (fx * np.cos(gyro) + fy * np.sin(gyro)))
             cands.append((r, e))
