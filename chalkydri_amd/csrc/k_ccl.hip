@@ -60,7 +60,7 @@ constexpr int OFF_MASK = OFF_POOL + POOL_CAP * 4;          // u32[TH][NWD][2] = 
 constexpr int OFF_MISC = OFF_MASK + TH * NWD * 2 * 4;      // u32[16]
 constexpr int LDS_BYTES = OFF_MISC + 64;
 constexpr int RING_CAP = CK_RING_CAP;                      // ring-touching roots of a tile: at most one per ring pixel
-constexpr uint32_t CK_ROOT = 0x8000u, CK_RING = 0x4000u, CK_COUNT = 0x1FFFu;
+constexpr uint32_t CK_ROOT = 0x8000u, CK_RING = 0x4000u, CK_CLAIM = 0x2000u, CK_COUNT = 0x1FFFu;
 static_assert(T4Y * T4X * 2 <= 704, "min/max scratch size");
 static_assert(OFF_THR + (TH / 4) * (TW / 4) * 2 <= OFF_LIST, "threshold scratch must fit in the parent array");
 static_assert(LDS_BYTES <= 20480, "keep eight workgroups per CU");
@@ -330,6 +330,7 @@ __global__ __launch_bounds__(KNT) void k_tile(const uint8_t *__restrict__ frames
 
     if (stop_after == 2) return; // diagnostics (CK_TILE_STOP_AFTER)
     uint32_t nruns = 0;
+    uint32_t ring_root[2] = {0xFFFFFFFFu, 0xFFFFFFFFu}, ring_white[2] = {0, 0}; // P6b: roots under this lane's ring pixels
     if (tile_has_runs) {
     // ---- P4: thread = (row, word, colour).  (a) The word's runs go to the tile's run list, in scan order (the balanced phases
     // P5b and P6 take one lane per run from it).  (b) Adoption: the lane walks its runs with the word's link masks in registers
@@ -482,43 +483,44 @@ __global__ __launch_bounds__(KNT) void k_tile(const uint8_t *__restrict__ frames
             }
     }
     __syncthreads();
-    // ---- P6b: the roots whose component touches the tile ring get their tile-local id (= place in the tile's slice of the
-    // frame's list, which takes the root's pixel and the component's pixel count); the id replaces the count in the root's entry
-    // (the flags stay): that is what the label pass looks up.  No global atomic: the slice has room for one root per ring pixel.
+    // ---- P6b: the components that touch the tile ring get their tile-local id (= place in the tile's slice of the frame's list,
+    // which takes the root's pixel and the component's pixel count).  One lane per RING PIXEL (320 of them, not one per run): it
+    // finds its component's root and claims it (atomic OR of CK_CLAIM on the root's entry); the lane that wins the claim draws
+    // the id and replaces the count in the root's entry by it (the flags stay).  The lane keeps the pixel's ring entry
+    // (id | colour << 15) for the merge stage in a register; ids are complete after the barrier.
     {
         ck_border_root *slice = broots + ((size_t)frame * 2 * tiles + tile) * RING_CAP; // [frame][slices | packed copy]
-        for (uint32_t j0 = 0; j0 < nruns; j0 += KNT) {
-            const uint32_t j = j0 + (uint32_t)tid;
-            const uint32_t p = list[j < nruns ? j : 0u] & 0xFFFu;
-            const uint32_t sw = parent[p];
-            const bool is = j < nruns && (sw & (CK_ROOT | CK_RING)) == (CK_ROOT | CK_RING);
-            const unsigned long long bal = __ballot(is);
-            if (bal) {
-                uint32_t wb = 0;
-                if ((tid & 63) == 0) wb = atomicAdd(&misc[6], (uint32_t)__popcll(bal));
-                wb = (uint32_t)__builtin_amdgcn_readfirstlane((int)wb);
-                if (is) {
-                    const uint32_t id = wb + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
-                    ck_border_root br;
-                    br.root = (uint32_t)(ty0 + (int)(p >> 7)) * (uint32_t)w + (uint32_t)(tx0 + (int)(p & (TW - 1)));
-                    br.size = sw & CK_COUNT;
-                    slice[id] = br; // id < RING_CAP: a ring-touching root owns at least one ring pixel
-                    parent[p] = (uint16_t)(CK_ROOT | CK_RING | id);
-                }
-            }
+#pragma unroll
+        for (int rnd = 0; rnd < 2; rnd++) {
+            const int item = rnd * KNT + tid;
+            if (item >= 2 * TW + 2 * TH) continue;
+            int rr, xx;
+            if (item < TW) { rr = 0; xx = item; }
+            else if (item < 2 * TW) { rr = TH - 1; xx = item - TW; }
+            else if (item < 2 * TW + TH) { rr = item - 2 * TW; xx = 0; }
+            else { rr = item - 2 * TW - TH; xx = TW - 1; }
+            if (ty0 + rr >= h || tx0 + xx >= w) continue;
+            const int wd = xx >> 5, i = xx & 31;
+            const uint32_t Wm = mk[(rr * NWD + wd) * 2], Bm = mk[(rr * NWD + wd) * 2 + 1];
+            const uint32_t white = (Wm >> i) & 1u;
+            if (!(((Wm | Bm) >> i) & 1u)) continue;
+            const uint32_t M = white ? Wm : Bm;
+            const uint32_t node = (uint32_t)(rr * TW + 32 * wd + ck_run_start32(ck_starts32(M, ck_origin32(tx0 + 32 * wd, w)), i));
+            const uint32_t e = parent[node];
+            const uint32_t root = (e & CK_ROOT) ? node : e; // flat since P6
+            ring_root[rnd] = root; ring_white[rnd] = white;
+            const uint32_t sh = (root & 1u) * 16u;
+            const uint32_t re = (parent32[root >> 1] >> sh) & 0xFFFFu;
+            if (!(re & CK_RING) || (re & CK_CLAIM)) continue;   // not ring-touching on a side that has a neighbour tile, or claimed already
+            const uint32_t old = atomicOr(&parent32[root >> 1], CK_CLAIM << sh);
+            if ((old >> sh) & CK_CLAIM) continue;               // another lane won
+            const uint32_t id = atomicAdd(&misc[6], 1u);        // id < RING_CAP: a ring-touching root owns at least one ring pixel
+            ck_border_root br;
+            br.root = (uint32_t)(ty0 + (int)(root >> 7)) * (uint32_t)w + (uint32_t)(tx0 + (int)(root & (TW - 1)));
+            br.size = (old >> sh) & CK_COUNT;
+            slice[id] = br;
+            parent[root] = (uint16_t)(CK_ROOT | CK_RING | CK_CLAIM | id);
         }
-    }
-    __syncthreads();
-    // ---- P6c: every non-root run's entry becomes the 16-bit code of its component, which the label pass expands per pixel with
-    // ONE lookup: ring-touching: CK_RING | id; interior: root node | 0x2000 when smaller than min_component_px.  (A run reads
-    // its own entry — flat since P6 — and its root's entry, and rewrites only its own, which no other run reads any more; the
-    // roots keep their entries: CK_ROOT | CK_RING | id, or CK_ROOT | count.)
-    for (uint32_t j = (uint32_t)tid; j < nruns; j += KNT) {
-        const uint32_t p = list[j] & 0xFFFu;
-        const uint32_t root = parent[p];
-        if (root & CK_ROOT) continue;
-        const uint32_t sw = parent[root];
-        parent[p] = (uint16_t)((sw & CK_RING) ? (CK_RING | (sw & 0x1FFu)) : (root | ((int)(sw & CK_COUNT) < min_comp ? 0x2000u : 0u)));
     }
     __syncthreads();
     } // tile_has_runs
@@ -527,75 +529,84 @@ __global__ __launch_bounds__(KNT) void k_tile(const uint8_t *__restrict__ frames
 
     if (stop_after == 7) return; // diagnostics (CK_TILE_STOP_AFTER)
     uint16_t *ring_f = ring + (size_t)frame * ring_len;
+    // the ring entries of the pixels this lane looked at in P6b (rows: HT / HB, columns: VL / VR; layout in ck_internal.h)
+#pragma unroll
+    for (int rnd = 0; rnd < 2; rnd++) {
+        const int item = rnd * KNT + tid;
+        if (item >= 2 * TW + 2 * TH) continue;
+        int rr, xx;
+        size_t dst;
+        if (item < TW) { rr = 0; xx = item; dst = (size_t)ty * w + (size_t)(tx0 + xx); }
+        else if (item < 2 * TW) { rr = TH - 1; xx = item - TW; dst = (size_t)tiles_y * w + (size_t)ty * w + (size_t)(tx0 + xx); }
+        else if (item < 2 * TW + TH) { rr = item - 2 * TW; xx = 0; dst = 2 * (size_t)tiles_y * w + (size_t)tx * h + (size_t)(ty0 + rr); }
+        else { rr = item - 2 * TW - TH; xx = TW - 1; dst = 2 * (size_t)tiles_y * w + (size_t)tiles_x * h + (size_t)tx * h + (size_t)(ty0 + rr); }
+        if (ty0 + rr >= h || tx0 + xx >= w) continue;
+        uint32_t val = 0xFFFFu;
+        if (tile_has_runs && ring_root[rnd] != 0xFFFFFFFFu) val = ((uint32_t)parent[ring_root[rnd]] & 0x1FFu) | (ring_white[rnd] << 15);
+        ring_f[dst] = (uint16_t)val;
+    }
     // ---- P7: write label words.  Four passes; in pass q lane L owns the 4-pixel group q*256 + L of the tile's 1024, so that a
-    // wave's store instruction covers 1 KiB of contiguous label words and its LDS lookups spread over the banks
+    // wave's store instruction covers 1 KiB of contiguous label words and its LDS lookups spread over the banks.  A pixel's run
+    // entry is either its component's root entry (CK_ROOT | flags | count or id) or the root's node: at most two lookups.
+    {
+        const int g = tid & 31, wd = g >> 3, sh = 4 * (g & 7);       // the same for the lane's four passes
+        const int gx = tx0 + 4 * g;
+        const uint32_t Oo = ck_origin32(tx0 + 32 * wd, w);
+        const uint32_t below = (1u << sh) - 1u;
+        const uint32_t gbase = (uint32_t)ty0 * (uint32_t)w + (uint32_t)tx0;
+        const uint32_t slot0 = CK_LBL_BORDER | ((uint32_t)tile * RING_CAP);
+        if (gx < w)
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
-        const int gi = q * KNT + tid, rr = gi >> 5, g = gi & 31, wd = g >> 3, sh = 4 * (g & 7);
-        const int gy = ty0 + rr, gx = tx0 + 4 * g;
-        if (gy >= h || gx >= w) continue;
-        const uint32_t wbase = (uint32_t)(rr * TW + 32 * wd), cbase = wbase + (uint32_t)sh;
-        const uint2 wb = *reinterpret_cast<const uint2 *>(&mk[(rr * NWD + wd) * 2]);
-        const uint32_t Wm = wb.x, Bm = wb.y;
-        const uint32_t w4 = (Wm >> sh) & 15u, b4 = (Bm >> sh) & 15u, any4 = w4 | b4;
-        uint32_t outw[4] = {CK_LBL_INVALID, CK_LBL_INVALID, CK_LBL_INVALID, CK_LBL_INVALID};
-        uint32_t ringv[4] = {0, 0, 0, 0};
-        if (any4) {
-            const uint32_t Oo = ck_origin32(tx0 + 32 * wd, w);
-            const uint32_t SW = ck_starts32(Wm, Oo), SB = ck_starts32(Bm, Oo);
-            const uint32_t st4 = ((SW | SB) >> sh) & 15u;
-            // the run that is already open when the group begins: nearest start below it in the word, per colour
-            const uint32_t below = (1u << sh) - 1u;
-            const uint32_t carryW = wbase + (uint32_t)ck_last_start32(SW & below), carryB = wbase + (uint32_t)ck_last_start32(SB & below);
-            // a pixel's run starts at the nearest start bit of EITHER colour at or below it (a start of the other colour cannot lie
-            // inside a run), or before the group (then the run has the colour of pixel 0 and the carried node of that colour).
-            // An uncoloured pixel looks up a harmless in-range node.
-            uint32_t cur = (w4 & 1u) ? carryW : carryB;
-            uint32_t codev[4];
+        for (int q = 0; q < 4; q++) {
+            const int rr = q * (KNT / 32) + (tid >> 5);
+            const int gy = ty0 + rr;
+            if (gy >= h) continue;
+            const uint32_t wbase = (uint32_t)(rr * TW + 32 * wd), cbase = wbase + (uint32_t)sh;
+            uint32_t outw[4] = {CK_LBL_INVALID, CK_LBL_INVALID, CK_LBL_INVALID, CK_LBL_INVALID};
+            uint32_t any4 = 0;
+            if (tile_has_runs) {
+                const uint2 wb = *reinterpret_cast<const uint2 *>(&mk[(rr * NWD + wd) * 2]);
+                const uint32_t Wm = wb.x, Bm = wb.y;
+                const uint32_t w4 = (Wm >> sh) & 15u, b4 = (Bm >> sh) & 15u;
+                any4 = w4 | b4;
+                if (any4) {
+                    const uint32_t SW = ck_starts32(Wm, Oo), SB = ck_starts32(Bm, Oo);
+                    const uint32_t st4 = ((SW | SB) >> sh) & 15u;
+                    // the run that is already open when the group begins: nearest start below it in the word, per colour
+                    const uint32_t carryW = wbase + (uint32_t)ck_last_start32(SW & below), carryB = wbase + (uint32_t)ck_last_start32(SB & below);
+                    // a pixel's run starts at the nearest start bit of EITHER colour at or below it (a start of the other colour cannot
+                    // lie inside a run), or before the group (then the run has the colour of pixel 0 and the carried node of that
+                    // colour).  An uncoloured pixel looks up a harmless in-range node; its word is not used.
+                    uint32_t cur = (w4 & 1u) ? carryW : carryB;
+                    uint32_t nodev[4], ev[4], rv[4];
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                cur = ((st4 >> k) & 1u) ? cbase + (uint32_t)k : cur;
-                codev[k] = cur;
+                    for (int k = 0; k < 4; k++) {
+                        cur = ((st4 >> k) & 1u) ? cbase + (uint32_t)k : cur;
+                        nodev[k] = cur;
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; k++) ev[k] = parent[nodev[k]];
+#pragma unroll
+                    for (int k = 0; k < 4; k++) rv[k] = parent[ev[k] & (uint32_t)(TH * TW - 1)]; // the root's entry when ev[k] is a node (harmless otherwise)
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const bool is_root = (ev[k] & CK_ROOT) != 0;
+                        const uint32_t node = is_root ? nodev[k] : ev[k];      // the component's root node
+                        const uint32_t c = is_root ? ev[k] : rv[k];           // its entry
+                        // interior component: the root's pixel index, final; ring-touching: the component's slot in the frame's tables
+                        const uint32_t word = (c & CK_RING) ? slot0 + (c & 0x1FFu)
+                                                            : ((gbase + (node >> 7) * (uint32_t)w + (node & (TW - 1))) | ((int)(c & CK_COUNT) < min_comp ? CK_LBL_SMALL : 0u));
+                        outw[k] = ((any4 >> k) & 1u) ? word : CK_LBL_INVALID;
+                    }
+                }
             }
-            uint32_t nodev[4];
+            uint32_t *dst = labels + fbase + (size_t)gy * w + gx;
+            if (packed_rows) *reinterpret_cast<uint4 *>(dst) = make_uint4(outw[0], outw[1], outw[2], outw[3]);
+            else {
 #pragma unroll
-            for (int k = 0; k < 4; k++) { nodev[k] = codev[k]; codev[k] = parent[codev[k]]; } // the component's code (P6c); undefined for an uncoloured pixel, whose word is not used
-            const uint32_t gbase = (uint32_t)ty0 * (uint32_t)w + (uint32_t)tx0;
-            const uint32_t slot0 = CK_LBL_BORDER | ((uint32_t)tile * RING_CAP);
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const uint32_t c = codev[k];
-                const bool is_root = (c & CK_ROOT) != 0;
-                const uint32_t node = is_root ? nodev[k] : (c & 0xFFFu);                                   // the component's root node
-                const bool small = is_root ? (int)(c & CK_COUNT) < min_comp : (c & 0x2000u) != 0;
-                // interior component: the root's pixel index, final; ring-touching: the component's slot in the frame's tables
-                const uint32_t word = (c & CK_RING) ? slot0 + (c & 0x1FFu) : ((gbase + (node >> 7) * (uint32_t)w + (node & (TW - 1))) | (small ? CK_LBL_SMALL : 0u));
-                outw[k] = ((any4 >> k) & 1u) ? word : CK_LBL_INVALID;
-                ringv[k] = c & 0x1FFu;
+                for (int k = 0; k < 4; k++)
+                    if (gx + k < w) dst[k] = outw[k];
             }
-        }
-        // the lanes on the tile's edges also leave the ids (and colours) of their pixels' components for the merge stage
-        // (a component that owns a ring pixel is ring-touching wherever a neighbouring tile exists: its size entry holds the id)
-        if (rr == 0 || rr == TH - 1 || g == 0 || g == 31) {
-            uint32_t rv[4];
-#pragma unroll
-            for (int k = 0; k < 4; k++) rv[k] = ((any4 >> k) & 1u) ? (ringv[k] | (((w4 >> k) & 1u) << 15)) : 0xFFFFu;
-            if (rr == 0 || rr == TH - 1) {
-                uint16_t *dr = ring_f + (rr == 0 ? (size_t)0 : (size_t)tiles_y * w) + (size_t)ty * w + (size_t)gx;
-                if (gx + 4 <= w && (w & 3) == 0) *reinterpret_cast<uint2 *>(dr) = make_uint2(rv[0] | (rv[1] << 16), rv[2] | (rv[3] << 16));
-                else
-                    for (int k = 0; k < 4; k++)
-                        if (gx + k < w) dr[k] = (uint16_t)rv[k];
-            }
-            if (g == 0) ring_f[2 * (size_t)tiles_y * w + (size_t)tx * h + (size_t)gy] = (uint16_t)rv[0];
-            if (g == 31) ring_f[2 * (size_t)tiles_y * w + (size_t)tiles_x * h + (size_t)tx * h + (size_t)gy] = (uint16_t)rv[3];
-        }
-        uint32_t *dst = labels + fbase + (size_t)gy * w + gx;
-        if (packed_rows) *reinterpret_cast<uint4 *>(dst) = make_uint4(outw[0], outw[1], outw[2], outw[3]);
-        else {
-#pragma unroll
-            for (int k = 0; k < 4; k++)
-                if (gx + k < w) dst[k] = outw[k];
         }
     }
     TPROF(8);
