@@ -110,6 +110,9 @@ __device__ __forceinline__ void lds_union(uint16_t *p, uint32_t a, uint32_t b) {
         a = old;                   // somebody hooked it first: go on from its parent
     }
 }
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ u16x2 as_u16x2(uint32_t v) { return __builtin_bit_cast(u16x2, v); }
+__device__ __forceinline__ uint32_t as_u32(u16x2 v) { return __builtin_bit_cast(uint32_t, v); }
 // gathers bit 7 of each byte of v into a nibble (bit k = byte k)
 __device__ __forceinline__ uint32_t msb_nibble(uint32_t v) {
     return (((v >> 7) & 0x01010101u) * 0x01020408u) >> 24 & 0xFu;
@@ -287,25 +290,29 @@ __global__ __launch_bounds__(KNT) void k_tile(const uint8_t *__restrict__ frames
         for (int k = 0; k < 4; k++) {
             const int x = gx + 4 * k;
             uint32_t tw_ = PRE ? 0u : thr[r4 * (TW / 4) + min(x >> 2, w4 - 1) - c4x];
-            uint32_t o;
-            if (gy >= h || x >= w) o = 0x7F7F7F7Fu;      // outside the frame: no colour
+            uint32_t o, wn, bn; // the four output bytes and the white / black bits of the group
+            if (gy >= h || x >= w) { o = 0x7F7F7F7Fu; wn = 0; bn = 0; }     // outside the frame: no colour
             else {
                 if (PRE) o = in[k];
-                else if (tw_ & 0x100u) o = 0x7F7F7F7Fu;
                 else {
-                    o = 0;
-#pragma unroll
-                    for (int b = 0; b < 4; b++)
-                        if (((in[k] >> (8 * b)) & 255u) > tw_) o |= 0xFFu << (8 * b);
+                    // four byte compares "pixel > threshold" as two packed 16-bit saturating subtractions (even and odd bytes)
+                    const uint32_t t2 = (tw_ & 0xFFu) * 0x00010001u;
+                    const u16x2 de = __builtin_elementwise_sub_sat(as_u16x2(in[k] & 0x00FF00FFu), as_u16x2(t2));
+                    const u16x2 dq = __builtin_elementwise_sub_sat(as_u16x2((in[k] >> 8) & 0x00FF00FFu), as_u16x2(t2));
+                    const u16x2 one = {1, 1};
+                    const uint32_t me = as_u32(__builtin_elementwise_min(de, one)), mo = as_u32(__builtin_elementwise_min(dq, one)); // 0 / 1 per pixel
+                    o = (tw_ & 0x100u) ? 0x7F7F7F7Fu : ((me * 0xFFu) | ((mo * 0xFFu) << 8));
                 }
                 if (x + 4 > w) { // the frame ends inside this group (width not a multiple of 4)
                     const uint32_t keep = 0xFFFFFFFFu >> (8 * (x + 4 - w));
                     o = (o & keep) | (0x7F7F7F7Fu & ~keep);
                 }
+                wn = msb_nibble(o);                     // 255 -> bit 7 set
+                bn = msb_nibble(~(o << 7));             // 0 -> bit 0 clear (127 and 255 have it set)
             }
             out[k] = o;
-            wbits |= msb_nibble(o) << (4 * k);                     // 255 -> bit 7 set
-            bbits |= msb_nibble(~(o << 7)) << (4 * k);             // 0 -> bit 0 clear (127 and 255 have it set)
+            wbits |= wn << (4 * k);
+            bbits |= bn << (4 * k);
         }
         if (gy < h && gx < w) {
             uint8_t *dst = thresh + fbase + (size_t)gy * w + gx;
@@ -332,22 +339,28 @@ __global__ __launch_bounds__(KNT) void k_tile(const uint8_t *__restrict__ frames
     uint32_t nruns = 0;
     uint32_t ring_root[2] = {0xFFFFFFFFu, 0xFFFFFFFFu}, ring_white[2] = {0, 0}; // P6b: roots under this lane's ring pixels
     if (tile_has_runs) {
-    // ---- P4: thread = (row, word, colour).  (a) The word's runs go to the tile's run list, in scan order (the balanced phases
+    // ---- P4: thread = (colour, row, word): waves 0-1 hold the white words, waves 2-3 the black ones, so that the black waves skip
+    // the diagonal links altogether (a scalar branch).  (a) The word's runs go to the tile's run list, in scan order (the balanced phases
     // P5b and P6 take one lane per run from it).  (b) Adoption: the lane walks its runs with the word's link masks in registers
     // (ck_links_of_word) and gives every run ONE earlier run as parent with a plain store — only the owner writes the entry and
     // nothing reads parent[] in this phase, so no find and no atomic is needed; the target has a smaller index, which keeps the
     // forest invariant parent <= self.  (c) The links that are left over go to the pool for the atomic unions of P5c.
     uint32_t *pool = reinterpret_cast<uint32_t *>(lds + OFF_POOL);
     {
-        const int r = tid >> 3, wd = (tid >> 1) & 3, c = tid & 1;
+        const int c = __builtin_amdgcn_readfirstlane(tid >> 7); // wave-uniform
+        const int r = (tid >> 2) & (TH - 1), wd = tid & 3;
+        const int mi = (r * NWD + wd) * 2 + c;                   // this word in the mask array
         const bool has_l = wd > 0, has_u = r > 0, has_r = wd < NWD - 1, white = c == 0;
         const int x0 = tx0 + 32 * wd;
         const uint32_t O = ck_origin32(x0, w), Op = ck_origin32(x0 - 32, w);
-        const uint32_t M = mk[tid]; // mk index (r*NWD + wd)*2 + c == tid
-        uint32_t Mp = mk[has_l ? tid - 2 : tid], U = mk[has_u ? tid - 2 * NWD : tid];
-        uint32_t Up = mk[(has_u && has_l) ? tid - 2 * NWD - 2 : tid], Un = mk[(has_u && has_r) ? tid - 2 * NWD + 2 : tid];
+        const uint32_t M = mk[mi];
+        uint32_t Mp = mk[has_l ? mi - 2 : mi], U = mk[has_u ? mi - 2 * NWD : mi];
+        uint32_t Up = 0, Un = 0;
+        if (white) { // (scalar branch)
+            Up = mk[(has_u && has_l) ? mi - 2 * NWD - 2 : mi]; Un = mk[(has_u && has_r) ? mi - 2 * NWD + 2 : mi];
+            Up = (has_u && has_l) ? Up : 0u; Un = (has_u && has_r) ? Un : 0u;
+        }
         Mp = has_l ? Mp : 0u; U = has_u ? U : 0u;
-        Up = (has_u && has_l && white) ? Up : 0u; Un = (has_u && has_r && white) ? Un : 0u;
         const bool on0 = (x0 + 32 >= 1) && (x0 + 32 <= w - 2);
         const uint32_t S = ck_starts32(M, O), Su = ck_starts32(U, O);
         ck_word_links K = ck_links_of_word(white, M, U, O, (Mp >> 31) != 0, (Up >> 31) != 0, (Un & 1u) != 0, on0);
@@ -361,26 +374,42 @@ __global__ __launch_bounds__(KNT) void k_tile(const uint8_t *__restrict__ frames
         if (tid == 0) misc[5] = 0;
         // (b) adoption, meanwhile
         uint32_t Ev = K.Ev, DL = K.DL, DR = K.DR, hl = K.hleft ? 1u : 0u;
-        for (uint32_t St = S; St;) {
-            const uint32_t low = St & (0u - St);
-            const int i = __builtin_ctz(low);
-            St ^= low;
-            const uint32_t span = ((St & (0u - St)) - 1u) & ~(low - 1u); // the run's pixels-to-be: bit i up to the next start
-            const uint32_t e = (Ev | DL | DR) & span;
-            const int x = __builtin_ctz(e | 0x80000000u);
-            const uint32_t bit = 1u << x;
-            const bool is_ev = (Ev & bit) != 0, is_dl = (DL & bit) != 0;
-            const uint32_t t_ev = upbase + (uint32_t)ck_run_start32(Su, x);
-            const uint32_t t_dl = x > 0 ? upbase + (uint32_t)ck_run_start32(Su, x - 1) : up_l;
-            const uint32_t t_dr = upbase + (uint32_t)x + 1u;
-            const bool use_left = !e && i == 0 && hl;
-            const uint32_t tgt = e ? (is_ev ? t_ev : (is_dl ? t_dl : t_dr)) : (use_left ? left : CK_ROOT); // no earlier run: a root (count 0 for now)
-            const uint32_t clr = e ? ~bit : 0xFFFFFFFFu;
-            Ev &= is_ev ? clr : 0xFFFFFFFFu;
-            DL &= (!is_ev && is_dl) ? clr : 0xFFFFFFFFu;
-            DR &= (!is_ev && !is_dl) ? clr : 0xFFFFFFFFu;
-            hl = use_left ? 0u : hl;
-            parent[wbase + (uint32_t)i] = (uint16_t)tgt;
+        if (white) {
+            for (uint32_t St = S; St;) {
+                const uint32_t low = St & (0u - St);
+                const int i = __builtin_ctz(low);
+                St ^= low;
+                const uint32_t span = ((St & (0u - St)) - 1u) & ~(low - 1u); // the run's pixels-to-be: bit i up to the next start
+                const uint32_t e = (Ev | DL | DR) & span;
+                const int x = __builtin_ctz(e | 0x80000000u);
+                const uint32_t bit = 1u << x;
+                const bool is_ev = (Ev & bit) != 0, is_dl = (DL & bit) != 0;
+                const uint32_t t_ev = upbase + (uint32_t)ck_run_start32(Su, x);
+                const uint32_t t_dl = x > 0 ? upbase + (uint32_t)ck_run_start32(Su, x - 1) : up_l;
+                const uint32_t t_dr = upbase + (uint32_t)x + 1u;
+                const bool use_left = !e && i == 0 && hl;
+                const uint32_t tgt = e ? (is_ev ? t_ev : (is_dl ? t_dl : t_dr)) : (use_left ? left : CK_ROOT); // no earlier run: a root (count 0 for now)
+                const uint32_t clr = e ? ~bit : 0xFFFFFFFFu;
+                Ev &= is_ev ? clr : 0xFFFFFFFFu;
+                DL &= (!is_ev && is_dl) ? clr : 0xFFFFFFFFu;
+                DR &= (!is_ev && !is_dl) ? clr : 0xFFFFFFFFu;
+                hl = use_left ? 0u : hl;
+                parent[wbase + (uint32_t)i] = (uint16_t)tgt;
+            }
+        } else { // black: vertical links only
+            for (uint32_t St = S; St;) {
+                const uint32_t low = St & (0u - St);
+                const int i = __builtin_ctz(low);
+                St ^= low;
+                const uint32_t span = ((St & (0u - St)) - 1u) & ~(low - 1u);
+                const uint32_t e = Ev & span;
+                const int x = __builtin_ctz(e | 0x80000000u);
+                const bool use_left = !e && i == 0 && hl;
+                const uint32_t tgt = e ? upbase + (uint32_t)ck_run_start32(Su, x) : (use_left ? left : CK_ROOT);
+                Ev &= e ? ~(1u << x) : 0xFFFFFFFFu;
+                hl = use_left ? 0u : hl;
+                parent[wbase + (uint32_t)i] = (uint16_t)tgt;
+            }
         }
         __syncthreads();
         uint32_t off = incl - cnt;
@@ -456,13 +485,11 @@ __global__ __launch_bounds__(KNT) void k_tile(const uint8_t *__restrict__ frames
             live[q] = j < nruns;
             const uint32_t e = list[live[q] ? j : 0u];
             const uint32_t p = e & 0xFFFu, c = e >> 12;
-            const int r = (int)(p >> 7), wd = (int)(p >> 5) & 3, i = (int)(p & 31u);
+            const int wd = (int)(p >> 5) & 3, i = (int)(p & 31u);
             const uint32_t M = mk[(int)((p >> 5) << 1) + (int)c];
             const uint32_t R = ck_run_bits32(M, ck_starts32(M, ck_origin32(tx0 + 32 * wd, w)), i);
-            const bool ring = ((r == 0) & (ty0 > 0)) | ((r == TH - 1) & (ty0 + TH < h)) | ((wd == 0) & (tx0 > 0) & ((R & 1u) != 0)) |
-                              ((wd == NWD - 1) & (tx0 + TW < w) & ((R >> 31) != 0));
             node[q] = p; root[q] = p;
-            add[q] = (uint32_t)__popc(R) | (ring ? CK_RING : 0u);
+            add[q] = (uint32_t)__popc(R);
         }
         for (int it = 0; it < TH * TW; it++) { // plain loads behind a compiler barrier: the two reads of a step go out together
             __asm__ volatile("" ::: "memory");
@@ -476,10 +503,8 @@ __global__ __launch_bounds__(KNT) void k_tile(const uint8_t *__restrict__ frames
             if (live[q]) {
                 if (root[q] != node[q]) parent[node[q]] = (uint16_t)root[q];
                 // the root's own entry takes the count (bits 0..12: a tile has 4096 pixels, so no carry reaches the flags or the
-                // other half of the word); the ring bit must be OR-ed, not added (several ring runs of one component)
-                const uint32_t sh = (root[q] & 1u) * 16u;
-                atomicAdd(&parent32[root[q] >> 1], (add[q] & CK_COUNT) << sh);
-                if (add[q] & CK_RING) atomicOr(&parent32[root[q] >> 1], CK_RING << sh);
+                // other half of the word)
+                atomicAdd(&parent32[root[q] >> 1], add[q] << ((root[q] & 1u) * 16u));
             }
     }
     __syncthreads();
@@ -500,10 +525,12 @@ __global__ __launch_bounds__(KNT) void k_tile(const uint8_t *__restrict__ frames
             else if (item < 2 * TW + TH) { rr = item - 2 * TW; xx = 0; }
             else { rr = item - 2 * TW - TH; xx = TW - 1; }
             if (ty0 + rr >= h || tx0 + xx >= w) continue;
+            // a pixel on a side behind which another tile lies makes its component ring-touching (that is the definition)
+            const bool side = item < TW ? ty0 > 0 : (item < 2 * TW ? ty0 + TH < h : (item < 2 * TW + TH ? tx0 > 0 : tx0 + TW < w));
             const int wd = xx >> 5, i = xx & 31;
             const uint32_t Wm = mk[(rr * NWD + wd) * 2], Bm = mk[(rr * NWD + wd) * 2 + 1];
             const uint32_t white = (Wm >> i) & 1u;
-            if (!(((Wm | Bm) >> i) & 1u)) continue;
+            if (!side || !(((Wm | Bm) >> i) & 1u)) continue;
             const uint32_t M = white ? Wm : Bm;
             const uint32_t node = (uint32_t)(rr * TW + 32 * wd + ck_run_start32(ck_starts32(M, ck_origin32(tx0 + 32 * wd, w)), i));
             const uint32_t e = parent[node];
@@ -511,8 +538,8 @@ __global__ __launch_bounds__(KNT) void k_tile(const uint8_t *__restrict__ frames
             ring_root[rnd] = root; ring_white[rnd] = white;
             const uint32_t sh = (root & 1u) * 16u;
             const uint32_t re = (parent32[root >> 1] >> sh) & 0xFFFFu;
-            if (!(re & CK_RING) || (re & CK_CLAIM)) continue;   // not ring-touching on a side that has a neighbour tile, or claimed already
-            const uint32_t old = atomicOr(&parent32[root >> 1], CK_CLAIM << sh);
+            if (re & CK_CLAIM) continue;                        // claimed already
+            const uint32_t old = atomicOr(&parent32[root >> 1], (CK_CLAIM | CK_RING) << sh);
             if ((old >> sh) & CK_CLAIM) continue;               // another lane won
             const uint32_t id = atomicAdd(&misc[6], 1u);        // id < RING_CAP: a ring-touching root owns at least one ring pixel
             ck_border_root br;
