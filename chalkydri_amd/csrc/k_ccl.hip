@@ -90,7 +90,8 @@ __device__ __forceinline__ void lds_find2(uint16_t *p, uint32_t &a, uint32_t &b)
 __device__ __forceinline__ uint32_t lds_min16(uint16_t *p, uint32_t idx, uint32_t val) {
     uint32_t *wp = reinterpret_cast<uint32_t *>(p) + (idx >> 1);
     const uint32_t sh = (idx & 1u) * 16u;
-    uint32_t wv = *reinterpret_cast<volatile uint32_t *>(wp);
+    __asm__ volatile("" ::: "memory"); // (a fresh read, but a plain one: a volatile access through the cast pointer becomes a flat load, which waits for every outstanding global store)
+    uint32_t wv = *wp;
     for (;;) {
         const uint32_t cur = (wv >> sh) & 0xFFFFu;
         if (cur <= val) return cur;
@@ -754,7 +755,8 @@ __device__ __forceinline__ uint32_t fm_find(uint16_t *p, uint32_t a) { // path h
 __device__ __forceinline__ bool fm_cas16(uint16_t *p, uint32_t idx, uint32_t expect, uint32_t val) {
     uint32_t *wp = reinterpret_cast<uint32_t *>(p) + (idx >> 1);
     const uint32_t sh = (idx & 1u) * 16u;
-    uint32_t wv = *reinterpret_cast<volatile uint32_t *>(wp);
+    __asm__ volatile("" ::: "memory"); // (a fresh read, but a plain one: a volatile access through the cast pointer becomes a flat load, which waits for every outstanding global store)
+    uint32_t wv = *wp;
     for (;;) {
         if (((wv >> sh) & 0xFFFFu) != expect) return false;
         const uint32_t prev = atomicCAS(wp, wv, (wv & ~(0xFFFFu << sh)) | (val << sh));
@@ -783,7 +785,8 @@ __device__ __forceinline__ void fm_union(uint16_t *p, const uint16_t *key, const
 __device__ __forceinline__ void fm_size_add(uint16_t *sz, uint32_t idx, uint32_t add, uint32_t enough) {
     uint32_t *wp = reinterpret_cast<uint32_t *>(sz) + (idx >> 1);
     const uint32_t sh = (idx & 1u) * 16u;
-    uint32_t wv = *reinterpret_cast<volatile uint32_t *>(wp);
+    __asm__ volatile("" ::: "memory"); // (a fresh read, but a plain one: a volatile access through the cast pointer becomes a flat load, which waits for every outstanding global store)
+    uint32_t wv = *wp;
     for (;;) {
         const uint32_t cur = (wv >> sh) & 0xFFFFu;
         if (cur >= enough) return;                       // already "large": nothing a further part could change
