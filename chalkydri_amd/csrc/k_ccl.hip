@@ -206,8 +206,8 @@ __global__ __launch_bounds__(KNT) void k_tile(const uint8_t *__restrict__ frames
     uint32_t *parent32 = reinterpret_cast<uint32_t *>(lds + OFF_PARENT);
     uint16_t *list = reinterpret_cast<uint16_t *>(lds + OFF_LIST);
     uint32_t *mk = reinterpret_cast<uint32_t *>(lds + OFF_MASK);
-    uint32_t *misc = reinterpret_cast<uint32_t *>(lds + OFF_MISC); // [0..3] wave run counts, [5] pooled links, [6] ring-touching roots
-    if (tid == 0) misc[6] = 0; // (the barrier after P0 publishes it)
+    uint32_t *misc = reinterpret_cast<uint32_t *>(lds + OFF_MISC); // [0..3] wave run counts, [5] pooled links, [6] / [7] white / black ring-touching roots
+    if (tid == 0) { misc[6] = 0; misc[7] = 0; } // (the barrier after P0 publishes them)
 
     // Whole 4x4 tiles only enter the min/max (the oracle's rule); pixels right of / below the last whole one take its
     // threshold.  Normally the threshold grid of a workgroup tile starts at its own first 4x4 column / row (c4x, c4y); when the
@@ -542,7 +542,9 @@ __global__ __launch_bounds__(KNT) void k_tile(const uint8_t *__restrict__ frames
             if (re & CK_CLAIM) continue;                        // claimed already
             const uint32_t old = atomicOr(&parent32[root >> 1], (CK_CLAIM | CK_RING) << sh);
             if ((old >> sh) & CK_CLAIM) continue;               // another lane won
-            const uint32_t id = atomicAdd(&misc[6], 1u);        // id < RING_CAP: a ring-touching root owns at least one ring pixel
+            // white roots take the ids 0, 1, ... and black ones RING_CAP - 1, RING_CAP - 2, ... (the merge stage joins the two
+            // colours in separate workgroups); they cannot meet: a ring-touching root owns at least one of the RING_CAP ring pixels
+            const uint32_t id = white ? atomicAdd(&misc[6], 1u) : (uint32_t)(RING_CAP - 1) - atomicAdd(&misc[7], 1u);
             ck_border_root br;
             br.root = (uint32_t)(ty0 + (int)(root >> 7)) * (uint32_t)w + (uint32_t)(tx0 + (int)(root & (TW - 1)));
             br.size = (old >> sh) & CK_COUNT;
@@ -552,7 +554,7 @@ __global__ __launch_bounds__(KNT) void k_tile(const uint8_t *__restrict__ frames
     }
     __syncthreads();
     } // tile_has_runs
-    if (tid == 0) tile_count[(size_t)frame * tiles + tile] = misc[6];
+    if (tid == 0) tile_count[(size_t)frame * tiles + tile] = misc[6] | (misc[7] << 16); // white | black << 16
     TPROF(7);
 
     if (stop_after == 7) return; // diagnostics (CK_TILE_STOP_AFTER)
@@ -666,78 +668,137 @@ namespace {
 // pixel, so a union hooks the root with the larger PIXEL under the other one (compare-and-swap on the root's own entry).
 constexpr int FM_NT = 1024;
 constexpr int FM_CAP = 28672;                 // roots per frame the LDS path holds
-constexpr int FM_LDS = 2 * FM_CAP * 2;        // parent u16[FM_CAP] + size / key u16[FM_CAP]
 constexpr int FM_WQ = 384;                    // joins a wave's queue holds (one round of boundary pixels adds at most 192)
-constexpr int FM_MAX_TILES = 4096;            // 4095 x 4095 pixels at most (ck_create)
 constexpr uint32_t NOJ = 0xFFFFFFFFu;         // "no join"
 
 struct FmFrame {
     const uint16_t *HT, *HB, *VL, *VR; // ring entries: tile-local id | colour << 15 (1 = white), 0xFFFF = no colour
-    const uint32_t *base;              // first number of every tile's roots (LDS)
+    const uint32_t *base;              // first number of every tile's roots that this workgroup joins (LDS)
+    const uint16_t *boff;              // mode 2: the tile's white roots, which its black ones are numbered behind; else 0 (LDS)
+    const uint16_t *hseg, *vseg;       // the tile edges worth sweeping (LDS): tile row << 5 | tile column of the tile below / on the right
+    int nhs, nvs;
     int w, h, tiles_x, tiles_y;
+    uint32_t mode;                     // what this workgroup joins: 0 the black roots, 1 the white ones, 2 both (a frame with few roots)
+    // k_tile hands out white ids from 0 up and black ones from RING_CAP - 1 down; among the roots this workgroup joins, a tile's
+    // white ones come first (in id order), then its black ones (in reverse id order)
+    __device__ __forceinline__ bool acc(uint32_t e) const { return e != 0xFFFFu && (mode == 2u || (e >> 15) == mode); }
+    __device__ __forceinline__ bool has(int t) const { return base[t + 1] != base[t]; }
+    __device__ __forceinline__ uint32_t num(int t, uint32_t e) const {
+        return base[t] + ((e & 0x8000u) ? (e & 0x7FFFu) : (uint32_t)boff[t] + (uint32_t)(RING_CAP - 1) - (e & 0x7FFFu));
+    }
+    // tile-local id of the l-th of the tile's cnt roots in that order
+    __device__ __forceinline__ uint32_t id_of(int t, uint32_t l, uint32_t cnt) const {
+        const uint32_t nw = mode == 2u ? (uint32_t)boff[t] : (mode == 1u ? cnt : 0u);
+        return l < nw ? l : (uint32_t)(RING_CAP - 1) - (l - nw);
+    }
 };
 // Calls emit(j0, j1, j2) once per boundary pixel slot and lane (uniformly: every lane of the workgroup makes the same number of
 // calls); a join is number | number << 16 when numbers fit 16 bits (LDS path) — the global path passes WIDE = true and gets
 // the two numbers in separate calls of emit2.
+constexpr int FM_BATCH = 4; // rounds whose ring entries are requested together
+// The sweep visits the tile edges of the two lists only: the top edge of a tile that has roots for this workgroup, the left edge of
+// a tile when it or its left neighbour has (fm_edges).  A frame whose background thresholds to "no colour" has few.
+__device__ __forceinline__ void fm_edges(const FmFrame &f, int tiles, uint16_t *hseg, uint16_t *vseg, uint32_t *segn, int tid) {
+    if (tid < 2) segn[tid] = 0;
+    __syncthreads();
+    for (int t = tid; t < tiles; t += FM_NT) {
+        const int ty = t / f.tiles_x, tx = t - ty * f.tiles_x;
+        if (ty >= 1 && f.has(t)) hseg[atomicAdd(&segn[0], 1u)] = (uint16_t)(ty << 5 | tx);
+        if (tx >= 1 && f.base[t + 1] != f.base[t - 1]) vseg[atomicAdd(&segn[1], 1u)] = (uint16_t)(ty << 5 | tx);
+    }
+    __syncthreads();
+}
 template <typename Emit>
 __device__ __forceinline__ void fm_boundaries(const FmFrame &f, int tid, Emit &&emit) {
     const int w = f.w, h = f.h, tiles_x = f.tiles_x;
-    // horizontal boundaries: the top row of tile row ty against the bottom row of tile row ty - 1 (up, and for white up-left / up-right)
-    const int nh = (f.tiles_y - 1) * w;
-    for (int item0 = 0; item0 < nh; item0 += FM_NT) {
-        const int item = item0 + tid;
-        uint32_t a0 = NOJ, b0 = NOJ, b1 = NOJ, b2 = NOJ;
-        if (item < nh) {
-            const int tyi = item / w + 1, x = item - (tyi - 1) * w;
-            const int tlow = (tyi - 1) * tiles_x + tiles_x + (x >> 7);
-            if (x >= 1 && x <= w - 2 && f.base[tlow + 1] != f.base[tlow]) { // an origin column of a tile that has ring-touching roots
-                const uint16_t *up = f.HB + (size_t)(tyi - 1) * w;
-                const uint32_t p = f.HT[(size_t)tyi * w + x], q1 = up[x], q0 = up[x - 1], q2 = up[x + 1], pl = f.HT[(size_t)tyi * w + x - 1];
-                // the pixel on the left made the same joins when it is the same component over the same component (and, for
-                // white, the new diagonal neighbour up-right is that component again): nothing to add
-                // (ring entries are tile-local ids: comparable inside one tile column only)
-                const bool same = x > 1 && (x & (TW - 1)) != 0 && (x & (TW - 1)) != TW - 1 && pl == p && q0 == q1 && (q2 == q1 || !(p & 0x8000u));
-                if (p != 0xFFFFu && !same) {
-                    const int trow = (tyi - 1) * tiles_x;
-                    a0 = f.base[trow + tiles_x + (x >> 7)] + (p & 0x7FFFu);
-                    if (q1 != 0xFFFFu && ((q1 ^ p) & 0x8000u) == 0) b0 = f.base[trow + (x >> 7)] + (q1 & 0x7FFFu);
-                    if (p & 0x8000u) { // white
-                        if ((q0 & 0x8000u) && q0 != 0xFFFFu && q0 != q1) b1 = f.base[trow + ((x - 1) >> 7)] + (q0 & 0x7FFFu);
-                        if ((q2 & 0x8000u) && q2 != 0xFFFFu && q2 != q1) b2 = f.base[trow + ((x + 1) >> 7)] + (q2 & 0x7FFFu);
-                    }
+    // A round = one boundary pixel per lane.  The ring entries come from global memory (written by another kernel: a trip to the
+    // Infinity Cache at best), so the entries of FM_BATCH rounds are requested together and the rounds then worked off.
+    // horizontal edges: the top row of tile row ty against the bottom row of tile row ty - 1 (up, and for white up-left / up-right)
+    const int nh = f.nhs * TW;
+    for (int item0 = 0; item0 < nh; item0 += FM_BATCH * FM_NT) {
+        uint32_t P[FM_BATCH], Q1[FM_BATCH], Q0[FM_BATCH], Q2[FM_BATCH], PL[FM_BATCH];
+        int X[FM_BATCH], TY[FM_BATCH];
+#pragma unroll
+        for (int k = 0; k < FM_BATCH; k++) {
+            const int item = item0 + k * FM_NT + tid;
+            P[k] = 0xFFFFu; Q1[k] = Q0[k] = Q2[k] = PL[k] = 0xFFFFu; X[k] = 0; TY[k] = 1;
+            if (item < nh) {
+                const uint32_t sg = f.hseg[item >> 7];
+                const int tyi = (int)(sg >> 5), x = (int)(sg & 31u) * TW + (item & (TW - 1));
+                X[k] = x; TY[k] = tyi;
+                if (x >= 1 && x <= w - 2) { // an origin column
+                    const uint16_t *up = f.HB + (size_t)(tyi - 1) * w, *lo = f.HT + (size_t)tyi * w;
+                    P[k] = lo[x]; Q1[k] = up[x]; Q0[k] = up[x - 1]; Q2[k] = up[x + 1]; PL[k] = lo[x - 1];
                 }
             }
         }
-        emit(a0, b0, a0, b1, a0, b2);
+#pragma unroll
+        for (int k = 0; k < FM_BATCH; k++) {
+            if (item0 + k * FM_NT >= nh) break; // (uniform)
+            uint32_t a0 = NOJ, b0 = NOJ, b1 = NOJ, b2 = NOJ;
+            const int x = X[k];
+            const uint32_t p = P[k], q1 = Q1[k], q0 = Q0[k], q2 = Q2[k];
+            // the pixel on the left made the same joins when it is the same component over the same component (and, for
+            // white, the new diagonal neighbour up-right is that component again): nothing to add
+            // (ring entries are tile-local ids: comparable inside one tile column only)
+            const bool same = x > 1 && (x & (TW - 1)) != 0 && (x & (TW - 1)) != TW - 1 && PL[k] == p && q0 == q1 && (q2 == q1 || !(p & 0x8000u));
+            if (f.acc(p) && !same) {
+                const int trow = (TY[k] - 1) * tiles_x;
+                a0 = f.num(trow + tiles_x + (x >> 7), p);
+                if (q1 != 0xFFFFu && ((q1 ^ p) & 0x8000u) == 0) b0 = f.num(trow + (x >> 7), q1);
+                if (p & 0x8000u) { // white
+                    if ((q0 & 0x8000u) && q0 != 0xFFFFu && q0 != q1) b1 = f.num(trow + ((x - 1) >> 7), q0);
+                    if ((q2 & 0x8000u) && q2 != 0xFFFFu && q2 != q1) b2 = f.num(trow + ((x + 1) >> 7), q2);
+                }
+            }
+            emit(a0, b0, a0, b1, a0, b2);
+        }
     }
-    // vertical boundaries: the left column of tile column tx against the right column of tile column tx - 1
-    const int nv = (tiles_x - 1) * h;
-    for (int item0 = 0; item0 < nv; item0 += FM_NT) {
-        const int item = item0 + tid;
-        uint32_t ap = NOJ, aq = NOJ, b0 = NOJ, b1 = NOJ, b2 = NOJ;
-        if (item < nv) {
-            const int txi = item / h + 1, y = item - (txi - 1) * h;
+    // vertical edges: the left column of tile column tx against the right column of tile column tx - 1
+    const int nv = f.nvs * TH;
+    for (int item0 = 0; item0 < nv; item0 += FM_BATCH * FM_NT) {
+        uint32_t P[FM_BATCH], Q[FM_BATCH], QL[FM_BATCH], PU[FM_BATCH];
+        int Y[FM_BATCH], TX[FM_BATCH];
+#pragma unroll
+        for (int k = 0; k < FM_BATCH; k++) {
+            const int item = item0 + k * FM_NT + tid;
+            P[k] = Q[k] = QL[k] = PU[k] = 0xFFFFu; Y[k] = 0; TX[k] = 1;
+            if (item < nv) {
+                const uint32_t sg = f.vseg[item >> 5];
+                const int txi = (int)(sg & 31u), y = (int)(sg >> 5) * TH + (item & (TH - 1));
+                Y[k] = y; TX[k] = txi;
+                if (y < h) {
+                    const uint16_t *lf = f.VR + (size_t)(txi - 1) * h, *rt = f.VL + (size_t)txi * h;
+                    P[k] = rt[y]; Q[k] = lf[y];                // pixels (x, y) and (x - 1, y)
+                    if (y > 0) { QL[k] = lf[y - 1]; PU[k] = rt[y - 1]; }
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < FM_BATCH; k++) {
+            if (item0 + k * FM_NT >= nv) break; // (uniform)
+            uint32_t ap = NOJ, aq = NOJ, b0 = NOJ, b1 = NOJ, b2 = NOJ;
+            const int txi = TX[k], y = Y[k];
             const int x = txi * TW;                        // >= 1; an origin unless it is the frame's last column
             const int tp = (y / TH) * tiles_x + txi;       // tile of (x, y); (x - 1, y) lies in tp - 1
-            const bool any = f.base[tp + 1] != f.base[tp - 1]; // either tile has ring-touching roots
-            const uint16_t *lf = f.VR + (size_t)(txi - 1) * h;
-            const uint32_t p = any ? f.VL[(size_t)txi * h + y] : 0xFFFFu; // pixel (x, y)
-            const uint32_t q = any ? lf[y] : 0xFFFFu;       // pixel (x - 1, y): always an origin column (1 <= x - 1 <= w - 2)
-            if (p != 0xFFFFu) ap = f.base[tp] + (p & 0x7FFFu);
-            if (q != 0xFFFFu) aq = f.base[tp - 1] + (q & 0x7FFFu);
+            uint32_t p = P[k], q = Q[k];                    // (x - 1, y) is always an origin column (1 <= x - 1 <= w - 2)
+            if (!f.acc(p)) p = 0xFFFFu;                     // the other colour's pixels: another workgroup's
+            if (!f.acc(q)) q = 0xFFFFu;
+            if (p != 0xFFFFu) ap = f.num(tp, p);
+            if (q != 0xFFFFu) aq = f.num(tp - 1, q);
             if (p != 0xFFFFu && x <= w - 2) {
                 if (q != 0xFFFFu && ((q ^ p) & 0x8000u) == 0) b0 = aq;
                 if ((p & 0x8000u) && y > 0) {              // white: up-left
-                    const uint32_t ql = lf[y - 1];
-                    if ((ql & 0x8000u) && ql != 0xFFFFu) b1 = f.base[((y - 1) / TH) * tiles_x + txi - 1] + (ql & 0x7FFFu);
+                    const uint32_t ql = QL[k];
+                    if ((ql & 0x8000u) && ql != 0xFFFFu) b1 = f.num(((y - 1) / TH) * tiles_x + txi - 1, ql);
                 }
             }
             if (q != 0xFFFFu && (q & 0x8000u) && y > 0) { // white pixel (x - 1, y): up-right is (x, y - 1)
-                const uint32_t pu = f.VL[(size_t)txi * h + y - 1];
-                if ((pu & 0x8000u) && pu != 0xFFFFu) b2 = f.base[((y - 1) / TH) * tiles_x + txi] + (pu & 0x7FFFu);
+                const uint32_t pu = PU[k];
+                if ((pu & 0x8000u) && pu != 0xFFFFu) b2 = f.num(((y - 1) / TH) * tiles_x + txi, pu);
             }
+            emit(ap, b0, ap, b1, aq, b2);
         }
-        emit(ap, b0, ap, b1, aq, b2);
     }
 }
 
@@ -839,70 +900,99 @@ __device__ void fm_global_path(const FmFrame &f, const ck_border_root *__restric
     }
     __threadfence();
     __syncthreads();
-    for (uint32_t k = tid; k < (uint32_t)tiles * RING_CAP; k += FM_NT) {
-        const uint32_t t = k / RING_CAP, l = k - t * RING_CAP;
-        if (l >= f.base[t + 1] - f.base[t]) continue;
-        const uint32_t r = gm_load(gparent, f.base[t] + l);
-        groot[k] = br[r].root;
-        gsize[k] = gm_load(gsz, r);
+    for (int t = tid >> 6; t < tiles; t += FM_NT / 64) {
+        const uint32_t b0 = f.base[t], cnt = f.base[t + 1] - b0;
+        for (uint32_t l = (uint32_t)(tid & 63); l < cnt; l += 64) {
+            const uint32_t r = gm_load(gparent, b0 + l);
+            const size_t slot = (size_t)t * RING_CAP + f.id_of(t, l, cnt);
+            groot[slot] = br[r].root;
+            gsize[slot] = gm_load(gsz, r);
+        }
     }
 }
 
-__global__ __launch_bounds__(FM_NT) void k_fmerge(ck_border_root *__restrict__ broots, const uint32_t *__restrict__ tile_count,
+// One workgroup per (frame, colour): white and black components never join, so the two colours of a frame are two independent
+// union-finds over half the roots each — two workgroups per CU instead of one, each with half the chain of dependent steps.
+// Dynamic LDS: parent u16[cap] | size / key u16[cap] | base u32[tiles + 1] | queue u32[16][FM_WQ].
+__global__ __launch_bounds__(FM_NT, 8) __attribute__((amdgpu_num_sgpr(80))) void k_fmerge(ck_border_root *__restrict__ broots, const uint32_t *__restrict__ tile_count,
                                                   const uint16_t *__restrict__ ring, size_t ring_len, uint32_t *__restrict__ groot_all,
                                                   uint32_t *__restrict__ gsize_all, uint32_t *__restrict__ gscratch, size_t npix, int w, int h,
-                                                  int tiles_x, int tiles_y, int min_comp, int lds_cap, int stop_after) {
-    __shared__ __attribute__((aligned(16))) uint8_t fm_lds[FM_LDS]; // 112 KB: one workgroup per CU
-    __shared__ uint32_t base[FM_MAX_TILES + 1];
-    __shared__ uint32_t wsum[FM_NT / 64];
-    __shared__ uint32_t queue[(FM_NT / 64) * FM_WQ]; // per wave: joins waiting to be worked off
-    const int frame = blockIdx.x, tid = threadIdx.x;
+                                                  int tiles_x, int tiles_y, int n_frames, int min_comp, int lds_cap, int stop_after) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t fm_lds[];
+    __shared__ uint32_t wsum[2 * (FM_NT / 64)];
+    __shared__ uint32_t segn[2];
+    // The first half of the grid are the white workgroups, the second half the black ones (which have nothing to do for a frame
+    // whose roots fit one workgroup: they must not hold the LDS of a CU while white ones wait for it).  Workgroups b and b + 8
+    // share an XCD: a frame's workgroups run where k_tile wrote its ring entries and root slices (XCD f % 8 when frames are
+    // dealt to XCDs).
+    const int half = (int)(gridDim.x >> 1); // a multiple of 8
+    const uint32_t col = (int)blockIdx.x < half ? 1u : 0u; // 1 = white
+    const int frame = (int)blockIdx.x - (col ? 0 : half), tid = threadIdx.x;
+    if (frame >= n_frames) return;
     const int tiles = tiles_x * tiles_y;
+    uint16_t *parent = reinterpret_cast<uint16_t *>(fm_lds);
+    uint16_t *size16 = parent + lds_cap;                                   // (lds_cap is even)
+    uint32_t *base = reinterpret_cast<uint32_t *>(size16 + lds_cap);
+    uint32_t *queue = base + ((tiles + 1 + 3) & ~3);                       // per wave: joins waiting to be worked off
+    uint16_t *boff = reinterpret_cast<uint16_t *>(queue + (FM_NT / 64) * FM_WQ);
+    uint16_t *hseg = boff + ((tiles + 7) & ~7), *vseg = hseg + ((tiles + 7) & ~7);
     const size_t slots = (size_t)tiles * RING_CAP;
     const ck_border_root *slice = broots + (size_t)frame * 2 * slots;
-    ck_border_root *br = broots + (size_t)frame * 2 * slots + slots; // the same entries packed: a root's index here is its number
     uint32_t *groot = groot_all + (size_t)frame * slots, *gsize = gsize_all + (size_t)frame * slots;
     const uint16_t *fr = ring + (size_t)frame * ring_len;
-    // numbers: the tiles' counts, scanned (up to four tiles per thread)
+    FmFrame f;
+    f.HT = fr; f.HB = fr + (size_t)tiles_y * w; f.VL = fr + 2 * (size_t)tiles_y * w; f.VR = f.VL + (size_t)tiles_x * h;
+    f.base = base; f.boff = boff; f.w = w; f.h = h; f.tiles_x = tiles_x; f.tiles_y = tiles_y;
+    // numbers: the tiles' counts, scanned (up to four tiles per thread).  Both colours are counted first: when all of a frame's
+    // roots fit the LDS path together, the white workgroup joins both colours in one sweep and the black one has nothing to do.
+    uint32_t n;
     {
         const int per = (tiles + FM_NT - 1) / FM_NT; // <= 4
-        uint32_t c[4] = {0, 0, 0, 0}, sum = 0;
+        uint32_t cw[4] = {0, 0, 0, 0}, cb[4] = {0, 0, 0, 0}, sw = 0, sb = 0;
         for (int k = 0; k < per; k++) {
             const int t = tid * per + k;
-            c[k] = t < tiles ? tile_count[(size_t)frame * tiles + t] : 0u;
-            sum += c[k];
+            const uint32_t tc = t < tiles ? tile_count[(size_t)frame * tiles + t] : 0u; // white | black << 16
+            cw[k] = tc & 0xFFFFu; cb[k] = tc >> 16;
+            sw += cw[k]; sb += cb[k];
         }
-        const uint32_t incl = wave_scan_u32(sum);
-        if ((tid & 63) == 63) wsum[tid >> 6] = incl;
+        const uint32_t iw = wave_scan_u32(sw), ib = wave_scan_u32(sb);
+        if ((tid & 63) == 63) { wsum[tid >> 6] = iw; wsum[FM_NT / 64 + (tid >> 6)] = ib; }
         __syncthreads();
-        uint32_t off = incl - sum;
-        for (int k = 0; k < (tid >> 6); k++) off += wsum[k];
+        uint32_t ow = iw - sw, ob = ib - sb, nw = 0, nb = 0;
+        for (int k = 0; k < FM_NT / 64; k++) {
+            if (k < (tid >> 6)) { ow += wsum[k]; ob += wsum[FM_NT / 64 + k]; }
+            nw += wsum[k]; nb += wsum[FM_NT / 64 + k];
+        }
+        const bool both = nw + nb <= (uint32_t)lds_cap && min_comp <= 0x7FFF;
+        if (both && !col) return;
+        f.mode = both ? 2u : col;
+        n = both ? nw + nb : (col ? nw : nb);
+        uint32_t off = both ? ow + ob : (col ? ow : ob);
         for (int k = 0; k < per; k++) {
             const int t = tid * per + k;
-            if (t < tiles) base[t] = off;
-            off += c[k];
+            if (t < tiles) { base[t] = off; boff[t] = (uint16_t)(both ? cw[k] : 0u); }
+            off += both ? cw[k] + cb[k] : (col ? cw[k] : cb[k]);
             if (t == tiles - 1) base[tiles] = off;
         }
         __syncthreads();
     }
-    const uint32_t n = base[tiles];
     if (n == 0) return;
-    for (int t = tid >> 6; t < tiles; t += FM_NT / 64) { // pack: a wave per tile copies the used prefix of its slice
+    fm_edges(f, tiles, hseg, vseg, segn, tid);
+    f.hseg = hseg; f.vseg = vseg; f.nhs = (int)segn[0]; f.nvs = (int)segn[1];
+    // the same entries packed, a root's index = its number: from the front of the frame's second half — the black workgroup of a
+    // frame whose colours are joined separately packs at its end (the two colours' roots together are at most `slots`)
+    ck_border_root *br = broots + (size_t)frame * 2 * slots + slots + (f.mode == 0u ? slots - n : 0);
+    for (int t = tid >> 6; t < tiles; t += FM_NT / 64) { // pack: a wave per tile copies the slice's entries it joins
         const uint32_t b0 = base[t], cnt = base[t + 1] - b0;
-        for (uint32_t l = (uint32_t)(tid & 63); l < cnt; l += 64) br[b0 + l] = slice[(size_t)t * RING_CAP + l];
+        for (uint32_t l = (uint32_t)(tid & 63); l < cnt; l += 64) br[b0 + l] = slice[(size_t)t * RING_CAP + f.id_of(t, l, cnt)];
     }
     __syncthreads(); // the packed list was written by this workgroup: visible to it after the barrier
     if (stop_after == 0) return; // diagnostics (CK_FMERGE_STOP_AFTER)
-    FmFrame f;
-    f.HT = fr; f.HB = fr + (size_t)tiles_y * w; f.VL = fr + 2 * (size_t)tiles_y * w; f.VR = f.VL + (size_t)tiles_x * h;
-    f.base = base; f.w = w; f.h = h; f.tiles_x = tiles_x; f.tiles_y = tiles_y;
     if (n > (uint32_t)lds_cap || min_comp > 0x7FFF) {
-        uint32_t *sc = gscratch + (size_t)frame * 2 * slots;
+        uint32_t *sc = gscratch + (size_t)frame * 2 * slots + (f.mode == 0u ? slots - n : 0); // parents; the sizes `slots` further on
         fm_global_path(f, br, n, sc, sc + slots, groot, gsize, tiles);
         return;
     }
-    uint16_t *parent = reinterpret_cast<uint16_t *>(fm_lds);
-    uint16_t *size16 = parent + ((n + 1u) & ~1u);
     // while the unions run, the size array holds the roots' pixel keys: pixel index >> key_shift, 16 bits
     int key_shift = 0;
     while ((npix - 1) >> key_shift > 0xFFFFu) key_shift++;
@@ -912,6 +1002,12 @@ __global__ __launch_bounds__(FM_NT) void k_fmerge(ck_border_root *__restrict__ b
     // Every boundary pixel yields up to three joins; most lanes have fewer, and a join is a chain of dependent LDS reads.  So the
     // joins of a wave are queued in LDS (wave prefix sums) and then worked off one per lane, all lanes busy, instead of every
     // lane running its own zero to three joins while the others wait.
+    if (stop_after == 10) { // diagnostics: the boundary sweep alone (loads and join numbers, no unions)
+        uint32_t acc = 0;
+        fm_boundaries(f, tid, [&](uint32_t a0, uint32_t b0, uint32_t a1, uint32_t b1, uint32_t a2, uint32_t b2) { acc += a0 ^ b0 ^ a1 ^ b1 ^ a2 ^ b2; });
+        if (acc == 0x12345u) groot[0] = acc;
+        return;
+    }
     uint32_t *wq = queue + (tid >> 6) * FM_WQ;
     const int lane = tid & 63;
     uint32_t qn = 0; // joins waiting in the wave's queue (wave-uniform)
@@ -955,13 +1051,14 @@ __global__ __launch_bounds__(FM_NT) void k_fmerge(ck_border_root *__restrict__ b
     }
     __syncthreads();
     if (stop_after == 3) return;
-    // the tables, slot by slot (a tile's used slots are consecutive, so the writes are too)
+    // the tables, tile by tile
     for (int t = tid >> 6; t < tiles; t += FM_NT / 64) {
         const uint32_t b0 = base[t], cnt = base[t + 1] - b0;
         for (uint32_t l = (uint32_t)(tid & 63); l < cnt; l += 64) {
             const uint32_t r = parent[b0 + l];
-            groot[(size_t)t * RING_CAP + l] = br[r].root;
-            gsize[(size_t)t * RING_CAP + l] = size16[r];
+            const size_t slot = (size_t)t * RING_CAP + f.id_of(t, l, cnt);
+            groot[slot] = br[r].root;
+            gsize[slot] = size16[r];
         }
     }
 }
@@ -1023,9 +1120,21 @@ int ck_launch_threshold_segment(ck_handle *h, const uint8_t *frames, int stride,
     {
         static const int fm_stop = getenv("CK_FMERGE_STOP_AFTER") ? atoi(getenv("CK_FMERGE_STOP_AFTER")) : 99;
         const char *cap_env = getenv("CK_FMERGE_CAP"); // tests force the global-memory path with a small value (read per call)
-        const int cap = (cap_env && atoi(cap_env) < FM_CAP) ? atoi(cap_env) : FM_CAP;
-        hipLaunchKernelGGL(k_fmerge, dim3((unsigned)n), dim3(FM_NT), 0, h->stream, h->d_broots, h->d_tile_count, h->d_ring, h->ring_len,
-                           h->d_groot, h->d_gsize, h->d_gscratch, h->npix, h->qw, h->qh, h->tiles_x, h->tiles_y, h->cfg.min_component_px, cap,
+        // roots the LDS path of one workgroup holds (dense binary noise has about 90 per tile).  A frame whose roots fit is joined by ONE
+        // workgroup, both colours in one sweep; a larger one by two, one per colour (1920 x 1080 of dense noise: 23 000 each); a
+        // workgroup with more takes the global-memory path.
+        int cap = tiles * 120;
+        cap = cap < 4096 ? 4096 : (cap > FM_CAP ? FM_CAP : cap);
+        if (cap_env && atoi(cap_env) < cap) cap = atoi(cap_env);
+        cap = (cap + 1) & ~1;
+        const size_t lds = (size_t)cap * 4 + (size_t)((tiles + 1 + 3) & ~3) * 4 + (size_t)(FM_NT / 64) * FM_WQ * 4 + (size_t)((tiles + 7) & ~7) * 2 * 3;
+        static bool attr_set = false;
+        if (!attr_set) {
+            CK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_fmerge), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(k_fmerge, dim3((unsigned)(((n + 7) / 8) * 16)), dim3(FM_NT), lds, h->stream, h->d_broots, h->d_tile_count, h->d_ring, h->ring_len,
+                           h->d_groot, h->d_gsize, h->d_gscratch, h->npix, h->qw, h->qh, h->tiles_x, h->tiles_y, n, h->cfg.min_component_px, cap,
                            fm_stop);
     }
     CK_HIP(hipGetLastError());
