@@ -22,7 +22,12 @@
 #include <unistd.h>
 
 #include <array>
+#include <atomic>
 #include <cmath>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
+#include <thread>
 #include <cstdint>
 #include <cstring>
 #include <map>
@@ -399,6 +404,92 @@ inline std::optional<double> decode_gyro(const uint8_t *buf, size_t len) {
     std::memcpy(&v, &bits, sizeof v);
     return v;
 }
+
+// Comm (lib.rs:99-185): the gyro listener and the measurement publisher, each on a thread of its own.  The listener binds
+// 0.0.0.0:<gyro_port> (7002 in the reference) and stores every 8-byte datagram as the current heading; publish() queues a
+// measurement for the sender thread, which puts it on the wire through a WhacknetClient.  gyro_angle() starts at 0.0 like
+// the reference's `Some(0f64)`; dropping the Comm ends both threads (the reference's listener only notices on its next
+// datagram; here the socket has a receive timeout so that the destructor returns).
+class Comm {
+  public:
+    explicit Comm(uint16_t gyro_port = 7002, const std::string &remote_ip = "10.45.33.2", uint16_t remote_port = 7001)
+        : client_(remote_ip, remote_port) {
+        gyro_fd_ = ::socket(AF_INET, SOCK_DGRAM, 0);
+        sockaddr_in local{};
+        local.sin_family = AF_INET; local.sin_addr.s_addr = htonl(INADDR_ANY); local.sin_port = htons(gyro_port);
+        if (gyro_fd_ < 0 || ::bind(gyro_fd_, reinterpret_cast<sockaddr *>(&local), sizeof local) != 0) {
+            if (gyro_fd_ >= 0) ::close(gyro_fd_);
+            throw Panic("whacknet: gyro socket bind failed"); // `.unwrap()` at lib.rs:113
+        }
+        socklen_t ll = sizeof local;
+        ::getsockname(gyro_fd_, reinterpret_cast<sockaddr *>(&local), &ll);
+        gyro_port_ = ntohs(local.sin_port);
+        timeval tv{0, 100000};
+        ::setsockopt(gyro_fd_, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof tv);
+        listener_ = std::thread([this] {
+            uint8_t buf[8];
+            while (!stop_.load(std::memory_order_acquire)) {
+                std::memset(buf, 0, sizeof buf);                                  // `buf = [0u8; 8]` per datagram (lib.rs:128)
+                const ssize_t got = ::recv(gyro_fd_, buf, sizeof buf, 0);
+                if (got < 0) continue;                                            // Err(_) => {} (lib.rs:125)
+                uint64_t bits = 0;                                                // f64::from_le_bytes(buf): a short datagram leaves zero bytes
+                for (int i = 7; i >= 0; i--) bits = (bits << 8) | buf[i];
+                gyro_bits_.store(bits, std::memory_order_release);
+            }
+        });
+        sender_ = std::thread([this] {
+            std::unique_lock<std::mutex> lk(mu_);
+            for (;;) {
+                cv_.wait(lk, [this] { return !queue_.empty() || stop_.load(std::memory_order_acquire); });
+                if (queue_.empty()) return;                                       // stopping and drained
+                const VisionMeasurement m = queue_.front();
+                queue_.pop_front();
+                lk.unlock();
+                client_.send(m);                                                  // `.ok()`: a failed send is dropped (lib.rs:142)
+                lk.lock();
+            }
+        });
+    }
+    ~Comm() {
+        stop_.store(true, std::memory_order_release);
+        cv_.notify_all();
+        if (sender_.joinable()) sender_.join();
+        if (listener_.joinable()) listener_.join();
+        ::close(gyro_fd_);
+    }
+    Comm(const Comm &) = delete;
+    Comm &operator=(const Comm &) = delete;
+    // lib.rs:154-172
+    void publish(uint8_t cam_id, uint8_t tag_count, uint64_t ts, double x, double y, double rot, double std_x, double std_y, double std_rot) {
+        VisionMeasurement m{};
+        m.pose_x = x; m.pose_y = y; m.pose_rot = rot; m.std_x = std_x; m.std_y = std_y; m.std_rot = std_rot;
+        m.ts = ts; m.camera_id = cam_id; m.tag_count = tag_count;
+        publish(m);
+    }
+    void publish(const VisionMeasurement &m) {
+        { std::lock_guard<std::mutex> lk(mu_); queue_.push_back(m); }
+        cv_.notify_one();
+    }
+    // lib.rs:174-179: the last heading received (0.0 before the first datagram)
+    std::optional<double> gyro_angle() const {
+        const uint64_t bits = gyro_bits_.load(std::memory_order_acquire);
+        double v;
+        std::memcpy(&v, &bits, sizeof v);
+        return v;
+    }
+    uint16_t gyro_port() const { return gyro_port_; } // the bound port (pass 0 to let the system pick one: tests)
+
+  private:
+    WhacknetClient client_;
+    int gyro_fd_ = -1;
+    uint16_t gyro_port_ = 0;
+    std::atomic<uint64_t> gyro_bits_{0};
+    std::atomic<bool> stop_{false};
+    std::mutex mu_;
+    std::condition_variable cv_;
+    std::deque<VisionMeasurement> queue_;
+    std::thread listener_, sender_;
+};
 } // namespace whacknet
 
 // Pinned host slots + asynchronous upload (the pooled host buffers of the camera layer,

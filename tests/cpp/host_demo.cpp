@@ -74,6 +74,42 @@ static int selfcheck() {
         auto back = whacknet::decode_gyro(gb, 8);
         if (!back || *back != g || whacknet::decode_gyro(gb, 4)) { std::puts("FAIL gyro decode"); return 1; }
     }
+    {   // whacknet::Comm: the gyro listener thread picks up a heading sent to its port, publish() reaches the wire through
+        // the sender thread (crates/whacknet/src/lib.rs:99-185)
+        int rx = ::socket(AF_INET, SOCK_DGRAM, 0);
+        sockaddr_in a{};
+        a.sin_family = AF_INET; a.sin_addr.s_addr = htonl(INADDR_LOOPBACK); a.sin_port = 0;
+        socklen_t al = sizeof a;
+        if (rx < 0 || ::bind(rx, reinterpret_cast<sockaddr *>(&a), sizeof a) != 0 || ::getsockname(rx, reinterpret_cast<sockaddr *>(&a), &al) != 0) {
+            std::puts("FAIL loopback socket"); return 1;
+        }
+        timeval tv{2, 0};
+        ::setsockopt(rx, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof tv);
+        {
+            whacknet::Comm comm(0, "127.0.0.1", ntohs(a.sin_port));
+            auto g0 = comm.gyro_angle();
+            if (!g0 || *g0 != 0.0) { std::puts("FAIL comm initial gyro"); return 1; }
+            int tx = ::socket(AF_INET, SOCK_DGRAM, 0);
+            sockaddr_in to{};
+            to.sin_family = AF_INET; to.sin_addr.s_addr = htonl(INADDR_LOOPBACK); to.sin_port = htons(comm.gyro_port());
+            const double heading = 0.7853981633974483;
+            bool seen = false;
+            for (int tries = 0; tries < 200 && !seen; tries++) {
+                ::sendto(tx, &heading, 8, 0, reinterpret_cast<sockaddr *>(&to), sizeof to);
+                ::usleep(5000);
+                seen = *comm.gyro_angle() == heading;
+            }
+            ::close(tx);
+            if (!seen) { std::puts("FAIL comm gyro listener"); return 1; }
+            comm.publish(2, 5, 0xABCDEF0123456789ull, 1.5, 2.5, -0.25, 0.1, 0.2, 0.3);
+            unsigned char buf[128];
+            whacknet::VisionMeasurement want{};
+            want.pose_x = 1.5; want.pose_y = 2.5; want.pose_rot = -0.25; want.std_x = 0.1; want.std_y = 0.2; want.std_rot = 0.3;
+            want.ts = 0xABCDEF0123456789ull; want.camera_id = 2; want.tag_count = 5;
+            if (::recv(rx, buf, sizeof buf, 0) != 64 || std::memcmp(buf, &want, 64) != 0) { std::puts("FAIL comm publish"); return 1; }
+        } // ~Comm joins both threads
+        ::close(rx);
+    }
     int devs = ck_device_count();
     if (devs <= 0) {
         try {

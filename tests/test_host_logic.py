@@ -108,3 +108,36 @@ def test_cat_utils_helpers(oracle):
     for i in range(len(hull)):
         a, b = hull[i], hull[(i + 1) % len(hull)]
         assert all(cat.orientation(a, p, b) != cat.COUNTERCLOCKWISE for p in pts)
+
+
+def test_whacknet_comm_loopback():
+    """crates/whacknet/src/lib.rs:99-185: the listener thread keeps the last heading sent to its port (0.0 before the first one,
+    short datagrams zero-extended), publish() puts exactly the 64 bytes of the record on the wire through the sender thread."""
+    import socket, struct, time
+    from chalkydri_amd import whacknet
+    from chalkydri_amd._abi import VisionMeasurement
+    rx = socket.socket(socket.AF_INET, socket.SOCK_DGRAM)
+    rx.bind(("127.0.0.1", 0))
+    rx.settimeout(2.0)
+    comm = whacknet.Comm(gyro_port=0, remote=("127.0.0.1", rx.getsockname()[1]))
+    try:
+        assert comm.gyro_angle() == 0.0
+        tx = socket.socket(socket.AF_INET, socket.SOCK_DGRAM)
+        heading = -2.356194490192345
+        for _ in range(200):
+            tx.sendto(struct.pack("<d", heading), ("127.0.0.1", comm.gyro_port))
+            time.sleep(0.005)
+            if comm.gyro_angle() == heading:
+                break
+        assert comm.gyro_angle() == heading
+        comm.publish(4, 3, 0x0102030405060708, (1.0, -2.0, 0.5), (0.01, 0.02, 0.03))
+        data = rx.recv(128)
+        want = VisionMeasurement()
+        want.pose_x, want.pose_y, want.pose_rot, want.std_x, want.std_y, want.std_rot = 1.0, -2.0, 0.5, 0.01, 0.02, 0.03
+        want.ts, want.camera_id, want.tag_count = 0x0102030405060708, 4, 3
+        assert len(data) == 64 and data == bytes(want)
+        assert data[:8] == struct.pack("<d", 1.0) and data[48:56] == struct.pack("<Q", 0x0102030405060708) and data[56] == 4 and data[57] == 3
+        assert whacknet.decode_gyro(struct.pack("<d", 1.25)) == 1.25 and whacknet.decode_gyro(b"\x00" * 4) is None
+    finally:
+        comm.close()
+        rx.close()
