@@ -230,7 +230,7 @@ def main():
             "config": {"workload": f"{w}x{h} mono8 batch={n}/GPU, tag36h11, {args.tags} field tags/frame (3-D scenes), background ramp+-24 "
                                    f"noise+-{args.noise}, quad_decimate={args.decimate}, detect+pose, one stream per GPU",
                        "frames_with_pose": round(valid_frac, 4), "post_segment_streams": int(os.environ.get("CK_STREAMS", "1")), "gather": gather_kind},
-            "roofline": {"bound": "hbm", "kernel": "threshold+segment (k_tile + k_merge + k_roots)", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
+            "roofline": {"bound": "hbm", "kernel": "threshold+segment (k_tile + k_fmerge)", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_src, "measured_copy_GBps": round(copy_gbps, 1),
                          "algorithmic_bytes_per_launch": ALG_BYTES_PER_PX * w * h * n, "avg_launch_ms": round(ms_thr, 4),
                          "launch_ms_p10_median_p90": [round(float(np.percentile(thr_ms, q)), 4) for q in (10, 50, 90)]},

@@ -6,7 +6,8 @@ out = {"kernel": "k_tile<false> (one launch = 1280x800x256, 64 000 workgroups of
                  "(SQ_* cycle counters are quad-cycles summed over waves)"}
 for k in (1, 2):
     acc, launches = {}, {}
-    for f in glob.glob(os.path.join(root, "gpurun_out", f"pmc_tile{k}", "**", "*counter_collection.csv"), recursive=True):
+    files = glob.glob(os.path.join(root, "gpurun_out", f"pmc_tile{k}", "**", "*counter_collection.csv"), recursive=True)
+    for f in sorted(files, key=os.path.getmtime)[-1:]: # the newest pass only: gpurun merges into whatever earlier runs left behind
         for r in csv.DictReader(open(f)):
             if "k_tile" not in r["Kernel_Name"]:
                 continue
