@@ -39,8 +39,10 @@ struct ck_dev_family {
 };
 
 // One boundary point while it waits to be grouped (k_clusters.hip)
-// size classes of the quad fit (k_quads.hip): <= 512, <= 2048, <= 4096, <= 8192, <= 16384 points per cluster
-constexpr int CK_FIT_CLASSES = 5;
+// size classes of the quad fit (k_quads.hip): <= 512, <= 2048, <= 4096, <= 8192, <= 16384 points per cluster, and the rest (up to
+// 3 * (2w + 2h): only frames with more than 2730 pixels of half-perimeter can have such clusters)
+constexpr int CK_FIT_CLASSES = 6;
+constexpr int CK_HUGE_CAP = 65536, CK_HUGE_WGS = 32; // largest class: points per cluster (3 * 4 * 4095 < 65536), workgroups in its grid
 constexpr int CK_FIT_PARALLEL_MAX_FRAMES = 4; // calls with at most this many frames run the classes side by side ...
 constexpr int CK_FIT_SIDE_STREAMS = 2;         // ... on the handle's stream and this many more (a process has few hardware queues)
 constexpr int CK_LSCRATCH_PER_WG = 16384, CK_LSCRATCH_WGS = 1024; // large class: points per cluster, workgroups in its grid (at most)
@@ -79,6 +81,7 @@ struct ck_stage_ws {
     ck_run *d_runs;            // [n][run_cap]
     int run_cap;
     unsigned long long *d_lscratch; // [CK_LSCRATCH_WGS][CK_LSCRATCH_PER_WG]: sort scratch / maxima list of the large fit class, per workgroup
+    unsigned long long *d_hscratch; // [2][CK_HUGE_WGS][2][CK_HUGE_CAP]: keys + sort scratch / maxima list of the largest class (null when no cluster can be that large)
     ck_cluster_t *d_clusters;  // [n][cluster_cap]
     uint32_t *d_counters;      // [n][8]: 0 tmp points, 1 clusters, 2 kept points, 3 quads, 4 detections, 5 status
     ck_quad_t *d_quads;        // [n][quad_cap]

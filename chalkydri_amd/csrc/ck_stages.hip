@@ -22,8 +22,7 @@ int ck_stage_alloc(ck_handle *h) {
     ws.det_cap = 256;
     ws.ht_size = next_pow2(2 * ws.cluster_cap);
     if (ws.ht_size < 1024) ws.ht_size = 1024;
-    ws.max_cluster_points = 3 * (2 * h->qw + 2 * h->qh);
-    if (ws.max_cluster_points > 16384) ws.max_cluster_points = 16384;
+    ws.max_cluster_points = 3 * (2 * h->qw + 2 * h->qh); // AprilTag-3's bound; <= 3 * 4 * 4095 < CK_HUGE_CAP (ck_create bounds the sides)
     if (cfg.max_nmaxima < 4 || cfg.max_nmaxima > 12) return CK_EINVAL;
     CK_HIP(hipMalloc(&ws.d_ht_keys, sizeof(unsigned long long) * (size_t)ws.ht_size * nb));
     CK_HIP(hipMalloc(&ws.d_ht_count, sizeof(uint32_t) * (size_t)ws.ht_size * nb));
@@ -33,6 +32,9 @@ int ck_stage_alloc(ck_handle *h) {
     ws.run_cap = 4 * ws.cluster_cap;
     CK_HIP(hipMalloc(&ws.d_runs, sizeof(ck_run) * (size_t)ws.run_cap * nb));
     CK_HIP(hipMalloc(&ws.d_lscratch, 2 * sizeof(unsigned long long) * (size_t)CK_LSCRATCH_PER_WG * CK_LSCRATCH_WGS));
+    ws.d_hscratch = nullptr;
+    if (ws.max_cluster_points > 16384) // (one copy per stream of a split batch)
+        CK_HIP(hipMalloc(&ws.d_hscratch, 2 * sizeof(unsigned long long) * 2 * (size_t)CK_HUGE_CAP * CK_HUGE_WGS));
     CK_HIP(hipMalloc(&ws.d_clusters, sizeof(ck_cluster_t) * (size_t)ws.cluster_cap * nb));
     CK_HIP(hipMalloc(&ws.d_counters, sizeof(uint32_t) * CK_CNT_STRIDE * nb));
     CK_HIP(hipMalloc(&ws.d_quads, sizeof(ck_quad_t) * (size_t)ws.quad_cap * nb));
@@ -82,7 +84,7 @@ void ck_stage_free(ck_handle *h) {
         (void)hipFree(h->d_fams);
     }
     (void)hipFree(ws.d_ht_keys); (void)hipFree(ws.d_ht_count); (void)hipFree(ws.d_ht_off); (void)hipFree(ws.d_tmp);
-    (void)hipFree(ws.d_points); (void)hipFree(ws.d_runs); (void)hipFree(ws.d_lscratch); (void)hipFree(ws.d_clusters); (void)hipFree(ws.d_counters); (void)hipFree(ws.d_quads);
+    (void)hipFree(ws.d_points); (void)hipFree(ws.d_runs); (void)hipFree(ws.d_lscratch); (void)hipFree(ws.d_hscratch); (void)hipFree(ws.d_clusters); (void)hipFree(ws.d_counters); (void)hipFree(ws.d_quads);
     (void)hipFree(ws.d_dets); (void)hipFree(ws.d_fit_scratch); (void)hipFree(ws.d_wimg);
     (void)hipFree(ws.d_field); (void)hipFree(ws.d_gyro); (void)hipFree(ws.d_has_gyro); (void)hipFree(ws.d_problems);
     (void)hipFree(ws.d_pose_tags); (void)hipFree(ws.d_bearings); (void)hipFree(ws.d_world); (void)hipFree(ws.d_results);
@@ -115,6 +117,7 @@ static ck_handle make_view(const ck_handle *h, int f0, bool second_stream = true
     w.d_ht_keys += f * w.ht_size; w.d_ht_count += f * w.ht_size; w.d_ht_off += f * w.ht_size;
     w.d_tmp += f * w.point_cap; w.d_points += f * w.point_cap; w.d_runs += f * w.run_cap;
     if (second_stream) w.d_lscratch += (size_t)CK_LSCRATCH_PER_WG * CK_LSCRATCH_WGS;
+    if (second_stream && w.d_hscratch) w.d_hscratch += 2 * (size_t)CK_HUGE_CAP * CK_HUGE_WGS;
     w.d_clusters += f * w.cluster_cap; w.d_counters += f * CK_CNT_STRIDE; w.d_quads += f * w.quad_cap; w.d_dets += f * w.det_cap;
     w.d_wimg += f * npix;
     if (second_stream) w.d_fit_scratch = static_cast<uint8_t *>(w.d_fit_scratch) + w.fit_scratch_bytes;

@@ -16,7 +16,7 @@
 //      fit per ordered pair, every 4-subset evaluated in parallel (argmin with the oracle's lexicographic tie-break);
 //   6. lines, corners, area/angle/winding checks on four lanes, wave-parallel edge refinement.
 // Clusters are dispatched through per-size-class work lists built by k_classify (<= 512, <= 2048, <= 4096, <= 8192,
-// <= 16384 points); each variant is a persistent grid whose workgroups take a first chunk of their list by index and the
+// <= 16384 points, and the rest); each variant is a persistent grid whose workgroups take a first chunk of their list by index and the
 // rest from a dequeue counter.  The phases can be cut short for measurements with CK_FIT_STOP_AFTER (tools/ablate_fit.sh).
 #include <stdlib.h>
 
@@ -469,7 +469,8 @@ __device__ __forceinline__ long long keys_bucket_sort(unsigned long long *sKeys,
 // pass walks that slice and writes the sorted keys to LDS.  The staged points stay intact until the bucket sizes are known,
 // so the bitonic fallback can still start from them.
 constexpr int BUCKET_LIMIT_L = 96;
-template <int NTH>
+// NOLIMIT: the largest class has no other sort to fall back on; its rank pass takes whatever the buckets hold
+template <int NTH, bool NOLIMIT>
 __device__ __forceinline__ long long keys_bucket_sort_global(unsigned long long *sKeys, uint32_t *hist /* [2 * (1024 + 1)] */, long long *sScratch,
                                                              unsigned long long *gtmp, int sz0, int xmin, int xmax, int ymin, int ymax,
                                                              int normal_ok, int reversed_ok, bool do_sort, bool *done) {
@@ -505,7 +506,7 @@ __device__ __forceinline__ long long keys_bucket_sort_global(unsigned long long 
         long long total;
         const long long incl = B::scan_incl((long long)sum, sScratch, &total);
         const int worst = -B::reduce_min(-(int)mx, reinterpret_cast<int *>(sScratch));
-        if (worst > BUCKET_LIMIT_L) { *done = false; __syncthreads(); return dot; }
+        if (!NOLIMIT && worst > BUCKET_LIMIT_L) { *done = false; __syncthreads(); return dot; }
         uint32_t run = (uint32_t)(incl - sum);
         for (int q = 0; q < per; q++) { uint32_t c = hist[tid * per + q]; hist[tid * per + q] = run; cursor[tid * per + q] = run; run += c; }
         if (tid == NTH - 1) hist[nb] = run;
@@ -530,8 +531,9 @@ __device__ __forceinline__ long long keys_bucket_sort_global(unsigned long long 
     return dot;
 }
 
-// NTH threads per cluster, up to CAP points, chunks of CH points; MLDS: the maxima list fits in LDS
-template <int NTH, int CAP, int CH, bool MLDS, int WPS>
+// NTH threads per cluster, up to CAP points, chunks of CH points; MLDS: the maxima list fits in LDS; GK: the per-point arrays
+// (keys, then coordinates and weights) live in a per-workgroup slice of global memory instead of LDS (the largest class)
+template <int NTH, int CAP, int CH, bool MLDS, int WPS, bool GK = false>
 __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(WPS, 8))) void k_fit(FitArgs a) {
     using B = Block<NTH>;
     constexpr int SL = CH + 2 * HALO;
@@ -544,7 +546,8 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(WPS, 8))) v
     constexpr int MAXM = MLDS ? CAP / 2 : 1;
     // sKeys holds the 64-bit sort keys; after duplicate removal its first half is reused for the packed
     // coordinates (x<<13|y, u32) and the third quarter for the u16 weights.
-    __shared__ unsigned long long sKeys[CAP];
+    __shared__ unsigned long long sKeysL[GK ? 1 : CAP];
+    unsigned long long *const sKeys = GK ? a.ws.d_hscratch + (size_t)blockIdx.x * 2 * CAP : sKeysL;
     // inclusive moment prefix sums over the current span of SL points: Mxx, Mxy, Myy as 64-bit and Mx, My, W as 32-bit
     // (a span's sums stay below 304 * 362 * 8192 < 2^32); the same bytes are the sort's histogram before and the pair-fit
     // table after the chunk loop
@@ -610,7 +613,7 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(WPS, 8))) v
         const ck_packed_point *pts = ws.d_points + (size_t)frame * ws.point_cap + cl.start;
         // 8 bytes per point for the large class (sort scratch, then the maxima list): one fixed region per workgroup, so
         // the same few hundred KB are reused cluster after cluster and stay in L2
-        unsigned long long *scratch8 = ws.d_lscratch + (size_t)blockIdx.x * CK_LSCRATCH_PER_WG;
+        unsigned long long *scratch8 = GK ? ws.d_hscratch + (size_t)blockIdx.x * 2 * CAP + CAP : ws.d_lscratch + (size_t)blockIdx.x * CK_LSCRATCH_PER_WG;
         const int sz0 = (int)cl.count;
         const uint16_t *wq = a.wimg + (size_t)frame * a.qw * a.qh;
         const uint8_t *im = a.im + (size_t)frame * a.pitch;
@@ -675,15 +678,15 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(WPS, 8))) v
                 dot = keys_bucket_sort<NTH, EPLS>(sKeys, reinterpret_cast<uint32_t *>(sPraw), sScratch, sz0, xmin, xmax, ymin, ymax,
                                                   a.normal_ok, a.reversed_ok, a.stop_after != 11, &sorted);
             else
-                dot = keys_bucket_sort_global<NTH>(sKeys, reinterpret_cast<uint32_t *>(sPraw), sScratch,
+                dot = keys_bucket_sort_global<NTH, GK>(sKeys, reinterpret_cast<uint32_t *>(sPraw), sScratch,
                                                    scratch8, sz0, xmin, xmax, ymin, ymax,
                                                    a.normal_ok, a.reversed_ok, a.stop_after != 11, &sorted);
-            if (sorted) {}
-            else if (EPLS >= 32 && epl == 32) dot = keys_sort<NTH, (EPLS >= 32 ? 32 : 1)>(sKeys, sScratch, sz0, xmin, xmax, ymin, ymax, a.normal_ok, a.reversed_ok, a.stop_after != 11);
-            else if (EPLS >= 16 && epl == 16) dot = keys_sort<NTH, (EPLS >= 16 ? 16 : 1)>(sKeys, sScratch, sz0, xmin, xmax, ymin, ymax, a.normal_ok, a.reversed_ok, a.stop_after != 11);
-            else if (EPLS >= 8 && epl == 8) dot = keys_sort<NTH, (EPLS >= 8 ? 8 : 1)>(sKeys, sScratch, sz0, xmin, xmax, ymin, ymax, a.normal_ok, a.reversed_ok, a.stop_after != 11);
-            else if (EPLS >= 4 && epl == 4) dot = keys_sort<NTH, (EPLS >= 4 ? 4 : 1)>(sKeys, sScratch, sz0, xmin, xmax, ymin, ymax, a.normal_ok, a.reversed_ok, a.stop_after != 11);
-            else if (EPLS >= 2 && epl == 2) dot = keys_sort<NTH, (EPLS >= 2 ? 2 : 1)>(sKeys, sScratch, sz0, xmin, xmax, ymin, ymax, a.normal_ok, a.reversed_ok, a.stop_after != 11);
+            if (sorted || GK) {}
+            else if (EPLS >= 32 && epl == 32) dot = keys_sort<NTH, (EPLS >= 32 && !GK ? 32 : 1)>(sKeys, sScratch, sz0, xmin, xmax, ymin, ymax, a.normal_ok, a.reversed_ok, a.stop_after != 11);
+            else if (EPLS >= 16 && epl == 16) dot = keys_sort<NTH, (EPLS >= 16 && !GK ? 16 : 1)>(sKeys, sScratch, sz0, xmin, xmax, ymin, ymax, a.normal_ok, a.reversed_ok, a.stop_after != 11);
+            else if (EPLS >= 8 && epl == 8) dot = keys_sort<NTH, (EPLS >= 8 && !GK ? 8 : 1)>(sKeys, sScratch, sz0, xmin, xmax, ymin, ymax, a.normal_ok, a.reversed_ok, a.stop_after != 11);
+            else if (EPLS >= 4 && epl == 4) dot = keys_sort<NTH, (EPLS >= 4 && !GK ? 4 : 1)>(sKeys, sScratch, sz0, xmin, xmax, ymin, ymax, a.normal_ok, a.reversed_ok, a.stop_after != 11);
+            else if (EPLS >= 2 && epl == 2) dot = keys_sort<NTH, (EPLS >= 2 && !GK ? 2 : 1)>(sKeys, sScratch, sz0, xmin, xmax, ymin, ymax, a.normal_ok, a.reversed_ok, a.stop_after != 11);
             else dot = keys_sort<NTH, 1>(sKeys, sScratch, sz0, xmin, xmax, ymin, ymax, a.normal_ok, a.reversed_ok, a.stop_after != 11);
         }
         const int reversed = dot < 0;
@@ -1278,7 +1281,7 @@ __global__ __launch_bounds__(1024) void k_classify(ck_stage_ws ws, int n, uint32
     const uint32_t *counters = ws.d_counters + (size_t)frame * CK_CNT_STRIDE;
     const uint32_t nc = counters[CK_CNT_CLUSTERS];
     const ck_cluster_t *cls = ws.d_clusters + (size_t)frame * ws.cluster_cap;
-    auto class_of = [](uint32_t c) { return c <= 512 ? 0 : (c <= 2048 ? 1 : (c <= 4096 ? 2 : (c <= 8192 ? 3 : 4))); };
+    auto class_of = [](uint32_t c) { return c <= 512 ? 0 : (c <= 2048 ? 1 : (c <= 4096 ? 2 : (c <= 8192 ? 3 : (c <= 16384 ? 4 : 5)))); };
     if (tid < CK_FIT_CLASSES) sCnt[tid] = 0;
     __syncthreads();
     for (uint32_t i = tid; i < nc; i += 1024) atomicAdd(&sCnt[class_of(cls[i].count)], 1u);
@@ -1343,7 +1346,7 @@ int ck_launch_fit_quads(ck_handle *h, const uint8_t *qframes, int qstride, size_
     const bool side_by_side = n <= CK_FIT_PARALLEL_MAX_FRAMES;
     // three lanes of similar length for a typical frame: {S, M1} on the handle's stream, {L1} and {M2, L2} on the side streams
     // (more streams than that end up sharing hardware queues and wait for each other anyway)
-    hipStream_t cs[CK_FIT_CLASSES] = {h->stream, h->stream, h->stream, h->stream, h->stream};
+    hipStream_t cs[CK_FIT_CLASSES] = {h->stream, h->stream, h->stream, h->stream, h->stream, h->stream};
     if (side_by_side) {
         cs[3] = h->fit_stream[0]; cs[2] = h->fit_stream[1]; cs[4] = h->fit_stream[1];
         CK_HIP(hipEventRecord(h->ev_fit_fork, h->stream));
@@ -1356,10 +1359,13 @@ int ck_launch_fit_quads(ck_handle *h, const uint8_t *qframes, int qstride, size_
         case 1: hipLaunchKernelGGL((k_fit<256, 2048, 512, true, 3>), dim3((unsigned)(cus * 3)), dim3(256), 0, cs[c], a); break;
         case 2: hipLaunchKernelGGL((k_fit<256, 4096, 512, true, 2>), dim3((unsigned)(cus * 2)), dim3(256), 0, cs[c], a); break;
         case 3: hipLaunchKernelGGL((k_fit<512, 8192, 512, true, 2>), dim3((unsigned)cus), dim3(512), 0, cs[c], a); break;
-        default: hipLaunchKernelGGL((k_fit<512, 16384, 512, false, 2>), dim3((unsigned)cus), dim3(512), 0, cs[c], a); break;
+        case 4: hipLaunchKernelGGL((k_fit<512, 16384, 512, false, 2>), dim3((unsigned)cus), dim3(512), 0, cs[c], a); break;
+        default: // more than 16384 points: only frames with more than 2730 pixels of half-perimeter have the buffer (and can have such clusters)
+            if (ws.d_hscratch) hipLaunchKernelGGL((k_fit<512, CK_HUGE_CAP, 512, false, 2, true>), dim3((unsigned)CK_HUGE_WGS), dim3(512), 0, cs[c], a);
+            break;
         }
     };
-    if (side_by_side) { launch(3); launch(2); launch(4); launch(0); launch(1); } // the side lanes first, then the handle's own
+    if (side_by_side) { launch(3); launch(2); launch(4); launch(0); launch(1); launch(5); } // the side lanes first, then the handle's own
     else for (int c = 0; c < CK_FIT_CLASSES; c++) launch(c);
     if (side_by_side)
         for (int k = 0; k < CK_FIT_SIDE_STREAMS; k++) {

@@ -542,7 +542,6 @@ int ora_fit_quads(const uint8_t *qim, int qw, int qh, int qstride, const uint8_t
     c.min_tag_width /= dec;
     if (c.min_tag_width < 3) c.min_tag_width = 3;
     c.max_cluster_points = 3 * (2 * qw + 2 * qh);
-    if (c.max_cluster_points > 16384) c.max_cluster_points = 16384;
     int nq = 0, overflow = 0;
     for (int k = 0; k < n_clusters; k++) {
         ck_quad_t q;

@@ -39,7 +39,7 @@ def test_clusters_match_oracle(oracle, w, h, n_tags, kw):
     frames, _ = _synth(11, w, h, n, n_tags, **kw)
     det = AprilTagDetector(w, h, max_batch=n)
     got = det.clusters(frames)
-    maxpts = min(3 * (2 * w + 2 * h), 16384)
+    maxpts = 3 * (2 * w + 2 * h)
     for i in range(n):
         th = oracle.threshold(frames[i])
         lab, sz = oracle.segment(th)
@@ -116,7 +116,9 @@ def _shapes(w, h, seed):
     return np.clip(im.astype(np.int64) + noise, 0, 255).astype(np.uint8)
 
 
-@pytest.mark.parametrize("w,h,seed", [(640, 480, 1), (1280, 800, 2)])
+# the two large frames have outlines of more than 16384 points (at most 3 * (2w + 2h), AprilTag-3's bound): the largest size class,
+# whose per-point arrays live in global memory
+@pytest.mark.parametrize("w,h,seed", [(640, 480, 1), (1280, 800, 2), (1920, 1080, 4), (2448, 2048, 3)])
 def test_quads_match_oracle_on_drawn_shapes(oracle, w, h, seed):
     from chalkydri_amd.detector import AprilTagDetector
     frames = np.stack([_shapes(w, h, seed), _shapes(w, h, seed + 10)[::-1].copy()])
@@ -137,6 +139,8 @@ def test_quads_match_oracle_on_drawn_shapes(oracle, w, h, seed):
     assert nq >= 3
     # all three size classes of the fit kernel were exercised
     assert any(s <= 512 for s in sizes) and any(512 < s <= 4096 for s in sizes) and any(4096 < s <= 16384 for s in sizes)
+    if 3 * (2 * w + 2 * h) > 16384:
+        assert any(16384 < s <= 3 * (2 * w + 2 * h) for s in sizes)
     det.close()
 
 
