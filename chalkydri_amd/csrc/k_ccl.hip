@@ -667,7 +667,7 @@ namespace {
 // more takes the same steps in global memory (fm_global_path).  The frame-level root must be the component's smallest
 // pixel, so a union hooks the root with the larger PIXEL under the other one (compare-and-swap on the root's own entry).
 constexpr int FM_NT = 1024;
-constexpr int FM_CAP = 28672;                 // roots per frame the LDS path holds
+constexpr int FM_CAP = 30000;                 // roots a workgroup's LDS path holds with 16-bit pixel keys beside the parents (twice as many without)
 constexpr int FM_WQ = 384;                    // joins a wave's queue holds (one round of boundary pixels adds at most 192)
 constexpr uint32_t NOJ = 0xFFFFFFFFu;         // "no join"
 
@@ -832,8 +832,8 @@ __device__ __forceinline__ void fm_union(uint16_t *p, const uint16_t *key, const
     for (;;) {
         a = fm_find(p, a); b = fm_find(p, b);
         if (a == b) break;
-        uint32_t pa = key[a], pb = key[b]; // both are roots right now; a root's pixel never changes
-        if (pa == pb) { pa = br[a].root; pb = br[b].root; }
+        uint32_t pa = key ? key[a] : 0u, pb = key ? key[b] : 0u; // both are roots right now; a root's pixel never changes
+        if (pa == pb) { pa = br[a].root; pb = br[b].root; }    // (no key array: every comparison reads the packed list, which this workgroup wrote: L2)
         const uint32_t hi = pa > pb ? a : b, lo = pa > pb ? b : a;
         if (fm_cas16(p, hi, hi, lo)) { a = lo; break; } // hooked while still a root: parent pixel < child pixel, so no cycle can form
     }
@@ -988,17 +988,25 @@ __global__ __launch_bounds__(FM_NT, 8) __attribute__((amdgpu_num_sgpr(80))) void
     }
     __syncthreads(); // the packed list was written by this workgroup: visible to it after the barrier
     if (stop_after == 0) return; // diagnostics (CK_FMERGE_STOP_AFTER)
-    if (n > (uint32_t)lds_cap || min_comp > 0x7FFF) {
-        uint32_t *sc = gscratch + (size_t)frame * 2 * slots + (f.mode == 0u ? slots - n : 0); // parents; the sizes `slots` further on
+    uint32_t *sc = gscratch + (size_t)frame * 2 * slots + (f.mode == 0u ? slots - n : 0); // global-memory path: parents; the sizes `slots` further on
+    // More roots than parents + keys fit: up to twice as many (and at most 65 535) still run their unions in LDS, on the parents
+    // alone — root pixels are then compared through the packed list and the sizes added up in global memory.
+    const bool keyless = n > (uint32_t)lds_cap;
+    if (n > 2u * (uint32_t)lds_cap || n > 0xFFFFu || min_comp > 0x7FFF) {
         fm_global_path(f, br, n, sc, sc + slots, groot, gsize, tiles);
         return;
     }
+    uint32_t *gsz = sc + slots;
     // while the unions run, the size array holds the roots' pixel keys: pixel index >> key_shift, 16 bits
     int key_shift = 0;
     while ((npix - 1) >> key_shift > 0xFFFFu) key_shift++;
-    for (uint32_t i = tid; i < n; i += FM_NT) { parent[i] = (uint16_t)i; size16[i] = (uint16_t)(br[i].root >> key_shift); }
+    for (uint32_t i = tid; i < n; i += FM_NT) {
+        parent[i] = (uint16_t)i; // (without keys the parents run on into the key array's bytes)
+        if (keyless) gsz[i] = 0; else size16[i] = (uint16_t)(br[i].root >> key_shift);
+    }
+    if (keyless) __threadfence();
     __syncthreads();
-    const uint16_t *key = size16;
+    const uint16_t *key = keyless ? nullptr : size16;
     // Every boundary pixel yields up to three joins; most lanes have fewer, and a join is a chain of dependent LDS reads.  So the
     // joins of a wave are queued in LDS (wave prefix sums) and then worked off one per lane, all lanes busy, instead of every
     // lane running its own zero to three joins while the others wait.
@@ -1040,15 +1048,17 @@ __global__ __launch_bounds__(FM_NT, 8) __attribute__((amdgpu_num_sgpr(80))) void
         uint32_t r = i;
         for (;;) { const uint32_t nx = parent[r]; if (nx == r) break; r = nx; }
         if (r != i) parent[i] = (uint16_t)r; // a non-root entry: rewriting it with its root keeps every other walk valid
-        size16[i] = 0;                       // the keys are dead: the array becomes the sizes
+        if (!keyless) size16[i] = 0;         // the keys are dead: the array becomes the sizes
     }
     __syncthreads();
     if (stop_after == 2) return;
     const uint32_t enough = (uint32_t)min_comp;
     for (uint32_t i = tid; i < n; i += FM_NT) {
         const uint32_t sz = br[i].size;
-        fm_size_add(size16, parent[i], sz > 0x7FFFu ? 0x7FFFu : sz, enough);
+        if (keyless) atomicAdd(&gsz[parent[i]], sz);
+        else fm_size_add(size16, parent[i], sz > 0x7FFFu ? 0x7FFFu : sz, enough);
     }
+    if (keyless) __threadfence();
     __syncthreads();
     if (stop_after == 3) return;
     // the tables, tile by tile
@@ -1058,7 +1068,7 @@ __global__ __launch_bounds__(FM_NT, 8) __attribute__((amdgpu_num_sgpr(80))) void
             const uint32_t r = parent[b0 + l];
             const size_t slot = (size_t)t * RING_CAP + f.id_of(t, l, cnt);
             groot[slot] = br[r].root;
-            gsize[slot] = size16[r];
+            gsize[slot] = keyless ? gm_load(gsz, r) : size16[r];
         }
     }
 }

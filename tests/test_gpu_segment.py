@@ -63,12 +63,15 @@ def test_threshold_segment_bit_exact(oracle, w, h, kind):
     det.close()
 
 
-@pytest.mark.parametrize("kind", ["noise", "blobs", "spiral", "checker1"])
-def test_merge_global_memory_path(oracle, kind, monkeypatch):
-    """A frame with more ring-touching roots than the merge kernel's LDS holds takes its global-memory path: forced here with a
-    tiny capacity (CK_FMERGE_CAP), on maps whose components span many tiles."""
+@pytest.mark.parametrize("kind,cap", [("noise", 64), ("blobs", 64), ("spiral", 64), ("checker1", 64),
+                                      ("noise", 1200), ("noise", 2000), ("noise", 3000), ("checker1", 2000), ("spiral", 300)])
+def test_merge_paths_beyond_one_workgroups_lds(oracle, kind, cap, monkeypatch):
+    """A frame with more ring-touching roots than one merge workgroup's LDS holds (parents + keys) is joined by two workgroups,
+    one per colour; a workgroup with still more roots keeps only the parents in LDS (up to twice the capacity), and beyond
+    that runs in global memory.  Forced here with small capacities (CK_FMERGE_CAP) on maps whose components span many tiles:
+    640x480 noise has about 3 400 roots per colour, so 64 means global memory, 2000 and 3000 parents-only, 1200 a mix."""
     from chalkydri_amd.detector import AprilTagDetector
-    monkeypatch.setenv("CK_FMERGE_CAP", "64")
+    monkeypatch.setenv("CK_FMERGE_CAP", str(cap))
     w, h, n = 640, 480, 2
     frames = _frames(kind, w, h, n, 5)
     det = AprilTagDetector(w, h, max_batch=n)
@@ -79,10 +82,11 @@ def test_merge_global_memory_path(oracle, kind, monkeypatch):
     det.close()
 
 
-def test_large_frames_use_the_tile_parallel_merge(oracle):
-    """Frames with more than 320 tiles (here 1920x1080: 510) keep k_merge + k_roots."""
+@pytest.mark.parametrize("w,h", [(1920, 1080), (2448, 2048)])
+def test_large_frames_merge_per_colour(oracle, w, h):
+    """Dense noise at 1920x1080 has about 45 000 ring-touching roots per frame: two workgroups, one per colour, each in LDS;
+    at 2448x2048 about 55 000 per colour: parents-only LDS."""
     from chalkydri_amd.detector import AprilTagDetector
-    w, h = 1920, 1080
     frames = _frames("noise", w, h, 1, 7)
     frames[0, 200:900, 300:1500] = _frames("blobs", 1200, 700, 1, 8)[0]
     det = AprilTagDetector(w, h, max_batch=1)
