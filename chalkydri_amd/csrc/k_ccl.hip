@@ -51,9 +51,9 @@ static_assert(TW == 128, "a node index splits with >> 7 / & 127");
 //   masks   u32[TH][NWD][2]  colour bits of every row word (0 white, 1 black)
 constexpr int OFF_PARENT = 0;                              // u16[TH*TW] = 8192
 constexpr int OFF_IMG = 0;                                 // IMG_ROWS*IMG_PITCH = 6400
-constexpr int OFF_MINMAX = OFF_IMG + IMG_ROWS * IMG_PITCH; // u16[T4Y*T4X] = 680 -> 704
-constexpr int OFF_THR = OFF_MINMAX + 704;                  // u16[(TH/4)*(TW/4)] = 512
+constexpr int OFF_MINMAX = OFF_IMG + IMG_ROWS * IMG_PITCH; // u32[T4Y*T4X] = 1360 (one dword per 4x4 tile: the dilation's neighbour reads stay 4-byte aligned)
 constexpr int OFF_LIST = TH * TW * 2;                      // u16[TH*TW] = 8192
+constexpr int OFF_THR = OFF_LIST;                          // u16[(TH/4)*(TW/4)] = 512 (the run list is not alive yet)
 constexpr int POOL_CAP = 640;                              // dense binary noise leaves about 340 links per tile for the pool
 constexpr int OFF_POOL = OFF_LIST + TH * TW * 2;           // u32[POOL_CAP] = 2560
 constexpr int OFF_MASK = OFF_POOL + POOL_CAP * 4;          // u32[TH][NWD][2] = 1024
@@ -61,8 +61,7 @@ constexpr int OFF_MISC = OFF_MASK + TH * NWD * 2 * 4;      // u32[16]
 constexpr int LDS_BYTES = OFF_MISC + 64;
 constexpr int RING_CAP = CK_RING_CAP;                      // ring-touching roots of a tile: at most one per ring pixel
 constexpr uint32_t CK_ROOT = 0x8000u, CK_RING = 0x4000u, CK_CLAIM = 0x2000u, CK_COUNT = 0x1FFFu;
-static_assert(T4Y * T4X * 2 <= 704, "min/max scratch size");
-static_assert(OFF_THR + (TH / 4) * (TW / 4) * 2 <= OFF_LIST, "threshold scratch must fit in the parent array");
+static_assert(OFF_MINMAX + T4Y * T4X * 4 <= OFF_LIST, "min/max scratch must fit in the parent array");
 static_assert(LDS_BYTES <= 20480, "keep eight workgroups per CU");
 static_assert(TH * TW <= CK_COUNT, "a component's pixel count fits below the flags of a root entry");
 
@@ -235,7 +234,7 @@ __global__ __launch_bounds__(KNT) void k_tile(const uint8_t *__restrict__ frames
 
     if (stop_after == 0) return; // diagnostics (CK_TILE_STOP_AFTER)
     // ---- P1: min/max of the 4x4 tiles: grid column j = 4x4 column c4x - 1 + j, row i = 4x4 row c4y - 1 + i ----------
-    uint16_t *minmax = reinterpret_cast<uint16_t *>(lds + OFF_MINMAX);
+    uint32_t *minmax = reinterpret_cast<uint32_t *>(lds + OFF_MINMAX);
     if (!PRE)
     for (int item = tid; item < T4Y * T4X; item += KNT) {
         const int i = item / T4X, j = item - i * T4X;
@@ -252,7 +251,7 @@ __global__ __launch_bounds__(KNT) void k_tile(const uint8_t *__restrict__ frames
                 }
             }
         }
-        minmax[item] = (uint16_t)(mn | (mx << 8)); // outside the frame: (255,0) is neutral for the dilation
+        minmax[item] = mn | (mx << 8); // outside the frame: (255,0) is neutral for the dilation
     }
     __syncthreads();
 
