@@ -880,7 +880,7 @@ __device__ __forceinline__ void gm_union(uint32_t *p, const ck_border_root *__re
         if (atomicCAS(&p[hi], hi, lo) == hi) return;
     }
 }
-__device__ void fm_global_path(const FmFrame &f, const ck_border_root *__restrict__ br, uint32_t n, uint32_t *gparent, uint32_t *gsz,
+__device__ __forceinline__ void fm_global_path(const FmFrame &f, const ck_border_root *__restrict__ br, uint32_t n, uint32_t *gparent, uint32_t *gsz,
                                uint32_t *groot, uint32_t *gsize, int tiles) {
     const int tid = threadIdx.x;
     for (uint32_t i = tid; i < n; i += FM_NT) { gparent[i] = i; gsz[i] = 0; }
