@@ -293,7 +293,7 @@ __global__ __launch_bounds__(KNT) void k_tile(const uint8_t *__restrict__ frames
             uint32_t o, wn, bn; // the four output bytes and the white / black bits of the group
             if (gy >= h || x >= w) { o = 0x7F7F7F7Fu; wn = 0; bn = 0; }     // outside the frame: no colour
             else {
-                if (PRE) o = in[k];
+                if (PRE) { o = in[k]; wn = msb_nibble(o); bn = msb_nibble(~(o << 7)); } // 255 -> bit 7 set; 0 -> bit 0 clear (127 and 255 have it set)
                 else {
                     // four byte compares "pixel > threshold" as two packed 16-bit saturating subtractions (even and odd bytes)
                     const uint32_t t2 = (tw_ & 0xFFu) * 0x00010001u;
@@ -301,14 +301,20 @@ __global__ __launch_bounds__(KNT) void k_tile(const uint8_t *__restrict__ frames
                     const u16x2 dq = __builtin_elementwise_sub_sat(as_u16x2((in[k] >> 8) & 0x00FF00FFu), as_u16x2(t2));
                     const u16x2 one = {1, 1};
                     const uint32_t me = as_u32(__builtin_elementwise_min(de, one)), mo = as_u32(__builtin_elementwise_min(dq, one)); // 0 / 1 per pixel
-                    o = (tw_ & 0x100u) ? 0x7F7F7F7Fu : ((me * 0xFFu) | ((mo * 0xFFu) << 8));
+                    const bool lowc = (tw_ & 0x100u) != 0;
+                    o = lowc ? 0x7F7F7F7Fu : ((me * 0xFFu) | ((mo * 0xFFu) << 8));
+                    // the white bits straight from the compare results (pixels 0, 1 in bits 0, 1; pixels 2, 3 in bits 16, 17); a pixel of
+                    // a tile with contrast is black when it is not white
+                    const uint32_t pm = me | (mo << 1);
+                    const uint32_t t = (pm | (pm >> 14)) & 15u;
+                    wn = lowc ? 0u : t; bn = lowc ? 0u : (t ^ 15u);
                 }
-                if (x + 4 > w) { // the frame ends inside this group (width not a multiple of 4)
-                    const uint32_t keep = 0xFFFFFFFFu >> (8 * (x + 4 - w));
-                    o = (o & keep) | (0x7F7F7F7Fu & ~keep);
-                }
-                wn = msb_nibble(o);                     // 255 -> bit 7 set
-                bn = msb_nibble(~(o << 7));             // 0 -> bit 0 clear (127 and 255 have it set)
+                if (__builtin_amdgcn_ballot_w64(x + 4 > w)) // (scalar branch: only the wave at the frame's right edge, and only when
+                    if (x + 4 > w) {                         // the width is not a multiple of 4: the frame ends inside this group)
+                        const uint32_t keep = 0xFFFFFFFFu >> (8 * (x + 4 - w));
+                        o = (o & keep) | (0x7F7F7F7Fu & ~keep);
+                        wn = msb_nibble(o); bn = msb_nibble(~(o << 7));
+                    }
             }
             out[k] = o;
             wbits |= wn << (4 * k);
@@ -584,6 +590,7 @@ __global__ __launch_bounds__(KNT) void k_tile(const uint8_t *__restrict__ frames
         const uint32_t below = (1u << sh) - 1u;
         const uint32_t gbase = (uint32_t)ty0 * (uint32_t)w + (uint32_t)tx0;
         const uint32_t slot0 = CK_LBL_BORDER | ((uint32_t)tile * RING_CAP);
+        const uint32_t w24 = (uint32_t)w & 0xFFFFFFu; // (the compiler then sees two 24-bit factors: a full-rate multiply instead of a 64-bit one)
         if (gx < w)
 #pragma unroll
         for (int q = 0; q < 4; q++) {
@@ -624,7 +631,7 @@ __global__ __launch_bounds__(KNT) void k_tile(const uint8_t *__restrict__ frames
                         const uint32_t c = is_root ? ev[k] : rv[k];           // its entry
                         // interior component: the root's pixel index, final; ring-touching: the component's slot in the frame's tables
                         const uint32_t word = (c & CK_RING) ? slot0 + (c & 0x1FFu)
-                                                            : ((gbase + (node >> 7) * (uint32_t)w + (node & (TW - 1))) | ((int)(c & CK_COUNT) < min_comp ? CK_LBL_SMALL : 0u));
+                                                            : ((gbase + ((node >> 7) & (uint32_t)(TH - 1)) * w24 + (node & (TW - 1))) | ((int)(c & CK_COUNT) < min_comp ? CK_LBL_SMALL : 0u));
                         outw[k] = ((any4 >> k) & 1u) ? word : CK_LBL_INVALID;
                     }
                 }
