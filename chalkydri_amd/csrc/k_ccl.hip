@@ -637,8 +637,13 @@ __global__ __launch_bounds__(KNT) void k_tile(const uint8_t *__restrict__ frames
                 }
             }
             uint32_t *dst = labels + fbase + (size_t)gy * w + gx;
-            if (packed_rows) *reinterpret_cast<uint4 *>(dst) = make_uint4(outw[0], outw[1], outw[2], outw[3]);
-            else {
+            if (packed_rows) {
+                // (the empty asm keeps the compiler from merging this store with the per-pixel ones of the other branch: merged, it
+                // became a 12-byte store plus a 4-byte one)
+                __asm__ volatile("" ::: "memory");
+                *reinterpret_cast<uint4 *>(dst) = make_uint4(outw[0], outw[1], outw[2], outw[3]);
+                __asm__ volatile("" ::: "memory");
+            } else {
 #pragma unroll
                 for (int k = 0; k < 4; k++)
                     if (gx + k < w) dst[k] = outw[k];
