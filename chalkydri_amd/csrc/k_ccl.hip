@@ -113,6 +113,14 @@ __device__ __forceinline__ void lds_union(uint16_t *p, uint32_t a, uint32_t b) {
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ u16x2 as_u16x2(uint32_t v) { return __builtin_bit_cast(u16x2, v); }
 __device__ __forceinline__ uint32_t as_u32(u16x2 v) { return __builtin_bit_cast(uint32_t, v); }
+// per 16-bit half: a > t ? 1 : 0, as a saturating packed subtraction and a packed minimum (written as instructions: from the
+// element-wise builtins the compiler makes four 16-bit compares, selects and a byte permute)
+__device__ __forceinline__ uint32_t pk_gt_u16(uint32_t a, uint32_t t, uint32_t ones) {
+    uint32_t d, r;
+    __asm__("v_pk_sub_u16 %0, %1, %2 clamp" : "=v"(d) : "v"(a), "v"(t));
+    __asm__("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(d), "v"(ones));
+    return r;
+}
 // gathers bit 7 of each byte of v into a nibble (bit k = byte k)
 __device__ __forceinline__ uint32_t msb_nibble(uint32_t v) {
     return (((v >> 7) & 0x01010101u) * 0x01020408u) >> 24 & 0xFu;
@@ -297,12 +305,10 @@ __global__ __launch_bounds__(KNT) void k_tile(const uint8_t *__restrict__ frames
                 else {
                     // four byte compares "pixel > threshold" as two packed 16-bit saturating subtractions (even and odd bytes)
                     const uint32_t t2 = (tw_ & 0xFFu) * 0x00010001u;
-                    const u16x2 de = __builtin_elementwise_sub_sat(as_u16x2(in[k] & 0x00FF00FFu), as_u16x2(t2));
-                    const u16x2 dq = __builtin_elementwise_sub_sat(as_u16x2((in[k] >> 8) & 0x00FF00FFu), as_u16x2(t2));
-                    const u16x2 one = {1, 1};
-                    const uint32_t me = as_u32(__builtin_elementwise_min(de, one)), mo = as_u32(__builtin_elementwise_min(dq, one)); // 0 / 1 per pixel
+                    const uint32_t me = pk_gt_u16(in[k] & 0x00FF00FFu, t2, 0x00010001u), mo = pk_gt_u16((in[k] >> 8) & 0x00FF00FFu, t2, 0x00010001u); // 0 / 1 per pixel
                     const bool lowc = (tw_ & 0x100u) != 0;
-                    o = lowc ? 0x7F7F7F7Fu : ((me * 0xFFu) | ((mo * 0xFFu) << 8));
+                    const uint32_t b01 = me | (mo << 8);                 // one bit per pixel at the bottom of its byte ...
+                    o = lowc ? 0x7F7F7F7Fu : (b01 << 8) - b01;           // ... times 255 (no byte carries into the next)
                     // the white bits straight from the compare results (pixels 0, 1 in bits 0, 1; pixels 2, 3 in bits 16, 17); a pixel of
                     // a tile with contrast is black when it is not white
                     const uint32_t pm = me | (mo << 1);
