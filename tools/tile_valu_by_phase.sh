@@ -5,7 +5,7 @@ cd /tmp && export TMPDIR=/tmp
 root=$GRAFT_REPO_ROOT
 kind=${1:-synth}
 pmc=${PMC:-SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY}
-for s in 0 1 2 4 5 6 7 99; do
+for s in ${STOPS:-0 1 2 4 5 6 65 7 99}; do
   out=$root/gpurun_out/valu_$s
   rm -rf $out
   CK_TILE_STOP_AFTER=$s timeout -k 10 200 rocprofv3 --pmc $pmc --output-format csv -d $out -- python3 $root/tools/bench_thrseg.py 1280 800 256 $kind > /dev/null 2>&1
