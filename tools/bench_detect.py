@@ -2,6 +2,9 @@
 import sys, os, time, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
+from chalkydri_amd import _lib
+if os.environ.get("LIB"):   # A/B against another build of the library in the same gpurun call
+    _lib.LIB_PATH = os.environ["LIB"]
 from chalkydri_amd import synth
 from chalkydri_amd.detector import AprilTagDetector
 
