@@ -829,33 +829,15 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(WPS, 8))) v
                 sErr[j] = e;
             }
             __syncthreads();
-            // smoothing, then maxima: every point of the chunk and its two neighbours gets its smoothed error ONCE (seven products
-            // and sums in the oracle's order, so the same bits), in registers; after a barrier the smoothed values replace the
-            // raw ones in sErr and the maxima test reads three of them.  (Fused, every point smoothed itself and both neighbours:
-            // three times the f64 work.)
-            {
-                constexpr int SPT = (CH + 2 + NTH - 1) / NTH;
-                double sv[SPT];
-#pragma unroll
-                for (int t = 0; t < SPT; t++) {
-                    const int j = HALO - 1 + tid + t * NTH;
-                    double sm = 0.0;
-                    if (j <= HALO + chn) {
-#pragma unroll
-                        for (int q = 0; q < 7; q++) sm += sErr[j + q - 3] * k_smooth[q];
-                    }
-                    sv[t] = sm;
-                }
-                __syncthreads();
-#pragma unroll
-                for (int t = 0; t < SPT; t++) {
-                    const int j = HALO - 1 + tid + t * NTH;
-                    if (j <= HALO + chn) sErr[j] = sv[t];
-                }
-                __syncthreads();
-            }
+            // smoothing and maxima in one pass: each point smooths itself and its two neighbours from nine errors (same
+            // operation order as the oracle's one-value-at-a-time loop, so the same bits)
             for (int j = HALO + tid; j < HALO + chn; j += NTH) {
-                const double sp = sErr[j - 1], s = sErr[j], sn = sErr[j + 1];
+                double e9[9];
+#pragma unroll
+                for (int q = 0; q < 9; q++) e9[q] = sErr[j + q - 4];
+                double sp = 0.0, s = 0.0, sn = 0.0;
+#pragma unroll
+                for (int q = 0; q < 7; q++) { sp += e9[q] * k_smooth[q]; s += e9[q + 1] * k_smooth[q]; sn += e9[q + 2] * k_smooth[q]; }
                 if (s > sn && s > sp) {
                     int pos = atomicAdd(&sNmax, 1); // pos < sz/2
                     if (MLDS) { sMaxVal[pos] = s; sMaxIdx[pos] = (uint16_t)(cbase + j - HALO); }
