@@ -213,8 +213,8 @@ __global__ __launch_bounds__(KNT) void k_tile(const uint8_t *__restrict__ frames
     uint32_t *parent32 = reinterpret_cast<uint32_t *>(lds + OFF_PARENT);
     uint16_t *list = reinterpret_cast<uint16_t *>(lds + OFF_LIST);
     uint32_t *mk = reinterpret_cast<uint32_t *>(lds + OFF_MASK);
-    uint32_t *misc = reinterpret_cast<uint32_t *>(lds + OFF_MISC); // [0..3] wave run counts, [5] pooled links, [6] / [7] white / black ring-touching roots
-    if (tid == 0) { misc[6] = 0; misc[7] = 0; } // (the barrier after P0 publishes them)
+    uint32_t *misc = reinterpret_cast<uint32_t *>(lds + OFF_MISC); // [0..3] wave run counts, [5] pooled links, [6] / [7] white / black ring-touching roots, [8] some 4x4 tile has contrast, [9] some pixel has a colour
+    if (tid == 0) { misc[6] = 0; misc[7] = 0; misc[8] = 0; misc[9] = 0; } // (the barrier after P0 publishes them)
 
     // Whole 4x4 tiles only enter the min/max (the oracle's rule); pixels right of / below the last whole one take its
     // threshold.  Normally the threshold grid of a workgroup tile starts at its own first 4x4 column / row (c4x, c4y); when the
@@ -265,6 +265,7 @@ __global__ __launch_bounds__(KNT) void k_tile(const uint8_t *__restrict__ frames
 
     // ---- P2: 3x3 dilation -> per-4x4-tile threshold word (bit 8 = low contrast); column j = 4x4 column c4x + j -------
     uint16_t *thr = reinterpret_cast<uint16_t *>(lds + OFF_THR);
+    int my_contrast = 0;
     if (!PRE)
     for (int item = tid; item < (TH / 4) * (TW / 4); item += KNT) {
         const int i = item / (TW / 4), j = item - i * (TW / 4);
@@ -278,16 +279,38 @@ __global__ __launch_bounds__(KNT) void k_tile(const uint8_t *__restrict__ frames
             }
         int diff = (int)mx - (int)mn;
         thr[item] = (uint16_t)((diff < min_diff) ? 0x100u : (mn + (uint32_t)(diff >> 1)));
+        my_contrast |= diff >= min_diff ? 1 : 0;
     }
+    // a tile none of whose 4x4 tiles has contrast (a smooth background) thresholds to 127 everywhere: the threshold pass below
+    // then only stores constants (every threshold word a pixel of this tile can look up is one of the 256 just written)
+    // (a flag word set by one lane per wave before the barrier: __syncthreads_or costs two more barriers)
+    if (__builtin_amdgcn_ballot_w64(my_contrast != 0) && (tid & 63) == 0) misc[8] = 1;
     __syncthreads();
+    const int tile_contrast = PRE ? 1 : (int)misc[8];
     TPROF(1);
 
     if (stop_after == 1) return; // diagnostics (CK_TILE_STOP_AFTER)
     // ---- P3: threshold 16 pixels per thread, write them, build the rows' colour words -------------------------------
     uint16_t *mask16 = reinterpret_cast<uint16_t *>(lds + OFF_MASK); // [r][word][colour][half]
     const bool packed_rows = (w & 3) == 0; // rows of thresh[] / labels[] start 4-pixel aligned: vector stores
+    // the lane's 16 threshold bytes to global memory
+    auto store_thresh = [&](int gy, int gx, const uint32_t (&out)[4]) {
+        if (gy < h && gx < w) {
+            uint8_t *dst = thresh + fbase + (size_t)gy * w + gx;
+            if (packed_rows && gx + 16 <= w && (w & 15) == 0) *reinterpret_cast<uint4 *>(dst) = make_uint4(out[0], out[1], out[2], out[3]);
+            else if (packed_rows) {
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                    if (gx + 4 * k < w) *reinterpret_cast<uint32_t *>(dst + 4 * k) = out[k];
+            } else {
+                for (int k = 0; k < 16; k++)
+                    if (gx + k < w) dst[k] = (uint8_t)(out[k >> 2] >> (8 * (k & 3)));
+            }
+        }
+    };
     uint32_t any_colour = 0;
-    {
+    int tile_has_runs = 0;
+    if (tile_contrast) {
         const int r = tid >> 3, c = tid & 7;
         const int gy = ty0 + r, gx = tx0 + 16 * c;
         uint4 px = *reinterpret_cast<const uint4 *>(lds + OFF_IMG + (r + yoff) * IMG_PITCH + 16 + 16 * c);
@@ -326,25 +349,19 @@ __global__ __launch_bounds__(KNT) void k_tile(const uint8_t *__restrict__ frames
             wbits |= wn << (4 * k);
             bbits |= bn << (4 * k);
         }
-        if (gy < h && gx < w) {
-            uint8_t *dst = thresh + fbase + (size_t)gy * w + gx;
-            if (packed_rows && gx + 16 <= w && (w & 15) == 0) *reinterpret_cast<uint4 *>(dst) = make_uint4(out[0], out[1], out[2], out[3]);
-            else if (packed_rows) {
-#pragma unroll
-                for (int k = 0; k < 4; k++)
-                    if (gx + 4 * k < w) *reinterpret_cast<uint32_t *>(dst + 4 * k) = out[k];
-            } else {
-                for (int k = 0; k < 16; k++)
-                    if (gx + k < w) dst[k] = (uint8_t)(out[k >> 2] >> (8 * (k & 3)));
-            }
-        }
+        store_thresh(gy, gx, out);
         const int wd = c >> 1, half = c & 1;
         mask16[(((r * NWD + wd) * 2 + 0) << 1) + half] = (uint16_t)wbits;
         mask16[(((r * NWD + wd) * 2 + 1) << 1) + half] = (uint16_t)bbits;
         any_colour = wbits | bbits;
+        // a tile without a coloured pixel has nothing to segment
+        if (__builtin_amdgcn_ballot_w64(any_colour != 0) && (tid & 63) == 0) misc[9] = 1;
+        __syncthreads();
+        tile_has_runs = (int)misc[9];
+    } else {
+        const uint32_t out[4] = {0x7F7F7F7Fu, 0x7F7F7F7Fu, 0x7F7F7F7Fu, 0x7F7F7F7Fu};
+        store_thresh(ty0 + (tid >> 3), tx0 + 16 * (tid & 7), out);
     }
-    // a tile without a coloured pixel (a background below min_white_black_diff) has nothing to segment
-    const int tile_has_runs = __syncthreads_or((int)any_colour);
     TPROF(2);
 
     if (stop_after == 2) return; // diagnostics (CK_TILE_STOP_AFTER)
