@@ -1046,12 +1046,6 @@ __global__ __launch_bounds__(FM_NT, 8) __attribute__((amdgpu_num_sgpr(80))) void
     // Every boundary pixel yields up to three joins; most lanes have fewer, and a join is a chain of dependent LDS reads.  So the
     // joins of a wave are queued in LDS (wave prefix sums) and then worked off one per lane, all lanes busy, instead of every
     // lane running its own zero to three joins while the others wait.
-    if (stop_after == 10) { // diagnostics: the boundary sweep alone (loads and join numbers, no unions)
-        uint32_t acc = 0;
-        fm_boundaries(f, tid, [&](uint32_t a0, uint32_t b0, uint32_t a1, uint32_t b1, uint32_t a2, uint32_t b2) { acc += a0 ^ b0 ^ a1 ^ b1 ^ a2 ^ b2; });
-        if (acc == 0x12345u) groot[0] = acc;
-        return;
-    }
     uint32_t *wq = queue + (tid >> 6) * FM_WQ;
     const int lane = tid & 63;
     uint32_t qn = 0; // joins waiting in the wave's queue (wave-uniform)
