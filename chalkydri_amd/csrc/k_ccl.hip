@@ -838,14 +838,18 @@ __device__ __forceinline__ void fm_boundaries(const FmFrame &f, int tid, Emit &&
     }
 }
 
-__device__ __forceinline__ uint32_t fm_find(uint16_t *p, uint32_t a) { // path halving, same argument as lds_find2
+// two halving finds walked in lockstep (as lds_find2 of k_tile: both chains have a read in flight at every step, and one loop's
+// worth of exec-mask bookkeeping instead of two); a root points at itself
+__device__ __forceinline__ void fm_find2(uint16_t *p, uint32_t &a, uint32_t &b) {
     for (;;) {
-        const uint32_t n = p[a];
-        if (n == a) return a;
-        const uint32_t g = p[n];
-        if (g == n) return n;
-        p[a] = (uint16_t)g;
-        a = g;
+        __asm__ volatile("" ::: "memory");
+        const uint32_t na = p[a], nb = p[b];
+        const bool da = na == a, db = nb == b;
+        if (da && db) return;
+        __asm__ volatile("" ::: "memory");
+        const uint32_t ga = p[na], gb = p[nb]; // (a root's parent is itself: the read is harmless)
+        if (!da) { if (ga != na) { p[a] = (uint16_t)ga; a = ga; } else a = na; }
+        if (!db) { if (gb != nb) { p[b] = (uint16_t)gb; b = gb; } else b = nb; }
     }
 }
 // swaps parent[idx] from `expect` to `val` (u16 entry inside a 32-bit word); false when the entry no longer holds `expect`
@@ -866,7 +870,7 @@ __device__ __forceinline__ bool fm_cas16(uint16_t *p, uint32_t idx, uint32_t exp
 __device__ __forceinline__ void fm_union(uint16_t *p, const uint16_t *key, const ck_border_root *__restrict__ br, uint32_t a0, uint32_t b0) {
     uint32_t a = a0, b = b0;
     for (;;) {
-        a = fm_find(p, a); b = fm_find(p, b);
+        fm_find2(p, a, b);
         if (a == b) break;
         uint32_t pa = key ? key[a] : 0u, pb = key ? key[b] : 0u; // both are roots right now; a root's pixel never changes
         if (pa == pb) { pa = br[a].root; pb = br[b].root; }    // (no key array: every comparison reads the packed list, which this workgroup wrote: L2)
