@@ -147,6 +147,7 @@ struct ck_handle {
     ck_stage_ms_t last_ms;
     ck_dev_family *d_fams;
     int n_staged;        // frames currently staged in d_frames
+    bool fmerge_lds_allowed; // k_fmerge's dynamic LDS limit has been raised on this handle's device
 };
 
 extern thread_local char ck_err_text[512];

@@ -1172,10 +1172,9 @@ int ck_launch_threshold_segment(ck_handle *h, const uint8_t *frames, int stride,
         if (cap_env && atoi(cap_env) < cap) cap = atoi(cap_env);
         cap = (cap + 1) & ~1;
         const size_t lds = (size_t)cap * 4 + (size_t)((tiles + 1 + 3) & ~3) * 4 + (size_t)(FM_NT / 64) * FM_WQ * 4 + (size_t)((tiles + 7) & ~7) * 2 * 3;
-        static bool attr_set = false;
-        if (!attr_set) {
+        if (!h->fmerge_lds_allowed) { // per handle, i.e. per device: a process may hold handles on several GPUs
             CK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_fmerge), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
-            attr_set = true;
+            h->fmerge_lds_allowed = true;
         }
         hipLaunchKernelGGL(k_fmerge, dim3((unsigned)(((n + 7) / 8) * 16)), dim3(FM_NT), lds, h->stream, h->d_broots, h->d_tile_count, h->d_ring, h->ring_len,
                            h->d_groot, h->d_gsize, h->d_gscratch, h->npix, h->qw, h->qh, h->tiles_x, h->tiles_y, n, h->cfg.min_component_px, cap,
