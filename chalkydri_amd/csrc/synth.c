@@ -184,6 +184,7 @@ int ck_synth_render(uint64_t seed, const ck_synth_params_t *p, const ck_family_t
     double f = (double)w, cx0 = (double)w * 0.5, cy0 = (double)h * 0.5;
     int max_side = p->max_side;
     if (max_side > h / 2) max_side = h / 2;
+    if (max_side < p->min_side) max_side = p->min_side; // a frame too low for min_side: the placement loop finds no room and draws no tag
     ck_synth_tag_t *tags = (ck_synth_tag_t *)calloc((size_t)(p->n_tags > 0 ? p->n_tags : 1), sizeof *tags);
     double *rad = (double *)calloc((size_t)(p->n_tags > 0 ? p->n_tags : 1), sizeof *rad);
     if (!tags || !rad) { free(tags); free(rad); return -2; }

@@ -26,6 +26,9 @@ for c in range(cases):
     frames[:, y0:y0 + h // 2, x0:x0 + w // 2] = fb[:, y0:y0 + h // 2, x0:x0 + w // 2]   # two kinds of content side by side
     cap = int(rng.choice([16, 64, 300, 1200, 100000]))
     os.environ["CK_FMERGE_CAP"] = str(cap)
+    if os.environ.get("STRESS_LOG"):
+        with open(os.environ["STRESS_LOG"], "a") as lf:
+            lf.write(json.dumps({"case": c, "w": w, "h": h, "n": n, "kinds": [str(ka), str(kb)], "cap": cap, "x0": x0, "y0": y0}) + "\n")
     det = AprilTagDetector(w, h, max_batch=n)
     th = det.threshold(frames)
     labels, sizes = det.segment(frames)
