@@ -1133,14 +1133,15 @@ __global__ __launch_bounds__(NT) void k_sizes(const uint32_t *__restrict__ canon
     sizes[i] = (g == CK_LBL_INVALID) ? 0u : cnt[(i / npix) * npix + g];
 }
 
+// rows of the decimated copy are padded to 16 bytes like every staged frame (k_tile reads 16-byte chunks): qstride >= qw
 __global__ __launch_bounds__(NT) void k_decimate(const uint8_t *__restrict__ src, size_t frame_pitch, int stride, int f, int qw, int qh,
-                                                 uint8_t *__restrict__ dst, size_t total) {
+                                                 int qstride, uint8_t *__restrict__ dst, size_t total) {
     size_t i = (size_t)blockIdx.x * NT + threadIdx.x;
     if (i >= total) return;
     size_t npix = (size_t)qw * qh;
     size_t fr = i / npix, rem = i - fr * npix;
     int y = (int)(rem / qw), x = (int)(rem - (size_t)y * qw);
-    dst[i] = src[fr * frame_pitch + (size_t)(y * f) * stride + (size_t)x * f];
+    dst[fr * (size_t)qstride * qh + (size_t)y * qstride + x] = src[fr * frame_pitch + (size_t)(y * f) * stride + (size_t)x * f];
 }
 
 } // namespace
@@ -1206,7 +1207,7 @@ int ck_launch_decimate(ck_handle *h, const uint8_t *frames, int stride, size_t f
     size_t total = h->npix * (size_t)n;
     unsigned blocks = (unsigned)((total + NT - 1) / NT);
     hipLaunchKernelGGL(k_decimate, dim3(blocks), dim3(NT), 0, h->stream, frames, frame_pitch, stride, h->cfg.quad_decimate, h->qw,
-                       h->qh, h->d_qframes, total);
+                       h->qh, (h->qw + 15) / 16 * 16, h->d_qframes, total);
     CK_HIP(hipGetLastError());
     return CK_OK;
 }
