@@ -31,7 +31,7 @@ for c in range(cases):
             lf.write(json.dumps({"case": c, "w": w, "h": h, "n": n, "tags": n_tags, "fams": fams, "dec": dec, "kw": kw, "settings": settings}) + "\n")
     frames, _ = synth.render_batch(40 + c, n, w, h, n_tags, fams, **kw)
     det = AprilTagDetector(w, h, max_batch=n, families=fams, quad_decimate=dec, **settings)
-    got, status = det.detect_batch(frames, cap=64, return_status=True)
+    got, status = det.detect_batch(frames, cap=256, return_status=True)   # the handle keeps at most 256 detections per frame (oracle: the same)
     cfg = default_config(w, h, families=fams, quad_decimate=dec, **settings)
     for i in range(n):
         want, st = pyoracle.detect(frames[i], cfg)
