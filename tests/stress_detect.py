@@ -1,0 +1,52 @@
+"""Randomised parity stress of the whole detector against the CPU oracle (test infrastructure: imports oracle/): random
+geometries, tag counts, noise levels, decimation, families and detector settings; detections must agree bit for bit (id,
+hamming, margin, centre, corners) and so must the status word.  usage: python tests/stress_detect.py [cases] [seed]"""
+import os, sys, json
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import numpy as np
+import pyoracle
+from chalkydri_amd import default_config, synth
+from chalkydri_amd.detector import AprilTagDetector
+
+def run(cases, seed):
+    rng = np.random.default_rng(seed)
+    bad = 0
+    for c in range(cases):
+        dec = int(rng.choice([1, 1, 2]))
+        w = int(rng.integers(120, 900)); h = int(rng.integers(100, 700))
+        w -= w % (4 * dec); h -= h % dec
+        n = int(rng.integers(1, 4))
+        n_tags = int(rng.integers(0, 7))
+        fams = ("tag36h11",) if rng.random() < 0.7 else ("tag16h5", "tag36h11")
+        kw = {"noise_amp": int(rng.choice([0, 1, 3, 6]))}
+        if min(w, h) < 300:
+            kw.update(min_side=24, max_side=max(24, min(w, h) // 3))
+        settings = {}
+        if rng.random() < 0.3: settings["refine_edges"] = 0
+        if rng.random() < 0.3: settings["max_nmaxima"] = int(rng.integers(4, 13))
+        if rng.random() < 0.3: settings["min_component_px"] = int(rng.choice([5, 25, 60, 200]))
+        if os.environ.get("STRESS_LOG"):
+            with open(os.environ["STRESS_LOG"], "a") as lf:
+                lf.write(json.dumps({"case": c, "w": w, "h": h, "n": n, "tags": n_tags, "fams": fams, "dec": dec, "kw": kw, "settings": settings}) + "\n")
+        frames, _ = synth.render_batch(40 + c, n, w, h, n_tags, fams, **kw)
+        det = AprilTagDetector(w, h, max_batch=n, families=fams, quad_decimate=dec, **settings)
+        got, status = det.detect_batch(frames, cap=256, return_status=True)   # the handle keeps at most 256 detections per frame (oracle: the same)
+        cfg = default_config(w, h, families=fams, quad_decimate=dec, **settings)
+        for i in range(n):
+            want, st = pyoracle.detect(frames[i], cfg)
+            ok = status[i] == st and len(got[i]) == len(want)
+            if ok:
+                for a, b in zip(got[i], want):
+                    ok = ok and (a.id(), a.hamming(), a.family()) == (b["id"], b["hamming"], b["family"]) and \
+                        np.float32(a.decision_margin()) == np.float32(b["margin"]) and np.array_equal(a.center(), b["c"]) and np.array_equal(a.corners(), b["p"])
+            if not ok:
+                bad += 1
+                print(json.dumps({"case": c, "frame": i, "w": w, "h": h, "dec": dec, "got": len(got[i]), "want": len(want), "status": [int(status[i]), int(st)]}))
+        det.close()
+    print(json.dumps({"cases": cases, "mismatching_frames": bad}))
+    return bad
+
+
+if __name__ == "__main__":
+    sys.exit(1 if run(int(sys.argv[1]) if len(sys.argv) > 1 else 60, int(sys.argv[2]) if len(sys.argv) > 2 else 1) else 0)

@@ -1,0 +1,27 @@
+"""Randomised parity stress, a small helping of it in the GPU suite (the scripts beside this file run thousands of cases:
+`python tests/stress_detect.py 1500 23`).  Every case draws its own geometry, content and settings; the device path must agree
+with the CPU oracle bit for bit (poses: within the stated tolerance).  These runs found the padded-row bug of the decimated
+copy (widths whose half is not a multiple of 16) that the fixed-size tests had missed."""
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_stress_segment(oracle):
+    import stress_segment
+    assert stress_segment.run(60, 101) == 0
+
+
+def test_stress_detect(oracle):
+    import stress_detect
+    assert stress_detect.run(40, 102) == 0
+
+
+def test_stress_pose(oracle):
+    import stress_pose
+    assert stress_pose.run(25, 103) == 0
+
+
+def test_stress_cat(oracle):
+    import stress_cat
+    assert stress_cat.run(40, 104) == 0
