@@ -14,7 +14,8 @@ def run(cases, seed):
     bad = 0
     for c in range(cases):
         dec = int(rng.choice([1, 1, 2]))
-        w = int(rng.integers(120, 900)); h = int(rng.integers(100, 700))
+        scale = int(os.environ.get("STRESS_SCALE", "1"))   # 3: frames up to 2700 x 2100 (the largest fit class, two-colour merges)
+        w = int(rng.integers(120, 900)) * scale; h = int(rng.integers(100, 700)) * scale
         w -= w % (4 * dec); h -= h % dec
         n = int(rng.integers(1, 4))
         n_tags = int(rng.integers(0, 7))
@@ -36,7 +37,8 @@ def run(cases, seed):
         for i in range(n):
             want, st = pyoracle.detect(frames[i], cfg)
             ok = status[i] == st and len(got[i]) == len(want)
-            if ok:
+            if ok and not (st & 15):   # with an overflow bit set, WHICH quads / detections were kept is not defined: only the flags and counts are
+
                 for a, b in zip(got[i], want):
                     ok = ok and (a.id(), a.hamming(), a.family()) == (b["id"], b["hamming"], b["family"]) and \
                         np.float32(a.decision_margin()) == np.float32(b["margin"]) and np.array_equal(a.center(), b["c"]) and np.array_equal(a.corners(), b["p"])
