@@ -9,15 +9,18 @@
 // Structure (one launch each, batched over frames):
 //   k_tile   one workgroup (256 threads) per 32x128 tile.  Coalesced 16-byte loads of the tile + halo into LDS, 4x4
 //            min/max, 3x3 dilation, tri-state threshold (written once, 16 B/lane) and the rows' colour bits as 32-pixel
-//            words.  The union-find works on RUNS, one lane per run from a compacted list (wave prefix sums), so every
-//            phase is straight-line code with balanced lanes: (a) adoption — a run takes ONE earlier run as parent with a
-//            plain store; (b) one pointer-jumping sweep over the static adoption forest; (c) the remaining links, pooled
-//            in LDS, one lane per link, through an atomic-min union; (d) flatten + exact sizes (ds_add on u16 halves);
-//            (e) label words written once (64 B/lane), ring-touching roots appended per wave.  25.7 KB of LDS: six
-//            workgroups per CU.  HBM traffic 1.4 R + 1 W + 4 W bytes per pixel.
-//   k_fmerge one workgroup per frame: the ring-touching roots of the frame's tiles are joined across the tile boundaries in LDS
-//            (ids and colours along the boundaries come from k_tile; no label or threshold word is read) and the frame's
-//            slot tables get every such component's frame-level root and size.
+//            words; a tile none of whose 4x4 tiles has contrast only stores constants.  The union-find works on RUNS, one lane
+//            per run from a compacted list (wave prefix sums), so that the phases are balanced: (a) adoption — a run takes ONE
+//            earlier run as parent with a plain store; (b) one pointer-jumping sweep over the static adoption forest; (c) the
+//            remaining links, pooled in LDS, one lane per link, through an atomic-min union; (d) flatten + exact sizes (ds_add
+//            into the roots' own entries); (e) ring-touching roots claimed from the 320 ring pixels and written to the tile's
+//            slice, white ids from 0 up and black ones from the top down; (f) label words written once (64 B/lane).  19.8 KB
+//            of LDS: eight workgroups per CU.  HBM traffic 1.3 R + 1 W + 4 W bytes per pixel.
+//   k_fmerge the ring-touching roots of a frame's tiles are joined across the tile boundaries in LDS (ids and colours along the
+//            boundaries come from k_tile; no label or threshold word is read) and the frame's slot tables get every such
+//            component's frame-level root and size.  One workgroup per frame when its roots fit (both colours in one sweep),
+//            else two, one per colour — white and black never join; a workgroup with more roots than parents + keys fit
+//            keeps only the parents in LDS, and beyond that runs in global memory.
 // No full-frame relabel pass exists: interior components are final when k_tile writes them; the label words of ring-touching
 // ones carry a slot, which consumers resolve with two independent table reads (label word format in ck_internal.h).
 #include <stdlib.h>
@@ -38,14 +41,15 @@ static_assert(TH * 8 == KNT, "threshold / label passes: one 16-pixel chunk per t
 static_assert(TH * TW <= 4096, "run list entries keep the node in 12 bits, the colour in bit 12");
 static_assert(TW == 128, "a node index splits with >> 7 / & 127");
 
-// LDS of k_tile, 19.6 KB, so that eight workgroups (32 waves: all a CU can hold) share a CU:
+// LDS of k_tile, 19.8 KB, so that eight workgroups (32 waves: all a CU can hold) share a CU:
 //   parent  u16[TH*TW]  one entry per node (nodes = first pixels of runs):
 //                         non-root: tile-local index of the parent (bit 15 clear)
 //                         root:     CK_ROOT | pixel count of the component in bits 0..12 (a tile has 4096 pixels) | CK_RING when it
 //                                   touches the tile ring — the union-find's sizes live in the roots' own entries
-//                       after the flatten passes every entry is a component code that the label pass expands (P6c);
-//                       while the threshold is computed the same bytes hold the staged image, the 4x4 min/max and the
-//                       per-4x4 threshold words
+//                       after the flatten pass an entry is the component's root entry or its root's node (the label pass
+//                       looks up at most two);
+//                       while the threshold is computed the same bytes hold the staged image and the 4x4 min/max (the
+//                       per-4x4 threshold words sit in the list's bytes, which is not alive yet)
 //   list    u16[TH*TW]  the tile's runs in scan order: node | colour << 12 (worst case one run per pixel)
 //   pool    u32[POOL_CAP]  links that need an atomic union (two u16 nodes each)
 //   masks   u32[TH][NWD][2]  colour bits of every row word (0 white, 1 black)
