@@ -1175,10 +1175,14 @@ int ck_launch_threshold_segment(ck_handle *h, const uint8_t *frames, int stride,
         int cap = tiles * 120;
         cap = cap < 4096 ? 4096 : (cap > FM_CAP ? FM_CAP : cap);
         if (cap_env && atoi(cap_env) < cap) cap = atoi(cap_env);
-        cap = (cap + 1) & ~1;
-        const size_t lds = (size_t)cap * 4 + (size_t)((tiles + 1 + 3) & ~3) * 4 + (size_t)(FM_NT / 64) * FM_WQ * 4 + (size_t)((tiles + 7) & ~7) * 2 * 3;
+        // (the per-tile arrays and the join queues come first: very large frames leave less room for roots)
+        const size_t fixed = (size_t)((tiles + 1 + 3) & ~3) * 4 + (size_t)(FM_NT / 64) * FM_WQ * 4 + (size_t)((tiles + 7) & ~7) * 2 * 3;
+        const size_t lds_max = 160 * 1024 - 512;
+        if ((size_t)cap * 4 + fixed > lds_max) cap = (int)((lds_max - fixed) / 4);
+        cap &= ~1;
+        const size_t lds = (size_t)cap * 4 + fixed;
         if (!h->fmerge_lds_allowed) { // per handle, i.e. per device: a process may hold handles on several GPUs
-            CK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_fmerge), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+            CK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_fmerge), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512));
             h->fmerge_lds_allowed = true;
         }
         hipLaunchKernelGGL(k_fmerge, dim3((unsigned)(((n + 7) / 8) * 16)), dim3(FM_NT), lds, h->stream, h->d_broots, h->d_tile_count, h->d_ring, h->ring_len,

@@ -82,10 +82,11 @@ def test_merge_paths_beyond_one_workgroups_lds(oracle, kind, cap, monkeypatch):
     det.close()
 
 
-@pytest.mark.parametrize("w,h", [(1920, 1080), (2448, 2048)])
+@pytest.mark.parametrize("w,h", [(1920, 1080), (2448, 2048), (4092, 2200)])
 def test_large_frames_merge_per_colour(oracle, w, h):
     """Dense noise at 1920x1080 has about 45 000 ring-touching roots per frame: two workgroups, one per colour, each in LDS;
-    at 2448x2048 about 55 000 per colour: parents-only LDS."""
+    at 2448x2048 about 55 000 per colour: parents-only LDS; 4092x2200 has 2 208 tiles, whose per-tile arrays take LDS from the
+    roots (the merge kernel's request once exceeded the 160 KB of a CU there) and whose roots run in global memory."""
     from chalkydri_amd.detector import AprilTagDetector
     frames = _frames("noise", w, h, 1, 7)
     frames[0, 200:900, 300:1500] = _frames("blobs", 1200, 700, 1, 8)[0]
