@@ -715,6 +715,7 @@ struct FmFrame {
     const uint16_t *HT, *HB, *VL, *VR; // ring entries: tile-local id | colour << 15 (1 = white), 0xFFFF = no colour
     const uint32_t *base;              // first number of every tile's roots that this workgroup joins (LDS)
     const uint16_t *boff;              // mode 2: the tile's white roots, which its black ones are numbered behind; else 0 (LDS)
+    const uint32_t *numtab;            // [tile][2]: what a white id is added to / a black id subtracted from to give the root's number (LDS)
     const uint16_t *hseg, *vseg;       // the tile edges worth sweeping (LDS): tile row << 5 | tile column of the tile below / on the right
     int nhs, nvs;
     int w, h, tiles_x, tiles_y;
@@ -724,7 +725,8 @@ struct FmFrame {
     __device__ __forceinline__ bool acc(uint32_t e) const { return e != 0xFFFFu && (mode == 2u || (e >> 15) == mode); }
     __device__ __forceinline__ bool has(int t) const { return base[t + 1] != base[t]; }
     __device__ __forceinline__ uint32_t num(int t, uint32_t e) const {
-        return base[t] + ((e & 0x8000u) ? (e & 0x7FFFu) : (uint32_t)boff[t] + (uint32_t)(RING_CAP - 1) - (e & 0x7FFFu));
+        const uint32_t black = (e >> 15) ^ 1u, id = e & 0x7FFFu; // white: base + id; black: base + boff + RING_CAP - 1 - id
+        return numtab[2 * t + black] + (black ? 0u - id : id);
     }
     // tile-local id of the l-th of the tile's cnt roots in that order
     __device__ __forceinline__ uint32_t id_of(int t, uint32_t l, uint32_t cnt) const {
@@ -980,13 +982,14 @@ __global__ __launch_bounds__(FM_NT, 8) __attribute__((amdgpu_num_sgpr(80))) void
     uint32_t *queue = base + ((tiles + 1 + 3) & ~3);                       // per wave: joins waiting to be worked off
     uint16_t *boff = reinterpret_cast<uint16_t *>(queue + (FM_NT / 64) * FM_WQ);
     uint16_t *hseg = boff + ((tiles + 7) & ~7), *vseg = hseg + ((tiles + 7) & ~7);
+    uint32_t *numtab = reinterpret_cast<uint32_t *>(vseg + ((tiles + 7) & ~7));
     const size_t slots = (size_t)tiles * RING_CAP;
     const ck_border_root *slice = broots + (size_t)frame * 2 * slots;
     uint32_t *groot = groot_all + (size_t)frame * slots, *gsize = gsize_all + (size_t)frame * slots;
     const uint16_t *fr = ring + (size_t)frame * ring_len;
     FmFrame f;
     f.HT = fr; f.HB = fr + (size_t)tiles_y * w; f.VL = fr + 2 * (size_t)tiles_y * w; f.VR = f.VL + (size_t)tiles_x * h;
-    f.base = base; f.boff = boff; f.w = w; f.h = h; f.tiles_x = tiles_x; f.tiles_y = tiles_y;
+    f.base = base; f.boff = boff; f.numtab = numtab; f.w = w; f.h = h; f.tiles_x = tiles_x; f.tiles_y = tiles_y;
     // numbers: the tiles' counts, scanned (up to four tiles per thread).  Both colours are counted first: when all of a frame's
     // roots fit the LDS path together, the white workgroup joins both colours in one sweep and the black one has nothing to do.
     uint32_t n;
@@ -1014,7 +1017,11 @@ __global__ __launch_bounds__(FM_NT, 8) __attribute__((amdgpu_num_sgpr(80))) void
         uint32_t off = both ? ow + ob : (col ? ow : ob);
         for (int k = 0; k < per; k++) {
             const int t = tid * per + k;
-            if (t < tiles) { base[t] = off; boff[t] = (uint16_t)(both ? cw[k] : 0u); }
+            if (t < tiles) {
+                const uint32_t bo = both ? cw[k] : 0u;
+                base[t] = off; boff[t] = (uint16_t)bo;
+                numtab[2 * t] = off; numtab[2 * t + 1] = off + bo + (uint32_t)(RING_CAP - 1);
+            }
             off += both ? cw[k] + cb[k] : (col ? cw[k] : cb[k]);
             if (t == tiles - 1) base[tiles] = off;
         }
@@ -1176,7 +1183,7 @@ int ck_launch_threshold_segment(ck_handle *h, const uint8_t *frames, int stride,
         cap = cap < 4096 ? 4096 : (cap > FM_CAP ? FM_CAP : cap);
         if (cap_env && atoi(cap_env) < cap) cap = atoi(cap_env);
         // (the per-tile arrays and the join queues come first: very large frames leave less room for roots)
-        const size_t fixed = (size_t)((tiles + 1 + 3) & ~3) * 4 + (size_t)(FM_NT / 64) * FM_WQ * 4 + (size_t)((tiles + 7) & ~7) * 2 * 3;
+        const size_t fixed = (size_t)((tiles + 1 + 3) & ~3) * 4 + (size_t)(FM_NT / 64) * FM_WQ * 4 + (size_t)((tiles + 7) & ~7) * 2 * 3 + (size_t)tiles * 8;
         const size_t lds_max = 160 * 1024 - 512;
         if ((size_t)cap * 4 + fixed > lds_max) cap = (int)((lds_max - fixed) / 4);
         cap &= ~1;
