@@ -1242,13 +1242,15 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(WPS, 8))) v
 }
 
 // Gradient-magnitude weights of a whole batch in one streaming pass (1 B read, 2 B written per pixel): the fitter then needs
-// ONE 2-byte gather per contour point instead of four byte gathers.  Four pixels per thread: three aligned 4-byte loads (row above, row, row below) plus the two bytes beside the group.
-// Rows are 4-byte aligned (staged frames have 16-byte rows, qw is a multiple of 4).
+// ONE 2-byte gather per contour point instead of four byte gathers.  Four pixels per thread: three aligned 4-byte loads (row
+// above, row, row below) plus the two bytes beside the group.  Image rows are padded to 16 bytes (staged frames and the decimated
+// copy alike), so a group that starts inside a row is readable; the weight image's rows are qw entries long, so a width that is
+// not a multiple of 4 ends in a partial group and its stores go out one by one.
 __global__ __launch_bounds__(256) void k_weight_image(const uint8_t *__restrict__ qim, size_t qpitch, int qstride, int qw, int qh,
                                                       uint16_t *__restrict__ wimg, size_t total4) {
     size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= total4) return;
-    const int w4 = qw >> 2;
+    const int w4 = (qw + 3) >> 2;
     const size_t per_frame = (size_t)w4 * qh;
     const size_t fr = i / per_frame, rem = i - fr * per_frame;
     const int iy = (int)(rem / w4), ix = 4 * (int)(rem - (size_t)iy * w4);
@@ -1269,8 +1271,14 @@ __global__ __launch_bounds__(256) void k_weight_image(const uint8_t *__restrict_
             }
         }
     }
-    *reinterpret_cast<uint2 *>(wimg + fr * ((size_t)qw * qh) + (size_t)iy * qw + ix) =
-        make_uint2((uint32_t)out[0] | ((uint32_t)out[1] << 16), (uint32_t)out[2] | ((uint32_t)out[3] << 16));
+    uint16_t *dst = wimg + fr * ((size_t)qw * qh) + (size_t)iy * qw + ix;
+    if ((qw & 3) == 0)
+        *reinterpret_cast<uint2 *>(dst) = make_uint2((uint32_t)out[0] | ((uint32_t)out[1] << 16), (uint32_t)out[2] | ((uint32_t)out[3] << 16));
+    else {
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if (ix + k < qw) dst[k] = out[k];
+    }
 }
 
 // builds the per-size-class work lists from the cluster tables: one workgroup per frame counts its clusters per class in
@@ -1321,7 +1329,7 @@ int ck_launch_fit_quads(ck_handle *h, const uint8_t *qframes, int qstride, size_
     a.qim = qframes; a.qw = h->qw; a.qh = h->qh; a.qstride = qstride; a.qpitch = qpitch;
     a.wimg = ws.d_wimg;
     {
-        size_t total4 = h->npix / 4 * (size_t)n;
+        size_t total4 = (size_t)((h->qw + 3) / 4) * h->qh * (size_t)n;
         hipLaunchKernelGGL(k_weight_image, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, h->stream, qframes, qpitch, qstride, h->qw, h->qh,
                            ws.d_wimg, total4);
     }

@@ -16,7 +16,7 @@ def run(cases, seed):
         dec = int(rng.choice([1, 1, 2]))
         scale = int(os.environ.get("STRESS_SCALE", "1"))   # 3: frames up to 2700 x 2100 (the largest fit class, two-colour merges)
         w = int(rng.integers(120, 900)) * scale; h = int(rng.integers(100, 700)) * scale
-        w -= w % (4 * dec); h -= h % dec
+        if rng.random() < 0.5: w -= w % (4 * dec)   # half of the cases keep whatever width and height were drawn (odd ones included)
         n = int(rng.integers(1, 4))
         n_tags = int(rng.integers(0, 7))
         fams = ("tag36h11",) if rng.random() < 0.7 else ("tag16h5", "tag36h11")
@@ -27,13 +27,21 @@ def run(cases, seed):
         if rng.random() < 0.3: settings["refine_edges"] = 0
         if rng.random() < 0.3: settings["max_nmaxima"] = int(rng.integers(4, 13))
         if rng.random() < 0.3: settings["min_component_px"] = int(rng.choice([5, 25, 60, 200]))
+        if rng.random() < 0.2: settings["min_white_black_diff"] = int(rng.choice([2, 5, 12, 40]))
+        if rng.random() < 0.2: settings["min_cluster_pixels"] = int(rng.choice([5, 24, 50, 120]))
+        if rng.random() < 0.2: settings["max_line_fit_mse"] = float(rng.choice([1.0, 4.0, 10.0, 30.0]))
+        if rng.random() < 0.2: settings["cos_critical_rad"] = float(rng.choice([0.5, 0.8, 0.984807753012208, 0.999]))
+        if rng.random() < 0.2: settings["decode_sharpening"] = float(rng.choice([0.0, 0.25, 1.0]))
+        if rng.random() < 0.2: settings["max_hamming"] = int(rng.choice([0, 1, 2, 3]))
+        extra = int(rng.integers(0, 3))                       # the handle is sized for more frames than the call brings
         if os.environ.get("STRESS_LOG"):
             with open(os.environ["STRESS_LOG"], "a") as lf:
                 lf.write(json.dumps({"case": c, "w": w, "h": h, "n": n, "tags": n_tags, "fams": fams, "dec": dec, "kw": kw, "settings": settings}) + "\n")
         frames, _ = synth.render_batch(40 + c, n, w, h, n_tags, fams, **kw)
-        det = AprilTagDetector(w, h, max_batch=n, families=fams, quad_decimate=dec, **settings)
+        bits = settings.pop("max_hamming", 3)
+        det = AprilTagDetector(w, h, max_batch=n + extra, families=fams, quad_decimate=dec, bits_corrected=bits, **settings)
         got, status = det.detect_batch(frames, cap=256, return_status=True)   # the handle keeps at most 256 detections per frame (oracle: the same)
-        cfg = default_config(w, h, families=fams, quad_decimate=dec, **settings)
+        cfg = default_config(w, h, families=fams, quad_decimate=dec, max_hamming=bits, **settings)
         for i in range(n):
             want, st = pyoracle.detect(frames[i], cfg)
             ok = status[i] == st and len(got[i]) == len(want)

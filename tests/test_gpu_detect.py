@@ -226,7 +226,8 @@ def test_detector_golden_vectors(built):
 
 
 @pytest.mark.parametrize("w,h", [(16, 16), (32, 20), (68, 52), (132, 68), (260, 72), (516, 36),
-                                 (64, 18), (132, 70), (260, 135), (640, 483)])   # the last four: height not a multiple of 4
+                                 (64, 18), (132, 70), (260, 135), (640, 483),    # these four: height not a multiple of 4
+                                 (261, 135), (322, 94), (643, 481)])            # width not a multiple of 4: the weight image's last, partial group
 def test_small_and_ragged_frames(oracle, w, h):
     """Frames much smaller than a 64x128 tile and not multiples of it: binary noise, blobs and a frame-filling square —
     labels, clusters, quads and detections still equal the oracle's (nothing reads or writes outside the frame).  Heights

@@ -25,3 +25,8 @@ def test_stress_pose(oracle):
 def test_stress_cat(oracle):
     import stress_cat
     assert stress_cat.run(40, 104) == 0
+
+
+def test_stress_batch(oracle):
+    import stress_batch
+    assert stress_batch.run(15, 105) == 0
