@@ -15,7 +15,8 @@ def run(cases, seed):
     rng = np.random.default_rng(seed)
     bad, solved = 0, 0
     for c in range(cases):
-        w = int(rng.integers(160, 330)) * 4; h = int(rng.integers(100, 210)) * 4
+        w = int(rng.integers(640, 1320)); h = int(rng.integers(400, 840))   # any width and height, odd ones included
+        dec = int(rng.choice([1, 1, 2]))
         f = float(rng.uniform(0.6, 1.1)) * w
         n = int(rng.integers(1, 5))
         layout = scenes.wall_layout(int(rng.integers(1, 19)), spacing=float(rng.uniform(0.3, 0.6)), cols=int(rng.integers(2, 7)))
@@ -33,9 +34,9 @@ def run(cases, seed):
         if os.environ.get("STRESS_LOG"):
             with open(os.environ["STRESS_LOG"], "a") as lf:
                 lf.write(json.dumps({"case": c, "w": w, "h": h, "n": n, "tags": len(layout["tags"]), "r2c": r2c}) + "\n")
-        task = AprilTags(w, h, layout, calib, r2c, cam_id=int(rng.integers(0, 200)), max_batch=n)
+        task = AprilTags(w, h, layout, calib, r2c, cam_id=int(rng.integers(0, 200)), max_batch=n, quad_decimate=dec)
         recs, valid = task.process_batch(frames, gyros)
-        cfg = default_config(w, h)
+        cfg = default_config(w, h, quad_decimate=dec)
         for i in range(n):
             out = A.VisionMeasurement(); v = C.c_int(0)
             pyoracle.lib().ora_process_frame(C.c_void_p(frames[i].ctypes.data), w, h, w, C.byref(cfg), C.byref(task._pp),

@@ -30,3 +30,8 @@ def test_stress_cat(oracle):
 def test_stress_batch(oracle):
     import stress_batch
     assert stress_batch.run(15, 105) == 0
+
+
+def test_stress_ingest(built):
+    import stress_ingest
+    assert stress_ingest.run(15, 106) == 0
