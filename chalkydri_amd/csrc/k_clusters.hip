@@ -291,7 +291,16 @@ __global__ __launch_bounds__(SNT) void k_scan(ck_stage_ws ws, int min_cluster, i
                 ck_cluster_t ck;
                 ck.rep0 = (uint32_t)(key >> 32); ck.rep1 = (uint32_t)key; ck.start = my_po; ck.count = c;
                 clusters[my_co] = ck;
-            } else atomicOr(&counters[CK_CNT_STATUS], (uint32_t)CK_FRAME_CLUSTERS_OVERFLOW);
+            } else {
+                // no room for the cluster's points (or for its record): it is dropped.  Its record must not stay what an earlier
+                // call left there — the count of clusters below includes it — so it becomes an empty one, which k_classify skips
+                if (my_co < (uint32_t)ws.cluster_cap) {
+                    ck_cluster_t ck;
+                    ck.rep0 = 0; ck.rep1 = 0; ck.start = 0; ck.count = 0;
+                    clusters[my_co] = ck;
+                }
+                atomicOr(&counters[CK_CNT_STATUS], (uint32_t)CK_FRAME_CLUSTERS_OVERFLOW);
+            }
         }
         goff[e] = off;
         po += (uint32_t)__builtin_amdgcn_readlane((int)ip, 63);

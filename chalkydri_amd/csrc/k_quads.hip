@@ -1292,13 +1292,15 @@ __global__ __launch_bounds__(1024) void k_classify(ck_stage_ws ws, int n, uint32
     auto class_of = [](uint32_t c) { return c <= 512 ? 0 : (c <= 2048 ? 1 : (c <= 4096 ? 2 : (c <= 8192 ? 3 : (c <= 16384 ? 4 : 5)))); };
     if (tid < CK_FIT_CLASSES) sCnt[tid] = 0;
     __syncthreads();
-    for (uint32_t i = tid; i < nc; i += 1024) atomicAdd(&sCnt[class_of(cls[i].count)], 1u);
+    // (a cluster without points is one k_scan had no room for: skipped)
+    for (uint32_t i = tid; i < nc; i += 1024) if (cls[i].count) atomicAdd(&sCnt[class_of(cls[i].count)], 1u);
     __syncthreads();
     if (tid < CK_FIT_CLASSES) { sBase[tid] = sCnt[tid] ? atomicAdd(&list_counts[tid], sCnt[tid]) : 0u; }
     __syncthreads();
     if (tid < CK_FIT_CLASSES) sCnt[tid] = 0;
     __syncthreads();
     for (uint32_t i = tid; i < nc; i += 1024) {
+        if (!cls[i].count) continue;
         const int k = class_of(cls[i].count);
         const uint32_t pos = sBase[k] + atomicAdd(&sCnt[k], 1u);
         if (pos < (uint32_t)list_cap) lists[(size_t)k * list_cap + pos] = ((uint32_t)frame << 20) | i;

@@ -274,6 +274,19 @@ def test_capacity_overflow_is_a_status_bit(oracle):
     assert not (status[0] | status[2]) & ~A.CK_FRAME_UNVERIFIED_ID
     _same_dets(dets[0], want_tags); _same_dets(dets[2], want_tags)
     det.close()
+    # points only: the clusters that k_scan has no room for are holes in the cluster table; they must read as empty, not as what
+    # an earlier call (or the allocator) left there — the fit once followed such a record out of its buffers
+    # (tests/stress_detect.py with STRESS_CAPS=1 found it).  Calls alternate so that every hole has a stale record under it.
+    det = AprilTagDetector(w, h, max_batch=2, max_points_per_frame=50000, max_clusters_per_frame=1024)
+    for frames in ([tags, tags], [noise, tags], [tags, noise], [noise, noise], [tags, tags]):
+        dets, status = det.detect_batch(np.stack(frames), cap=64, return_status=True)
+        for f, d, st in zip(frames, dets, status):
+            if f is tags:
+                assert not st & ~A.CK_FRAME_UNVERIFIED_ID
+                _same_dets(d, want_tags)
+            else:
+                assert st & (A.CK_FRAME_POINTS_OVERFLOW | A.CK_FRAME_CLUSTERS_OVERFLOW)
+    det.close()
     # quads: twelve clean tags against room for four candidate quads
     det = AprilTagDetector(w, h, max_batch=2, max_quads_per_frame=4)
     dets, status = det.detect_batch(np.stack([many, tags]), cap=64, return_status=True)

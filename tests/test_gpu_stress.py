@@ -17,6 +17,13 @@ def test_stress_detect(oracle):
     assert stress_detect.run(40, 102) == 0
 
 
+def test_stress_detect_small_capacities(oracle, monkeypatch):
+    """Undersized point / cluster / quad capacities drawn at random: an overflow is a status bit on both sides, never a fault."""
+    import stress_detect
+    monkeypatch.setenv("STRESS_CAPS", "1")
+    assert stress_detect.run(40, 107) == 0
+
+
 def test_stress_pose(oracle):
     import stress_pose
     assert stress_pose.run(25, 103) == 0
