@@ -42,3 +42,8 @@ def test_stress_batch(oracle):
 def test_stress_ingest(built):
     import stress_ingest
     assert stress_ingest.run(15, 106) == 0
+
+
+def test_stress_sqpnp(oracle):
+    import stress_sqpnp
+    assert stress_sqpnp.run(256, 108) == 0
