@@ -63,16 +63,16 @@ extern "C" int ck_create(const ck_config_t *cfg, ck_handle_t **out) {
     CK_TRY(hipEventCreateWithFlags(&h->ev_fit_fork, hipEventDisableTiming));
     for (auto &st : h->fit_stream) CK_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
     for (auto &e : h->ev_fit_join) CK_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    CK_TRY(hipMalloc(&h->d_frames, h->frame_pitch * nb));
-    if (cfg->quad_decimate > 1) CK_TRY(hipMalloc(&h->d_qframes, (size_t)round_up(qw, 16) * qh * nb));
-    CK_TRY(hipMalloc(&h->d_thresh, h->npix * nb));
-    CK_TRY(hipMalloc(&h->d_labels, h->npix * nb * sizeof(uint32_t)));
-    CK_TRY(hipMalloc(&h->d_groot, (size_t)h->broot_cap * nb * sizeof(uint32_t)));
-    CK_TRY(hipMalloc(&h->d_gsize, (size_t)h->broot_cap * nb * sizeof(uint32_t)));
-    CK_TRY(hipMalloc(&h->d_gscratch, 2 * (size_t)h->broot_cap * nb * sizeof(uint32_t)));
-    CK_TRY(hipMalloc(&h->d_broots, 2 * (size_t)h->broot_cap * nb * sizeof(ck_border_root)));
-    CK_TRY(hipMalloc(&h->d_tile_count, (size_t)h->tiles_x * h->tiles_y * nb * sizeof(uint32_t)));
-    CK_TRY(hipMalloc(&h->d_ring, h->ring_len * nb * sizeof(uint16_t)));
+    CK_TRY(ck_malloc_dev(&h->d_frames, h->frame_pitch * nb));
+    if (cfg->quad_decimate > 1) CK_TRY(ck_malloc_dev(&h->d_qframes, (size_t)round_up(qw, 16) * qh * nb));
+    CK_TRY(ck_malloc_dev(&h->d_thresh, h->npix * nb));
+    CK_TRY(ck_malloc_dev(&h->d_labels, h->npix * nb * sizeof(uint32_t)));
+    CK_TRY(ck_malloc_dev(&h->d_groot, (size_t)h->broot_cap * nb * sizeof(uint32_t)));
+    CK_TRY(ck_malloc_dev(&h->d_gsize, (size_t)h->broot_cap * nb * sizeof(uint32_t)));
+    CK_TRY(ck_malloc_dev(&h->d_gscratch, 2 * (size_t)h->broot_cap * nb * sizeof(uint32_t)));
+    CK_TRY(ck_malloc_dev(&h->d_broots, 2 * (size_t)h->broot_cap * nb * sizeof(ck_border_root)));
+    CK_TRY(ck_malloc_dev(&h->d_tile_count, (size_t)h->tiles_x * h->tiles_y * nb * sizeof(uint32_t)));
+    CK_TRY(ck_malloc_dev(&h->d_ring, h->ring_len * nb * sizeof(uint16_t)));
     rc = ck_stage_alloc(h);
     if (rc != CK_OK) return fail(rc);
 #undef CK_TRY
@@ -173,8 +173,8 @@ extern "C" int ck_segment_batch(ck_handle_t *h, const ck_image_u8_t *imgs, int32
     if (rc != CK_OK) return rc;
     size_t total = h->npix * (size_t)n;
     uint32_t *d_canon = nullptr, *d_sizes = nullptr;
-    if (hipMalloc(&d_canon, total * sizeof(uint32_t)) != hipSuccess) return CK_ENOMEM;
-    if (sizes_out && hipMalloc(&d_sizes, total * sizeof(uint32_t)) != hipSuccess) { (void)hipFree(d_canon); return CK_ENOMEM; }
+    if (ck_malloc_dev(&d_canon, total * sizeof(uint32_t)) != hipSuccess) return CK_ENOMEM;
+    if (sizes_out && ck_malloc_dev(&d_sizes, total * sizeof(uint32_t)) != hipSuccess) { (void)hipFree(d_canon); return CK_ENOMEM; }
     rc = ck_launch_canonical_labels(h, n, d_canon, d_sizes);
     if (rc == CK_OK) {
         hipError_t e = hipMemcpyAsync(labels_out, d_canon, total * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream);
@@ -230,9 +230,9 @@ extern "C" int ck_selftest_fp64(ck_handle_t *h, int32_t op, const double *a, con
     if (n == 0) return CK_OK;
     double *da = nullptr, *db = nullptr, *dout = nullptr;
     const size_t bytes = sizeof(double) * (size_t)n;
-    hipError_t e = hipMalloc(&da, bytes);
-    if (e == hipSuccess) e = hipMalloc(&dout, bytes);
-    if (e == hipSuccess && b) e = hipMalloc(&db, bytes);
+    hipError_t e = ck_malloc_dev(&da, bytes);
+    if (e == hipSuccess) e = ck_malloc_dev(&dout, bytes);
+    if (e == hipSuccess && b) e = ck_malloc_dev(&db, bytes);
     if (e == hipSuccess) e = hipMemcpy(da, a, bytes, hipMemcpyHostToDevice);
     if (e == hipSuccess && b) e = hipMemcpy(db, b, bytes, hipMemcpyHostToDevice);
     if (e == hipSuccess) {

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include "chalkydri_hip.h"
 
@@ -160,6 +161,18 @@ extern thread_local char ck_err_text[512];
             return CK_EDEVICE;                                                                              \
         }                                                                                                   \
     } while (0)
+
+// Device allocation of the handle's buffers.  CK_POISON=1 (tests) fills every buffer with 0xA5 bytes, so that a kernel which
+// reads an entry nobody wrote in this call — what an undersized capacity once made of the cluster and run tables — meets the
+// same garbage on every run instead of whatever the allocator happens to hand back.
+template <typename T>
+static inline hipError_t ck_malloc_dev(T **p, size_t bytes) {
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(p), bytes);
+    const char *pe = getenv("CK_POISON"); // (read per allocation: a test sets it for the handles it creates)
+    const bool poison = pe && atoi(pe) != 0;
+    if (e == hipSuccess && poison && bytes) e = hipMemset(*p, 0xA5, bytes);
+    return e;
+}
 
 // ---- stage launchers (k_*.hip) ------------------------------------------------------------------------
 // threshold + tile-local CCL + cross-tile merge + border-root flatten, on frames [0,n) of `frames`

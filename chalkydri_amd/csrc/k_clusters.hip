@@ -227,13 +227,14 @@ __global__ __launch_bounds__(NT) void k_emit(EmitArgs a) {
         for (int q = 0; q < 2; q++) {
             if ((q ? k1 : k0) == 0ull) continue;
             const uint32_t found = q ? found1 : found0;
-            if (found != SKIP) {
-                if (ri < (uint32_t)ws.run_cap) {
-                    ck_run r;
-                    r.slot = found; r.base = 0; r.tmp_start = tile_base + sTBase[2 * tid + q]; r.count = q ? c1 : c0;
-                    runs[ri] = r;
-                } else atomicOr(&counters[CK_CNT_STATUS], (uint32_t)CK_FRAME_CLUSTERS_OVERFLOW);
-            }
+            // (a key the frame's table had no room for still owns its place in the run list: it gets an empty record — left
+            // as it was, k_scatter would follow whatever an earlier call had written there)
+            if (ri < (uint32_t)ws.run_cap) {
+                ck_run r;
+                r.slot = found != SKIP ? found : 0u; r.base = 0; r.tmp_start = tile_base + sTBase[2 * tid + q];
+                r.count = found != SKIP ? (q ? c1 : c0) : 0u;
+                runs[ri] = r;
+            } else if (found != SKIP) atomicOr(&counters[CK_CNT_STATUS], (uint32_t)CK_FRAME_CLUSTERS_OVERFLOW);
             ri++;
         }
     }
