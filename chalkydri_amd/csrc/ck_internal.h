@@ -166,13 +166,16 @@ extern thread_local char ck_err_text[512];
 // reads an entry nobody wrote in this call — what an undersized capacity once made of the cluster and run tables — meets the
 // same garbage on every run instead of whatever the allocator happens to hand back.
 template <typename T>
-static inline hipError_t ck_malloc_dev(T **p, size_t bytes) {
+static inline hipError_t ck_malloc_dev_at(T **p, size_t bytes, const char *what, int line) {
     hipError_t e = hipMalloc(reinterpret_cast<void **>(p), bytes);
     const char *pe = getenv("CK_POISON"); // (read per allocation: a test sets it for the handles it creates)
-    const bool poison = pe && atoi(pe) != 0;
+    const int poison = pe ? atoi(pe) : 0;
     if (e == hipSuccess && poison && bytes) e = hipMemset(*p, 0xA5, bytes);
+    // CK_POISON=2 also lists the buffers (address range, what, where): the page a GPU memory fault names can then be matched to one
+    if (poison >= 2) fprintf(stderr, "ck_alloc %p..%p %zu %s:%d\n", (void *)*p, (void *)((char *)*p + bytes), bytes, what, line);
     return e;
 }
+#define ck_malloc_dev(p, bytes) ck_malloc_dev_at(p, bytes, #p, __LINE__)
 
 // ---- stage launchers (k_*.hip) ------------------------------------------------------------------------
 // threshold + tile-local CCL + cross-tile merge + border-root flatten, on frames [0,n) of `frames`
