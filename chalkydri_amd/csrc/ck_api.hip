@@ -9,6 +9,59 @@
 
 thread_local char ck_err_text[512] = "";
 
+// ---- CK_POISON=3: guard-page allocations (ck_internal.h) --------------------------------------------------------------------------
+#include <map>
+#include <mutex>
+namespace {
+std::mutex g_guard_mu;
+std::map<void *, ck_guarded_alloc> g_guarded;
+}
+hipError_t ck_guarded_malloc(void **p, size_t bytes) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    hipMemAllocationProp prop = {};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = dev;
+    size_t gran = 0;
+    e = hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityMinimum);
+    if (e != hipSuccess || gran == 0) return e != hipSuccess ? e : hipErrorUnknown;
+    ck_guarded_alloc g = {};
+    const size_t used = (bytes + 15) / 16 * 16;                    // the buffer keeps 16-byte alignment (its widest accesses); at most 15 bytes of slack
+    g.map_bytes = (used + gran - 1) / gran * gran;
+    g.va_bytes = g.map_bytes + gran;                               // ... and one granule that stays unmapped
+    e = hipMemAddressReserve(&g.va, g.va_bytes, gran, nullptr, 0);
+    if (e != hipSuccess) return e;
+    e = hipMemCreate(&g.mem, g.map_bytes, &prop, 0);
+    if (e != hipSuccess) { (void)hipMemAddressFree(g.va, g.va_bytes); return e; }
+    e = hipMemMap(g.va, g.map_bytes, 0, g.mem, 0);
+    hipMemAccessDesc acc = {};
+    acc.location = prop.location;
+    acc.flags = hipMemAccessFlagsProtReadWrite;
+    if (e == hipSuccess) e = hipMemSetAccess(g.va, g.map_bytes, &acc, 1);
+    if (e != hipSuccess) { (void)hipMemRelease(g.mem); (void)hipMemAddressFree(g.va, g.va_bytes); return e; }
+    *p = static_cast<char *>(g.va) + (g.map_bytes - used);
+    std::lock_guard<std::mutex> lk(g_guard_mu);
+    g_guarded[*p] = g;
+    return hipSuccess;
+}
+bool ck_guarded_free(void *p) {
+    ck_guarded_alloc g;
+    {
+        std::lock_guard<std::mutex> lk(g_guard_mu);
+        auto it = g_guarded.find(p);
+        if (it == g_guarded.end()) return false;
+        g = it->second;
+        g_guarded.erase(it);
+    }
+    (void)hipDeviceSynchronize();
+    (void)hipMemUnmap(g.va, g.map_bytes);
+    (void)hipMemRelease(g.mem);
+    (void)hipMemAddressFree(g.va, g.va_bytes);
+    return true;
+}
+
 extern "C" const char *ck_last_error(void) { return ck_err_text; }
 
 extern "C" int ck_device_count(void) {
@@ -87,8 +140,8 @@ extern "C" void ck_destroy(ck_handle_t *h) {
     if (h->stream2) (void)hipStreamSynchronize(h->stream2);
     for (auto &st : h->fit_stream) if (st) (void)hipStreamSynchronize(st);
     ck_stage_free(h);
-    (void)hipFree(h->d_frames); (void)hipFree(h->d_qframes); (void)hipFree(h->d_thresh); (void)hipFree(h->d_labels);
-    (void)hipFree(h->d_groot); (void)hipFree(h->d_gsize); (void)hipFree(h->d_gscratch); (void)hipFree(h->d_broots); (void)hipFree(h->d_tile_count); (void)hipFree(h->d_ring);
+    (void)ck_free_dev(h->d_frames); (void)ck_free_dev(h->d_qframes); (void)ck_free_dev(h->d_thresh); (void)ck_free_dev(h->d_labels);
+    (void)ck_free_dev(h->d_groot); (void)ck_free_dev(h->d_gsize); (void)ck_free_dev(h->d_gscratch); (void)ck_free_dev(h->d_broots); (void)ck_free_dev(h->d_tile_count); (void)ck_free_dev(h->d_ring);
     for (auto &e : h->ev) if (e) (void)hipEventDestroy(e);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
@@ -174,7 +227,7 @@ extern "C" int ck_segment_batch(ck_handle_t *h, const ck_image_u8_t *imgs, int32
     size_t total = h->npix * (size_t)n;
     uint32_t *d_canon = nullptr, *d_sizes = nullptr;
     if (ck_malloc_dev(&d_canon, total * sizeof(uint32_t)) != hipSuccess) return CK_ENOMEM;
-    if (sizes_out && ck_malloc_dev(&d_sizes, total * sizeof(uint32_t)) != hipSuccess) { (void)hipFree(d_canon); return CK_ENOMEM; }
+    if (sizes_out && ck_malloc_dev(&d_sizes, total * sizeof(uint32_t)) != hipSuccess) { (void)ck_free_dev(d_canon); return CK_ENOMEM; }
     rc = ck_launch_canonical_labels(h, n, d_canon, d_sizes);
     if (rc == CK_OK) {
         hipError_t e = hipMemcpyAsync(labels_out, d_canon, total * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream);
@@ -182,7 +235,7 @@ extern "C" int ck_segment_batch(ck_handle_t *h, const ck_image_u8_t *imgs, int32
         if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
         if (e != hipSuccess) { snprintf(ck_err_text, sizeof ck_err_text, "segment D2H failed: %s", hipGetErrorString(e)); rc = CK_EDEVICE; }
     }
-    (void)hipFree(d_canon); (void)hipFree(d_sizes);
+    (void)ck_free_dev(d_canon); (void)ck_free_dev(d_sizes);
     return rc;
 }
 
@@ -240,7 +293,7 @@ extern "C" int ck_selftest_fp64(ck_handle_t *h, int32_t op, const double *a, con
         e = hipStreamSynchronize(h->stream);
     }
     if (e == hipSuccess) e = hipMemcpy(out, dout, bytes, hipMemcpyDeviceToHost);
-    (void)hipFree(da); (void)hipFree(db); (void)hipFree(dout); // one exit: nothing leaks on an error path
+    (void)ck_free_dev(da); (void)ck_free_dev(db); (void)ck_free_dev(dout); // one exit: nothing leaks on an error path
     if (e != hipSuccess) { snprintf(ck_err_text, sizeof ck_err_text, "fp64 probe failed: %s", hipGetErrorString(e)); return CK_EDEVICE; }
     return CK_OK;
 }

@@ -164,18 +164,31 @@ extern thread_local char ck_err_text[512];
 
 // Device allocation of the handle's buffers.  CK_POISON=1 (tests) fills every buffer with 0xA5 bytes, so that a kernel which
 // reads an entry nobody wrote in this call — what an undersized capacity once made of the cluster and run tables — meets the
-// same garbage on every run instead of whatever the allocator happens to hand back.
+// same garbage on every run instead of whatever the allocator happens to hand back.  CK_POISON=2 also lists the buffers.
+// CK_POISON=3 gives every buffer a virtual-address range of its own, mapped so that the buffer ENDS at the end of the mapping
+// and the next granule is reserved but unmapped: an access past a buffer's end is a GPU memory fault at once, wherever the
+// allocator would have put its neighbours (guard pages; hipMemAddressReserve / hipMemCreate / hipMemMap).
+struct ck_guarded_alloc { void *va; size_t va_bytes; hipMemGenericAllocationHandle_t mem; size_t map_bytes; };
+hipError_t ck_guarded_malloc(void **p, size_t bytes); // ck_api.hip
+bool ck_guarded_free(void *p);                        // true when p was a guarded allocation (and is released now)
 template <typename T>
 static inline hipError_t ck_malloc_dev_at(T **p, size_t bytes, const char *what, int line) {
-    hipError_t e = hipMalloc(reinterpret_cast<void **>(p), bytes);
     const char *pe = getenv("CK_POISON"); // (read per allocation: a test sets it for the handles it creates)
     const int poison = pe ? atoi(pe) : 0;
-    if (e == hipSuccess && poison && bytes) e = hipMemset(*p, 0xA5, bytes);
-    // CK_POISON=2 also lists the buffers (address range, what, where): the page a GPU memory fault names can then be matched to one
+    hipError_t e = (poison >= 3 && bytes && bytes < ((size_t)1 << 30)) ? ck_guarded_malloc( // (buffers of a gigabyte and more keep the plain allocator)
+                   reinterpret_cast<void **>(p), bytes) : hipMalloc(reinterpret_cast<void **>(p), bytes);
+    if (e == hipSuccess && poison && bytes) {
+        e = hipMemset(*p, 0xA5, bytes);
+        if (e == hipSuccess) e = hipDeviceSynchronize(); // (the fill is asynchronous, and the handle's streams do not wait for the null stream)
+    }
     if (poison >= 2) fprintf(stderr, "ck_alloc %p..%p %zu %s:%d\n", (void *)*p, (void *)((char *)*p + bytes), bytes, what, line);
     return e;
 }
 #define ck_malloc_dev(p, bytes) ck_malloc_dev_at(p, bytes, #p, __LINE__)
+static inline hipError_t ck_free_dev(const void *p) {
+    if (p && ck_guarded_free(const_cast<void *>(p))) return hipSuccess;
+    return hipFree(const_cast<void *>(p));
+}
 
 // ---- stage launchers (k_*.hip) ------------------------------------------------------------------------
 // threshold + tile-local CCL + cross-tile merge + border-root flatten, on frames [0,n) of `frames`

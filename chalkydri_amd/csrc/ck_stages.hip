@@ -80,15 +80,15 @@ void ck_stage_free(ck_handle *h) {
     if (h->d_fams) {
         std::vector<ck_dev_family> fams((size_t)h->cfg.n_families);
         if (hipMemcpy(fams.data(), h->d_fams, sizeof(ck_dev_family) * fams.size(), hipMemcpyDeviceToHost) == hipSuccess)
-            for (auto &f : fams) (void)hipFree(const_cast<uint64_t *>(f.codes));
-        (void)hipFree(h->d_fams);
+            for (auto &f : fams) (void)ck_free_dev(const_cast<uint64_t *>(f.codes));
+        (void)ck_free_dev(h->d_fams);
     }
-    (void)hipFree(ws.d_ht_keys); (void)hipFree(ws.d_ht_count); (void)hipFree(ws.d_ht_off); (void)hipFree(ws.d_tmp);
-    (void)hipFree(ws.d_points); (void)hipFree(ws.d_runs); (void)hipFree(ws.d_lscratch); (void)hipFree(ws.d_hscratch); (void)hipFree(ws.d_clusters); (void)hipFree(ws.d_counters); (void)hipFree(ws.d_quads);
-    (void)hipFree(ws.d_dets); (void)hipFree(ws.d_fit_scratch); (void)hipFree(ws.d_wimg);
-    (void)hipFree(ws.d_field); (void)hipFree(ws.d_gyro); (void)hipFree(ws.d_has_gyro); (void)hipFree(ws.d_problems);
-    (void)hipFree(ws.d_pose_tags); (void)hipFree(ws.d_bearings); (void)hipFree(ws.d_world); (void)hipFree(ws.d_results);
-    (void)hipFree(ws.d_meas); (void)hipFree(ws.d_valid);
+    (void)ck_free_dev(ws.d_ht_keys); (void)ck_free_dev(ws.d_ht_count); (void)ck_free_dev(ws.d_ht_off); (void)ck_free_dev(ws.d_tmp);
+    (void)ck_free_dev(ws.d_points); (void)ck_free_dev(ws.d_runs); (void)ck_free_dev(ws.d_lscratch); (void)ck_free_dev(ws.d_hscratch); (void)ck_free_dev(ws.d_clusters); (void)ck_free_dev(ws.d_counters); (void)ck_free_dev(ws.d_quads);
+    (void)ck_free_dev(ws.d_dets); (void)ck_free_dev(ws.d_fit_scratch); (void)ck_free_dev(ws.d_wimg);
+    (void)ck_free_dev(ws.d_field); (void)ck_free_dev(ws.d_gyro); (void)ck_free_dev(ws.d_has_gyro); (void)ck_free_dev(ws.d_problems);
+    (void)ck_free_dev(ws.d_pose_tags); (void)ck_free_dev(ws.d_bearings); (void)ck_free_dev(ws.d_world); (void)ck_free_dev(ws.d_results);
+    (void)ck_free_dev(ws.d_meas); (void)ck_free_dev(ws.d_valid);
 }
 
 // the whole detector on n frames resident on the device
