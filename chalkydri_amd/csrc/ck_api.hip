@@ -104,6 +104,7 @@ extern "C" int ck_create(const ck_config_t *cfg, ck_handle_t **out) {
         hipError_t e_ = (call);                                                                       \
         if (e_ != hipSuccess) {                                                                       \
             snprintf(ck_err_text, sizeof ck_err_text, "%s failed: %s", #call, hipGetErrorString(e_)); \
+            (void)hipGetLastError(); /* (not left behind for a later call's launch check) */         \
             return fail(e_ == hipErrorOutOfMemory ? CK_ENOMEM : CK_EDEVICE);                          \
         }                                                                                             \
     } while (0)
@@ -151,6 +152,7 @@ extern "C" void ck_destroy(ck_handle_t *h) {
     if (h->stream2) (void)hipStreamDestroy(h->stream2);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
+    (void)hipGetLastError(); // (what the clean-up calls above may have left behind — a handle that never got its device, say — is not the next call's error)
 }
 
 static int check_imgs(const ck_handle *h, const ck_image_u8_t *imgs, int n) {

@@ -158,6 +158,7 @@ extern thread_local char ck_err_text[512];
         if (e_ != hipSuccess) {                                                                             \
             snprintf(ck_err_text, sizeof ck_err_text, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), \
                      __FILE__, __LINE__);                                                                   \
+            (void)hipGetLastError(); /* the runtime keeps the error per thread: the next launch check must not meet it */ \
             return CK_EDEVICE;                                                                              \
         }                                                                                                   \
     } while (0)
