@@ -27,8 +27,8 @@ def run(cases, seed):
     for c0 in range(0, cases, 64):
         probs, want, kinds = [], [], []
         for k in range(min(64, cases - c0)):
-            kind = str(rng.choice(["plain", "noisy", "gyro_off", "one_tag", "wall", "twins", "behind", "short"]))
-            n_tags = 1 if kind == "one_tag" else int(rng.integers(1, 31))
+            kind = str(rng.choice(["plain", "noisy", "gyro_off", "one_tag", "wall", "twins", "behind", "short", "many"]))
+            n_tags = 1 if kind == "one_tag" else (int(rng.integers(100, 400)) if kind == "many" else int(rng.integers(1, 31)))   # many: far beyond a field's 30 tags
             tags, b, rtc, truth = N.make_scene(rng, n_tags, noise_px={"noisy": 8.0, "plain": 0.0}.get(kind, 0.3))
             gyro = truth["yaw"] + (rng.uniform(-3.1, 3.1) if kind == "gyro_off" else rng.uniform(-0.3, 0.3))
             if kind == "wall":                                   # all tags in one plane, same orientation
