@@ -311,7 +311,7 @@ extern "C" int ck_cat_detect_corners(ck_handle_t *h, const uint8_t *classes, int
 
 extern "C" int ck_cat_check_edges(ck_handle_t *h, const uint8_t *classes, int32_t w, int32_t ht, const uint32_t *points_xy, int32_t n_points,
                                   uint32_t *lines_xyxy, int32_t cap, int32_t *n_lines) {
-    if (!h || !classes || !lines_xyxy || !n_lines || n_points < 0 || (n_points > 0 && !points_xy) || cap < 0) return CK_EINVAL;
+    if (!h || !classes || !lines_xyxy || !n_lines || n_points < 0 || (n_points > 0 && !points_xy) || cap < 0 || w < 1 || ht < 1) return CK_EINVAL;
     CK_HIP(hipSetDevice(h->device));
     size_t n = (size_t)w * ht;
     DevBuf<uint8_t> dcls; DevBuf<uint32_t> dpts, dlines;
@@ -353,7 +353,7 @@ extern "C" int ck_cat_connected_components(ck_handle_t *h, const uint8_t *classe
 extern "C" int ck_cat_process_frame(ck_handle_t *h, const uint8_t *rgb, size_t rgb_len, int32_t w, int32_t ht, uint8_t *classes_out,
                                     uint32_t *points_xy, int32_t point_cap, int32_t *n_points, uint32_t *lines_xyxy, int32_t line_cap,
                                     int32_t *n_lines) {
-    if (!h || !rgb || !classes_out || !points_xy || !n_points || !lines_xyxy || !n_lines || w < 1 || ht < 1) return CK_EINVAL;
+    if (!h || !rgb || !classes_out || !points_xy || !n_points || !lines_xyxy || !n_lines || w < 1 || ht < 1 || point_cap < 0 || line_cap < 0) return CK_EINVAL;
     if (rgb_len != (size_t)w * ht * 3) return CK_EINVAL; // the reference asserts (lib.rs:267)
     CK_HIP(hipSetDevice(h->device));
     size_t n = (size_t)w * ht;

@@ -611,13 +611,14 @@ struct DevBuf {
 extern "C" int ck_sqpnp_solve_batch(ck_handle_t *h, const ck_sqpnp_params_t *params, const ck_sqpnp_problem_t *problems, int32_t n,
                                     const ck_iso3_t *tags, int32_t n_tags_total, const double *bearings, int32_t n_bearings_total,
                                     ck_sqpnp_result_t *out) {
-    if (!h || !params || !problems || !out || n < 0 || (n_tags_total > 0 && !tags) || (n_bearings_total > 0 && !bearings)) return CK_EINVAL;
+    if (!h || !params || !problems || !out || n < 0 || n_tags_total < 0 || n_bearings_total < 0 || (n_tags_total > 0 && !tags) ||
+        (n_bearings_total > 0 && !bearings)) return CK_EINVAL;
     if (n == 0) return CK_OK;
     int max_pts = 4;
     for (int i = 0; i < n; i++) {
         const ck_sqpnp_problem_t &p = problems[i];
-        if (p.n_tags < 0 || p.n_bearings < 0 || p.tag_offset < 0 || p.bearing_offset < 0 || p.tag_offset + p.n_tags > n_tags_total ||
-            p.bearing_offset + p.n_bearings > n_bearings_total) return CK_EINVAL;
+        if (p.n_tags < 0 || p.n_bearings < 0 || p.tag_offset < 0 || p.bearing_offset < 0 || (int64_t)p.tag_offset + p.n_tags > n_tags_total ||
+            (int64_t)p.bearing_offset + p.n_bearings > n_bearings_total) return CK_EINVAL;
         if (4 * p.n_tags > max_pts) max_pts = 4 * p.n_tags;
     }
     CK_HIP(hipSetDevice(h->device));

@@ -114,3 +114,70 @@ def test_ingest_and_pose_entry_points_reject_bad_arguments(built):
     assert [len(d) for d in dets] == [len(d) for d in det.detect_batch(frames)]
     ring.close()
     det.close()
+
+
+def test_cat_and_solver_entry_points_reject_bad_arguments(built):
+    from chalkydri_amd.detector import AprilTagDetector
+    w, h = 96, 64
+    det = AprilTagDetector(w, h)
+    L, hd = det._L, det._h
+    rgb = np.random.default_rng(1).integers(0, 256, (h, w, 3), dtype=np.uint8)
+    cls = np.zeros((h, w), np.uint8)
+    pts = np.zeros(64, np.uint32); lines = np.zeros(64, np.uint32)
+    n_pts = C.c_int32(0); n_lines = C.c_int32(0)
+    R, K, P, Ln = rgb.ctypes.data, cls.ctypes.data, pts.ctypes.data, lines.ctypes.data
+    bad = []
+    def expect_error(rc, what):
+        if rc == 0:
+            bad.append(what)
+    expect_error(L.ck_cat_calc_otsu(hd, None, w, h, K), "otsu: null frame")
+    expect_error(L.ck_cat_calc_otsu(hd, R, w, h, None), "otsu: null output")
+    expect_error(L.ck_cat_calc_otsu(hd, R, 0, h, K), "otsu: zero width")
+    expect_error(L.ck_cat_calc_otsu(hd, R, w, -1, K), "otsu: negative height")
+    expect_error(L.ck_cat_calc_otsu(None, R, w, h, K), "otsu: null handle")
+    expect_error(L.ck_cat_thresh(None, R, w, h, K), "thresh: null handle")
+    expect_error(L.ck_cat_thresh(hd, None, w, h, K), "thresh: null frame")
+    expect_error(L.ck_cat_detect_corners(hd, K, w, h, P, -1, C.byref(n_pts)), "corners: negative capacity")
+    expect_error(L.ck_cat_detect_corners(hd, K, w, h, P, 32, None), "corners: null count")
+    expect_error(L.ck_cat_detect_corners(hd, None, w, h, P, 32, C.byref(n_pts)), "corners: null classes")
+    expect_error(L.ck_cat_check_edges(hd, K, w, h, P, -3, Ln, 16, C.byref(n_lines)), "edges: negative point count")
+    expect_error(L.ck_cat_check_edges(hd, K, w, h, None, 4, Ln, 16, C.byref(n_lines)), "edges: null points")
+    expect_error(L.ck_cat_check_edges(hd, K, w, h, P, 4, Ln, 16, None), "edges: null count")
+    expect_error(L.ck_cat_connected_components(hd, None, w, h, None, None), "components: nulls")
+    # process_frame: the reference asserts the buffer length (lib.rs:267)
+    rc = L.ck_cat_process_frame(hd, R, w * h * 3 - 1, w, h, K, P, 16, C.byref(n_pts), Ln, 16, C.byref(n_lines))
+    assert rc == A.CK_EINVAL
+    # the solver: counts and offsets that do not fit the arrays
+    prm = A.SqpnpParams(); L.ck_sqpnp_params_default(C.byref(prm))
+    prob = (A.SqpnpProblem * 1)(); res = (A.SqpnpResult * 1)()
+    tags = (A.Iso3 * 2)(); bearings = np.zeros(3 * 8)
+    for t in tags:
+        t.q[0] = 1.0
+    prob[0].robot_to_cam.q[0] = 1.0
+    B = bearings.ctypes.data
+    def solve(n=1, params=prm, out=res, n_tags_total=2, n_bearings_total=8, tg=tags, bp=B):
+        return L.ck_sqpnp_solve_batch(hd, C.byref(params) if params is not None else None, prob, n, tg, n_tags_total, bp,
+                                      n_bearings_total, out)
+    prob[0].n_tags, prob[0].n_bearings, prob[0].tag_offset, prob[0].bearing_offset = 2, 8, 1, 0
+    expect_error(solve(), "solver: tags 1..2 of 2")
+    prob[0].tag_offset, prob[0].bearing_offset = 0, 4
+    expect_error(solve(), "solver: bearings 4..11 of 8")
+    prob[0].bearing_offset, prob[0].tag_offset = -1, 0
+    expect_error(solve(), "solver: negative bearing offset")
+    prob[0].bearing_offset, prob[0].tag_offset = 0, 2**31 - 1
+    expect_error(solve(), "solver: tag offset + count wraps")
+    prob[0].tag_offset, prob[0].n_tags = 0, -1
+    expect_error(solve(), "solver: negative tag count")
+    prob[0].n_tags = 2
+    expect_error(solve(params=None), "solver: null parameters")
+    expect_error(solve(n=-1), "solver: negative problem count")
+    expect_error(solve(out=None), "solver: null results")
+    expect_error(solve(tg=None), "solver: null tags")
+    expect_error(solve(bp=None), "solver: null bearings")
+    assert not bad, bad
+    # a well-formed but unsolvable problem (all-zero bearings) is a result with valid = 0, not an error; no problems is a no-op
+    assert solve() == 0 and res[0].valid == 0
+    assert solve(n=0) == 0
+    # and the handle still classifies a frame
+    assert L.ck_cat_calc_otsu(hd, R, w, h, K) == 0 and set(np.unique(cls)) <= {0, 1, 2}
+    det.close()
