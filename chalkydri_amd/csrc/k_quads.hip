@@ -32,6 +32,7 @@ struct FitArgs {
     double cos_critical, max_mse;
     ck_stage_ws ws;
     int stop_after;         // diagnostics (CK_FIT_STOP_AFTER): end every cluster after phase k; 99 = run everything
+    int guided;             // chunks handed out by the work counter shrink towards the end of the list
     int list_cap;           // capacity of one class list
     const uint32_t *list;   // work list of this size class: frame << 20 | cluster index
     const uint32_t *list_count;
@@ -543,7 +544,7 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(WPS, 8))) v
     constexpr int LPM = (CAP > 4096) ? 32 : (NTH >= MAXSEL * 8) ? 8 : 4; // lanes per selected maximum, G / LPM points each
     static_assert(MAXSEL * LPM <= NTH && CH % G == 0, "one lane group per selected maximum");
     constexpr int NG = CAP / G;
-    constexpr int MAXM = MLDS ? CAP / 2 : 1;
+    constexpr int MAXM = MLDS ? (CAP / 2 > 2 * MAXSEL * 6 ? CAP / 2 : 2 * MAXSEL * 6) : 1;
     // sKeys holds the 64-bit sort keys; after duplicate removal its first half is reused for the packed
     // coordinates (x<<13|y, u32) and the third quarter for the u16 weights.
     __shared__ unsigned long long sKeysL[GK ? 1 : CAP];
@@ -573,7 +574,7 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(WPS, 8))) v
     __shared__ double sQuad[4][2];
     // per edge, per sample of the current round: refined point (x,y); x = NaN: no point.  Lives in the pair-fit table's bytes
     double (*sRefine)[16][2] = reinterpret_cast<double (*)[16][2]>(sPraw);
-    static_assert(SPB >= 2 * (1024 + 1) * 4 || CAP <= 512, "sort histogram must fit in sPraw");
+    static_assert(SPB >= ((CAP < 2048 ? CAP : 2048) + 1) * 4 || CAP <= 512, "sort histogram must fit in sPraw");
     long long (*sP64)[SL] = reinterpret_cast<long long (*)[SL]>(sPraw);            // [3][SL]: Mxx, Mxy, Myy
     uint32_t (*sP32)[SL] = reinterpret_cast<uint32_t (*)[SL]>(sPraw + 24 * SL);     // [3][SL]: Mx, My, W
     const int tid = threadIdx.x;
@@ -594,17 +595,22 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(WPS, 8))) v
     // The first chunk of every workgroup is its own (no atomic: a launch with little or no work — one frame per call, an empty
     // class — must not queue thousands of adds on one address); the counter hands out what lies beyond those.
     const uint32_t static_total = gridDim.x * DQ;
-    uint32_t chunk_base = blockIdx.x * DQ, chunk_left = DQ;
+    uint32_t chunk_base = blockIdx.x * DQ, chunk_left = DQ, chunk_len = DQ, dq_next = DQ;
     for (;;) {
         __syncthreads();
         if (chunk_left == 0) {
             if (static_total >= n_work) break;
-            if (tid == 0) sWork = static_total + atomicAdd(a.head, DQ);
+            if (tid == 0) sWork = static_total + atomicAdd(a.head, dq_next);
             __syncthreads();
             chunk_base = sWork;
-            chunk_left = DQ;
+            if (chunk_base >= n_work) break;
+            chunk_left = chunk_len = dq_next;
+            if (a.guided) { // the chunks shrink towards the end of the list: the launch's tail is one cluster, not one chunk
+                const uint32_t g = (n_work - chunk_base) / (gridDim.x * 2u);
+                dq_next = g < 1u ? 1u : (g > DQ ? DQ : g);
+            }
         }
-        const uint32_t work = chunk_base + (DQ - chunk_left);
+        const uint32_t work = chunk_base + (chunk_len - chunk_left);
         chunk_left--;
         if (work >= n_work) break;
         const uint32_t item = a.list[work];
@@ -1283,13 +1289,13 @@ __global__ __launch_bounds__(256) void k_weight_image(const uint8_t *__restrict_
 
 // builds the per-size-class work lists from the cluster tables: one workgroup per frame counts its clusters per class in
 // LDS, reserves the four list ranges with four global atomics, then writes (the lists' internal order is irrelevant)
-__global__ __launch_bounds__(1024) void k_classify(ck_stage_ws ws, int n, uint32_t *lists, uint32_t *list_counts, int list_cap) {
+__global__ __launch_bounds__(1024) void k_classify(ck_stage_ws ws, int n, uint32_t *lists, uint32_t *list_counts, int list_cap, int split) {
     __shared__ uint32_t sCnt[CK_FIT_CLASSES], sBase[CK_FIT_CLASSES];
     const int frame = blockIdx.x, tid = threadIdx.x;
     const uint32_t *counters = ws.d_counters + (size_t)frame * CK_CNT_STRIDE;
     const uint32_t nc = counters[CK_CNT_CLUSTERS];
     const ck_cluster_t *cls = ws.d_clusters + (size_t)frame * ws.cluster_cap;
-    auto class_of = [](uint32_t c) { return c <= 512 ? 0 : (c <= 2048 ? 1 : (c <= 4096 ? 2 : (c <= 8192 ? 3 : (c <= 16384 ? 4 : 5)))); };
+    auto class_of = [split](uint32_t c) { return (c <= 256 && (split & 2)) ? 7 : c <= 512 ? 0 : (c <= 1024 && (split & 1)) ? 6 : (c <= 2048 ? 1 : (c <= 4096 ? 2 : (c <= 8192 ? 3 : (c <= 16384 ? 4 : 5)))); };
     if (tid < CK_FIT_CLASSES) sCnt[tid] = 0;
     __syncthreads();
     // (a cluster without points is one k_scan had no room for: skipped)
@@ -1326,7 +1332,8 @@ int ck_launch_fit_quads(ck_handle *h, const uint8_t *qframes, int qstride, size_
     const ck_fit_layout fl = ck_fit_scratch_layout(ws, h->cfg.max_batch);
     const int list_cap = fl.list_cap;
     uint32_t *lists = fl.lists, *list_counts = fl.list_counts, *heads = fl.heads;
-    hipLaunchKernelGGL(k_classify, dim3((unsigned)n), dim3(1024), 0, h->stream, ws, n, lists, list_counts, list_cap);
+    static const int fit_split = getenv("CK_FIT_SPLIT") ? atoi(getenv("CK_FIT_SPLIT")) : 3; // (diagnostics: bit 0 = 513..1024 points have their own class, bit 1 = up to 256 points have)
+    hipLaunchKernelGGL(k_classify, dim3((unsigned)n), dim3(1024), 0, h->stream, ws, n, lists, list_counts, list_cap, fit_split);
     FitArgs a;
     a.qim = qframes; a.qw = h->qw; a.qh = h->qh; a.qstride = qstride; a.qpitch = qpitch;
     a.wimg = ws.d_wimg;
@@ -1348,15 +1355,17 @@ int ck_launch_fit_quads(ck_handle *h, const uint8_t *qframes, int qstride, size_
     if (a.min_tag_width < 3) a.min_tag_width = 3;
     a.ws = ws; a.list_cap = list_cap;
     { const char *e = getenv("CK_FIT_STOP_AFTER"); a.stop_after = e ? atoi(e) : 99; }
+    { const char *e = getenv("CK_FIT_GUIDED"); a.guided = e ? atoi(e) : 1; }
     // chunk sizes: 512 points for the multi-wave classes (fewer scans and barriers per point, 9 % less halo work); their LDS
     // then sits at the occupancy steps — 52.9 KB (3 workgroups/CU), 80.5 KB (2/CU), ≈ 124 KB and ≈ 163 KB (1/CU each)
     int cus = 256;
     // A small call (one frame per call is the reference's own pattern) gives every class a handful of workgroups whose time is
     // one cluster's dependency chain: the classes then run side by side on their own streams instead of one after the other.
-    const bool side_by_side = n <= CK_FIT_PARALLEL_MAX_FRAMES;
+    static const int force_par = getenv("CK_FIT_PAR") ? atoi(getenv("CK_FIT_PAR")) : 0;
+    const bool side_by_side = n <= CK_FIT_PARALLEL_MAX_FRAMES || force_par;
     // three lanes of similar length for a typical frame: {S, M1} on the handle's stream, {L1} and {M2, L2} on the side streams
     // (more streams than that end up sharing hardware queues and wait for each other anyway)
-    hipStream_t cs[CK_FIT_CLASSES] = {h->stream, h->stream, h->stream, h->stream, h->stream, h->stream};
+    hipStream_t cs[CK_FIT_CLASSES] = {h->stream, h->stream, h->stream, h->stream, h->stream, h->stream, h->stream, h->stream};
     if (side_by_side) {
         cs[3] = h->fit_stream[0]; cs[2] = h->fit_stream[1]; cs[4] = h->fit_stream[1];
         CK_HIP(hipEventRecord(h->ev_fit_fork, h->stream));
@@ -1367,6 +1376,8 @@ int ck_launch_fit_quads(ck_handle *h, const uint8_t *qframes, int qstride, size_
         switch (c) {
         case 0: { static const int s_wgs = getenv("CK_FIT_S_WGS") ? atoi(getenv("CK_FIT_S_WGS")) : 12; // (diagnostics: workgroups per CU of the small class)
             hipLaunchKernelGGL((k_fit<64, 512, 64, true, 3>), dim3((unsigned)(cus * s_wgs)), dim3(64), 0, cs[c], a); break; }
+        case 7: hipLaunchKernelGGL((k_fit<64, 256, 64, true, 4>), dim3((unsigned)(cus * 16)), dim3(64), 0, cs[c], a); break;
+        case 6: hipLaunchKernelGGL((k_fit<128, 1024, 128, true, 3>), dim3((unsigned)(cus * 6)), dim3(128), 0, cs[c], a); break;
         case 1: hipLaunchKernelGGL((k_fit<256, 2048, 512, true, 3>), dim3((unsigned)(cus * 3)), dim3(256), 0, cs[c], a); break;
         case 2: hipLaunchKernelGGL((k_fit<256, 4096, 512, true, 2>), dim3((unsigned)(cus * 2)), dim3(256), 0, cs[c], a); break;
         case 3: hipLaunchKernelGGL((k_fit<512, 8192, 512, true, 2>), dim3((unsigned)cus), dim3(512), 0, cs[c], a); break;
@@ -1376,8 +1387,8 @@ int ck_launch_fit_quads(ck_handle *h, const uint8_t *qframes, int qstride, size_
             break;
         }
     };
-    if (side_by_side) { launch(3); launch(2); launch(4); launch(0); launch(1); launch(5); } // the side lanes first, then the handle's own
-    else for (int c = 0; c < CK_FIT_CLASSES; c++) launch(c);
+    if (side_by_side) { launch(3); launch(2); launch(4); launch(7); launch(0); launch(6); launch(1); launch(5); } // the side lanes first, then the handle's own
+    else { launch(7); launch(0); launch(6); for (int c = 1; c < 6; c++) launch(c); }
     if (side_by_side)
         for (int k = 0; k < CK_FIT_SIDE_STREAMS; k++) {
             CK_HIP(hipEventRecord(h->ev_fit_join[k], h->fit_stream[k]));
