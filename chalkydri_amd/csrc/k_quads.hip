@@ -248,10 +248,10 @@ struct ComboTable {
     uint16_t v[495];
     constexpr ComboTable() : v() {
         int k = 0;
-        for (int m0 = 0; m0 < MAXSEL - 3; m0++)
-            for (int m1 = m0 + 1; m1 < MAXSEL - 2; m1++)
-                for (int m2 = m1 + 1; m2 < MAXSEL - 1; m2++)
-                    for (int m3 = m2 + 1; m3 < MAXSEL; m3++) v[k++] = (uint16_t)((m0 << 12) | (m1 << 8) | (m2 << 4) | m3);
+        for (int m3 = 3; m3 < MAXSEL; m3++) // ordered by the largest member: the subsets of {0..nsel-1} are the first C(nsel, 4) entries
+            for (int m2 = 2; m2 < m3; m2++)
+                for (int m1 = 1; m1 < m2; m1++)
+                    for (int m0 = 0; m0 < m1; m0++) v[k++] = (uint16_t)((m0 << 12) | (m1 << 8) | (m2 << 4) | m3);
     }
 };
 __device__ const ComboTable g_combo_table{}; // built at compile time: nothing to upload, valid on every device of the process
@@ -1018,10 +1018,10 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(WPS, 8))) v
         double best = HUGE_VAL;
         int bestc = 1 << 30;
         {
-            for (int cb = tid; cb < 495; cb += NTH) { // every lane walks its own subsets; ties resolved by the packed index
+            const int ncomb = nsel * (nsel - 1) * (nsel - 2) * (nsel - 3) / 24;
+            for (int cb = tid; cb < ncomb; cb += NTH) { // every lane walks its own subsets; ties resolved by the packed index
                 const int pk = g_combo_table.v[cb];
                 const int m0 = pk >> 12, m1 = (pk >> 8) & 15, m2 = (pk >> 4) & 15, m3 = pk & 15;
-                if (m3 >= nsel) continue;
                 {
                     {
                         {
