@@ -771,6 +771,11 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(WPS, 8))) v
             const int chn = min(CH, sz - cbase);
             const int sl = chn + 2 * HALO;
             constexpr int EPT = (SL + NTH - 1) / NTH;
+            // The errors of the points cbase-4 .. cbase+3 were formed by the previous chunk (its last eight: window sums are exact
+            // integers, so the value of a point does not depend on the chunk that forms it).  Carried over, this chunk forms
+            // exactly chn errors — one round of the lanes for a full chunk instead of two with the second nearly empty.
+            double carry = 0.0;
+            if (c > 0 && tid < 8) carry = sErr[HALO + CH - 4 + tid];
             M6 loc[EPT];
             M6 run = m6_zero();
 #pragma unroll
@@ -812,7 +817,8 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(WPS, 8))) v
                     }
                 }
             }
-            for (int j = HALO - 4 + tid; j < HALO + chn + 4; j += NTH) {
+            if (c > 0 && tid < 8) sErr[HALO - 4 + tid] = carry;
+            for (int j = (c > 0 ? HALO + 4 : HALO - 4) + tid; j < HALO + chn + 4; j += NTH) {
                 int hi = j + ksz, lo = j - ksz - 1;
                 uint32_t mx = sP32[0][hi], my = sP32[1][hi], mw = sP32[2][hi];
                 M6 m;
