@@ -988,9 +988,8 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(WPS, 8))) v
         if (a.stop_after == 6) continue;
         // ---- 5c. one line fit per ordered pair of maxima; the 4-subset search is then table lookups ------------------------
         PairFit *sF = reinterpret_cast<PairFit *>(sPraw);
-        {   // lane k takes the pair a < b from the table and fits both directions in one go: a -> b with the line normal
-            // (the subset search reads normals of forward spans only), b -> a around the end without it; the two f64
-            // dependency chains overlap
+        {   // lane k takes the pair a < b from the table and fits both directions in one go (a -> b, and b -> a around the
+            // end); the two f64 dependency chains overlap
             const int npf = nsel * (nsel - 1) / 2;
             if constexpr (NTH > 64) { // enough lanes for one fit each
                 const int npairs = nsel * nsel;
@@ -1010,13 +1009,13 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(WPS, 8))) v
                 const int pk = g_pair_table.v[k], sa = pk >> 4, sb = pk & 15;
                 int Nf, Nw;
                 const M6 mf = rangeM(sa, sb, &Nf), mw = rangeM(sb, sa, &Nw);
-                double lp[4], ef, msf, ew, msw;
+                double lp[4], lq[4], ef, msf, ew, msw;
                 fit_line_m(mf, Nf, lp, &ef, &msf);
-                fit_line_m(mw, Nw, nullptr, &ew, &msw);
+                fit_line_m(mw, Nw, lq, &ew, &msw);
                 PairFit f;
                 f.err = ef; f.mse = msf; f.nx = lp[2]; f.ny = lp[3];
                 sF[sa * MAXSEL + sb] = f;
-                f.err = ew; f.mse = msw; f.nx = 0.0; f.ny = 0.0;
+                f.err = ew; f.mse = msw; f.nx = lq[2]; f.ny = lq[3];
                 sF[sb * MAXSEL + sa] = f;
             }
         }
@@ -1075,12 +1074,16 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(WPS, 8))) v
             const int sel[4] = {(bestc >> 12) & 15, (bestc >> 8) & 15, (bestc >> 4) & 15, bestc & 15};
             int ok = 1;
             double line[4];
-            {
+            {   // the side's line: normal and mse are in the pair table already (the same fit of the same sums), only the
+                // point on the line (the weighted mean) is formed here
                 int N;
-                double mse;
-                M6 m = rangeM(sel[li], sel[(li + 1) & 3], &N);
-                fit_line_m(m, N, line, nullptr, &mse);
-                if (mse > a.max_mse) ok = 0;
+                const int s0 = sel[li], s1 = sel[(li + 1) & 3];
+                const M6 m = rangeM(s0, s1, &N);
+                const PairFit pf = sF[s0 * MAXSEL + s1];
+                const double inv = 1.0 / (double)m.W;
+                line[0] = (0.5 * (double)m.Mx) * inv; line[1] = (0.5 * (double)m.My) * inv;
+                line[2] = pf.nx; line[3] = pf.ny;
+                if (pf.mse > a.max_mse) ok = 0;
             }
             double ln[4]; // the next side's line
 #pragma unroll
