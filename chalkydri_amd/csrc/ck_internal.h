@@ -40,8 +40,10 @@ struct ck_dev_family {
 };
 
 // One boundary point while it waits to be grouped (k_clusters.hip)
-// size classes of the quad fit (k_quads.hip): <= 512, <= 2048, <= 4096, <= 8192, <= 16384 points per cluster, and the rest (up to
-// 3 * (2w + 2h): only frames with more than 2730 pixels of half-perimeter can have such clusters)
+// size classes of the quad fit (k_quads.hip), by list index: 0: 257..512 points per cluster, 1: 1025..2048, 2: <= 4096, 3: <= 8192,
+// 4: <= 16384, 5: the rest (up to 3 * (2w + 2h): only frames with more than 2730 pixels of half-perimeter can have such clusters),
+// 6: 513..1024, 7: <= 256 (the two youngest classes took the free indices: a cluster's cost is mostly per cluster, not per
+// point, so the small ones run on small workgroups, many per CU)
 constexpr int CK_FIT_CLASSES = 8;
 constexpr int CK_HUGE_CAP = 65536, CK_HUGE_WGS = 256; // largest class: points per cluster (3 * 4 * 4095 < 65536), workgroups in its grid
 constexpr int CK_FIT_PARALLEL_MAX_FRAMES = 4; // calls with at most this many frames run the classes side by side ...

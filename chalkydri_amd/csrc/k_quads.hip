@@ -15,8 +15,8 @@
 //   5. the max_nmaxima strongest maxima (rank-based selection), moment sums at them from a 32/128-point table, one line
 //      fit per ordered pair, every 4-subset evaluated in parallel (argmin with the oracle's lexicographic tie-break);
 //   6. lines, corners, area/angle/winding checks on four lanes, wave-parallel edge refinement.
-// Clusters are dispatched through per-size-class work lists built by k_classify (<= 512, <= 2048, <= 4096, <= 8192,
-// <= 16384 points, and the rest); each variant is a persistent grid whose workgroups take a first chunk of their list by index and the
+// Clusters are dispatched through per-size-class work lists built by k_classify (<= 256, <= 512, <= 1024, <= 2048, <= 4096,
+// <= 8192, <= 16384 points, and the rest); each variant is a persistent grid whose workgroups take a first chunk of their list by index and the
 // rest from a dequeue counter.  The phases can be cut short for measurements with CK_FIT_STOP_AFTER (tools/ablate_fit.sh).
 #include <stdlib.h>
 
