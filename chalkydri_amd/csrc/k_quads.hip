@@ -1386,7 +1386,7 @@ int ck_launch_fit_quads(ck_handle *h, const uint8_t *qframes, int qstride, size_
         case 0: { static const int s_wgs = getenv("CK_FIT_S_WGS") ? atoi(getenv("CK_FIT_S_WGS")) : 12; // (diagnostics: workgroups per CU of the small class)
             hipLaunchKernelGGL((k_fit<64, 512, 64, true, 3>), dim3((unsigned)(cus * s_wgs)), dim3(64), 0, cs[c], a); break; }
         case 7: hipLaunchKernelGGL((k_fit<64, 256, 64, true, 4>), dim3((unsigned)(cus * 16)), dim3(64), 0, cs[c], a); break;
-        case 6: hipLaunchKernelGGL((k_fit<128, 1024, 128, true, 3>), dim3((unsigned)(cus * 6)), dim3(128), 0, cs[c], a); break;
+        case 6: hipLaunchKernelGGL((k_fit<128, 1024, 128, true, 4>), dim3((unsigned)(cus * 7)), dim3(128), 0, cs[c], a); break;
         case 1: hipLaunchKernelGGL((k_fit<256, 2048, 512, true, 3>), dim3((unsigned)(cus * 3)), dim3(256), 0, cs[c], a); break;
         case 2: hipLaunchKernelGGL((k_fit<256, 4096, 512, true, 2>), dim3((unsigned)(cus * 2)), dim3(256), 0, cs[c], a); break;
         case 3: hipLaunchKernelGGL((k_fit<512, 8192, 512, true, 2>), dim3((unsigned)cus), dim3(512), 0, cs[c], a); break;
