@@ -1387,7 +1387,7 @@ int ck_launch_fit_quads(ck_handle *h, const uint8_t *qframes, int qstride, size_
             hipLaunchKernelGGL((k_fit<64, 512, 64, true, 3>), dim3((unsigned)(cus * s_wgs)), dim3(64), 0, cs[c], a); break; }
         case 7: hipLaunchKernelGGL((k_fit<64, 256, 64, true, 4>), dim3((unsigned)(cus * 16)), dim3(64), 0, cs[c], a); break;
         case 6: hipLaunchKernelGGL((k_fit<128, 1024, 128, true, 4>), dim3((unsigned)(cus * 7)), dim3(128), 0, cs[c], a); break;
-        case 1: hipLaunchKernelGGL((k_fit<256, 2048, 512, true, 3>), dim3((unsigned)(cus * 3)), dim3(256), 0, cs[c], a); break;
+        case 1: hipLaunchKernelGGL((k_fit<256, 2048, 224, true, 4>), dim3((unsigned)(cus * 4)), dim3(256), 0, cs[c], a); break;
         case 2: hipLaunchKernelGGL((k_fit<256, 4096, 512, true, 2>), dim3((unsigned)(cus * 2)), dim3(256), 0, cs[c], a); break;
         case 3: hipLaunchKernelGGL((k_fit<512, 8192, 512, true, 2>), dim3((unsigned)cus), dim3(512), 0, cs[c], a); break;
         case 4: hipLaunchKernelGGL((k_fit<512, 16384, 512, false, 2>), dim3((unsigned)cus), dim3(512), 0, cs[c], a); break;
