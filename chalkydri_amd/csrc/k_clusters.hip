@@ -131,7 +131,11 @@ __global__ __launch_bounds__(NT) void k_emit(EmitArgs a) {
                 uint32_t s = key_hash(key) & (LHT - 1);
                 bool placed = false;
                 for (int probe = 0; probe < LHT; probe++) {
-                    unsigned long long prev = atomicCAS(&sKey[s], 0ull, key);
+                    // most points meet their key already in place: a plain read (lanes with one address are served together)
+                    // finds that out, and only a slot seen empty costs a compare-and-swap (same-address lanes one by one)
+                    __asm__ volatile("" ::: "memory");
+                    unsigned long long prev = sKey[s];
+                    if (prev == 0ull) prev = atomicCAS(&sKey[s], 0ull, key);
                     if (prev == 0ull || prev == key) { cand[rr * 4 + k] = (s << 16) | atomicAdd(&sCnt[s], 1u); placed = true; break; }
                     s = (s + 1) & (LHT - 1);
                 }
