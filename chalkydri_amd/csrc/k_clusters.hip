@@ -121,12 +121,27 @@ __global__ __launch_bounds__(NT) void k_emit(EmitArgs a) {
             int v0 = sT[ly][lx];
             uint32_t r0 = sR[ly][lx];
             if (r0 == SKIP) continue;
+            // the (up to four) points of a pixel often share their key — the three neighbours below are side by side, so when
+            // they are white they are one component: one slot search and ONE add per distinct key, the first point of the key
+            // doing it for the others (fewer LDS atomics, and fewer lanes on one address in each)
+            uint32_t r1v[4];
+            bool ok[4];
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                int v1 = sT[ly + dys[k]][lx + dxs[k]];
-                if (v0 + v1 != 255) continue;
-                uint32_t r1 = sR[ly + dys[k]][lx + dxs[k]];
-                if (r1 == SKIP) continue;
+                const int v1 = sT[ly + dys[k]][lx + dxs[k]];
+                r1v[k] = sR[ly + dys[k]][lx + dxs[k]];
+                ok[k] = (v0 + v1 == 255) && r1v[k] != SKIP;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                bool leader = ok[k];
+#pragma unroll
+                for (int j = 0; j < k; j++) leader = leader && !(ok[j] && r1v[j] == r1v[k]);
+                if (!leader) continue;
+                uint32_t n = 1;
+#pragma unroll
+                for (int j = k + 1; j < 4; j++) n += (ok[j] && r1v[j] == r1v[k]) ? 1u : 0u;
+                const uint32_t r1 = r1v[k];
                 unsigned long long key = r0 < r1 ? ((unsigned long long)r0 << 32) | r1 : ((unsigned long long)r1 << 32) | r0;
                 uint32_t s = key_hash(key) & (LHT - 1);
                 bool placed = false;
@@ -136,7 +151,15 @@ __global__ __launch_bounds__(NT) void k_emit(EmitArgs a) {
                     __asm__ volatile("" ::: "memory");
                     unsigned long long prev = sKey[s];
                     if (prev == 0ull) prev = atomicCAS(&sKey[s], 0ull, key);
-                    if (prev == 0ull || prev == key) { cand[rr * 4 + k] = (s << 16) | atomicAdd(&sCnt[s], 1u); placed = true; break; }
+                    if (prev == 0ull || prev == key) {
+                        uint32_t c = (s << 16) | atomicAdd(&sCnt[s], n);
+                        cand[rr * 4 + k] = c;
+#pragma unroll
+                        for (int j = k + 1; j < 4; j++)
+                            if (ok[j] && r1v[j] == r1) cand[rr * 4 + j] = ++c;
+                        placed = true;
+                        break;
+                    }
                     s = (s + 1) & (LHT - 1);
                 }
                 if (!placed) atomicOr(&counters[CK_CNT_STATUS], (uint32_t)CK_FRAME_CLUSTERS_OVERFLOW);
