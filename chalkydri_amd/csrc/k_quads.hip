@@ -1262,13 +1262,13 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(WPS, 8))) v
 // copy alike), so a group that starts inside a row is readable; the weight image's rows are qw entries long, so a width that is
 // not a multiple of 4 ends in a partial group and its stores go out one by one.
 __global__ __launch_bounds__(256) void k_weight_image(const uint8_t *__restrict__ qim, size_t qpitch, int qstride, int qw, int qh,
-                                                      uint16_t *__restrict__ wimg, size_t total4) {
-    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= total4) return;
+                                                      uint16_t *__restrict__ wimg) {
+    // block = 64 groups of four pixels x 4 rows; the grid's y and z are row blocks and frames (no index arithmetic to undo)
     const int w4 = (qw + 3) >> 2;
-    const size_t per_frame = (size_t)w4 * qh;
-    const size_t fr = i / per_frame, rem = i - fr * per_frame;
-    const int iy = (int)(rem / w4), ix = 4 * (int)(rem - (size_t)iy * w4);
+    const int g = blockIdx.x * 64 + (threadIdx.x & 63), iy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (g >= w4 || iy >= qh) return;
+    const size_t fr = blockIdx.z;
+    const int ix = 4 * g;
     uint16_t out[4] = {1, 1, 1, 1};
     if (iy > 0 && iy + 1 < qh) {
         const uint8_t *row = qim + fr * qpitch + (size_t)iy * qstride + ix;
@@ -1347,9 +1347,9 @@ int ck_launch_fit_quads(ck_handle *h, const uint8_t *qframes, int qstride, size_
     a.qim = qframes; a.qw = h->qw; a.qh = h->qh; a.qstride = qstride; a.qpitch = qpitch;
     a.wimg = ws.d_wimg;
     {
-        size_t total4 = (size_t)((h->qw + 3) / 4) * h->qh * (size_t)n;
-        hipLaunchKernelGGL(k_weight_image, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, h->stream, qframes, qpitch, qstride, h->qw, h->qh,
-                           ws.d_wimg, total4);
+        const int w4 = (h->qw + 3) / 4;
+        hipLaunchKernelGGL(k_weight_image, dim3((unsigned)((w4 + 63) / 64), (unsigned)((h->qh + 3) / 4), (unsigned)n), dim3(256), 0, h->stream, qframes,
+                           qpitch, qstride, h->qw, h->qh, ws.d_wimg);
     }
     a.im = frames; a.w = h->w; a.h = h->h; a.stride = stride; a.pitch = pitch;
     a.decimate = h->cfg.quad_decimate; a.refine = h->cfg.refine_edges; a.max_nmaxima = h->cfg.max_nmaxima;
