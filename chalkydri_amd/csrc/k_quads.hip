@@ -1389,7 +1389,7 @@ int ck_launch_fit_quads(ck_handle *h, const uint8_t *qframes, int qstride, size_
         case 6: hipLaunchKernelGGL((k_fit<128, 1024, 128, true, 4>), dim3((unsigned)(cus * 7)), dim3(128), 0, cs[c], a); break;
         case 1: hipLaunchKernelGGL((k_fit<256, 2048, 224, true, 4>), dim3((unsigned)(cus * 4)), dim3(256), 0, cs[c], a); break;
         case 2: hipLaunchKernelGGL((k_fit<256, 4096, 512, true, 2>), dim3((unsigned)(cus * 2)), dim3(256), 0, cs[c], a); break;
-        case 3: hipLaunchKernelGGL((k_fit<512, 8192, 512, true, 2>), dim3((unsigned)cus), dim3(512), 0, cs[c], a); break;
+        case 3: hipLaunchKernelGGL((k_fit<512, 8192, 896, true, 2>), dim3((unsigned)cus), dim3(512), 0, cs[c], a); break;
         case 4: hipLaunchKernelGGL((k_fit<512, 16384, 512, false, 2>), dim3((unsigned)cus), dim3(512), 0, cs[c], a); break;
         default: // more than 16384 points: only frames with more than 2730 pixels of half-perimeter have the buffer (and can have such clusters)
             if (ws.d_hscratch) hipLaunchKernelGGL((k_fit<512, CK_HUGE_CAP, 512, false, 2, true>), dim3((unsigned)CK_HUGE_WGS), dim3(512), 0, cs[c], a);
