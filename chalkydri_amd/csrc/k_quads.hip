@@ -1392,7 +1392,7 @@ int ck_launch_fit_quads(ck_handle *h, const uint8_t *qframes, int qstride, size_
         case 3: hipLaunchKernelGGL((k_fit<512, 8192, 896, true, 2>), dim3((unsigned)cus), dim3(512), 0, cs[c], a); break;
         case 4: hipLaunchKernelGGL((k_fit<512, 16384, 512, false, 2>), dim3((unsigned)cus), dim3(512), 0, cs[c], a); break;
         default: // more than 16384 points: only frames with more than 2730 pixels of half-perimeter have the buffer (and can have such clusters)
-            if (ws.d_hscratch) hipLaunchKernelGGL((k_fit<512, CK_HUGE_CAP, 512, false, 2, true>), dim3((unsigned)CK_HUGE_WGS), dim3(512), 0, cs[c], a);
+            if (ws.d_hscratch) hipLaunchKernelGGL((k_fit<512, CK_HUGE_CAP, 896, false, 2, true>), dim3((unsigned)CK_HUGE_WGS), dim3(512), 0, cs[c], a);
             break;
         }
     };
