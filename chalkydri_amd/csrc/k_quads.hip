@@ -1375,14 +1375,15 @@ int ck_launch_fit_quads(ck_handle *h, const uint8_t *qframes, int qstride, size_
     // three lanes of similar length for a typical frame: {S, M1} on the handle's stream, {L1} and {M2, L2} on the side streams
     // (more streams than that end up sharing hardware queues and wait for each other anyway)
     hipStream_t cs[CK_FIT_CLASSES] = {h->stream, h->stream, h->stream, h->stream, h->stream, h->stream, h->stream, h->stream};
-    // A batch keeps one lane, except for the two classes with one 512-thread workgroup per CU and a handful of clusters per
-    // workgroup (8193..16384 points: 2.2 on average, so a quarter of the CUs do a third cluster while the rest idle; and the
-    // largest): on a side stream, started first, their tail runs under the small classes instead of before them.
+    // A batch keeps one lane, except for the three classes with ONE 512-thread workgroup per CU (8193..16384 points: 2.2 clusters
+    // per workgroup on average, so a quarter of the CUs do a third cluster while the rest idle; the largest; 4097..8192): one after
+    // the other on a side stream, started first, their tails and barrier waits run under the small classes instead of before
+    // them.  (Measured: the 2049..4096 class there as well, or the three on two side streams, is slower than this.)
     static const int tails_aside_ok = (getenv("CK_FIT_TAILS_ASIDE") ? atoi(getenv("CK_FIT_TAILS_ASIDE")) : 1) &&
                                       (getenv("CK_STREAMS") ? atoi(getenv("CK_STREAMS")) : 1) < 2;
     const bool tails_aside = !side_by_side && tails_aside_ok;
     if (side_by_side) { cs[3] = h->fit_stream[0]; cs[2] = h->fit_stream[1]; cs[4] = h->fit_stream[1]; }
-    if (tails_aside) { cs[4] = h->fit_stream[0]; cs[5] = h->fit_stream[0]; }
+    if (tails_aside) { cs[4] = h->fit_stream[0]; cs[5] = h->fit_stream[0]; cs[3] = h->fit_stream[0]; }
     if (side_by_side || tails_aside) {
         CK_HIP(hipEventRecord(h->ev_fit_fork, h->stream));
         for (int k = 0; k < CK_FIT_SIDE_STREAMS; k++) CK_HIP(hipStreamWaitEvent(h->fit_stream[k], h->ev_fit_fork, 0));
@@ -1404,7 +1405,7 @@ int ck_launch_fit_quads(ck_handle *h, const uint8_t *qframes, int qstride, size_
         }
     };
     if (side_by_side) { launch(3); launch(2); launch(4); launch(7); launch(0); launch(6); launch(1); launch(5); } // the side lanes first, then the handle's own
-    else if (tails_aside) { launch(4); launch(5); launch(7); launch(0); launch(6); launch(1); launch(2); launch(3); }
+    else if (tails_aside) { launch(4); launch(5); launch(3); launch(7); launch(0); launch(6); launch(1); launch(2); }
     else { launch(7); launch(0); launch(6); for (int c = 1; c < 6; c++) launch(c); }
     if (side_by_side || tails_aside)
         for (int k = 0; k < CK_FIT_SIDE_STREAMS; k++) {
