@@ -1342,7 +1342,14 @@ int ck_launch_fit_quads(ck_handle *h, const uint8_t *qframes, int qstride, size_
     const int list_cap = fl.list_cap;
     uint32_t *lists = fl.lists, *list_counts = fl.list_counts, *heads = fl.heads;
     static const int fit_split = getenv("CK_FIT_SPLIT") ? atoi(getenv("CK_FIT_SPLIT")) : 3; // (diagnostics: bit 0 = 513..1024 points have their own class, bit 1 = up to 256 points have)
-    hipLaunchKernelGGL(k_classify, dim3((unsigned)n), dim3(1024), 0, h->stream, ws, n, lists, list_counts, list_cap, fit_split);
+    // A small call (one frame per call is the reference's own pattern) gives every class a handful of workgroups whose time is
+    // one cluster's dependency chain: the classes then run side by side on their own streams instead of one after the other —
+    // and without the two youngest classes, which exist for throughput (more clusters in flight per CU) and would only add two
+    // more chains to the handle's lane (0.64 -> 0.70 ms per 1280x800 frame at quad_decimate 2).
+    static const int force_par = getenv("CK_FIT_PAR") ? atoi(getenv("CK_FIT_PAR")) : 0;
+    const bool side_by_side = n <= CK_FIT_PARALLEL_MAX_FRAMES || force_par;
+    const int split = side_by_side ? 0 : fit_split;
+    hipLaunchKernelGGL(k_classify, dim3((unsigned)n), dim3(1024), 0, h->stream, ws, n, lists, list_counts, list_cap, split);
     FitArgs a;
     a.qim = qframes; a.qw = h->qw; a.qh = h->qh; a.qstride = qstride; a.qpitch = qpitch;
     a.wimg = ws.d_wimg;
@@ -1368,10 +1375,6 @@ int ck_launch_fit_quads(ck_handle *h, const uint8_t *qframes, int qstride, size_
     // chunk sizes: 512 points for the multi-wave classes (fewer scans and barriers per point, 9 % less halo work); their LDS
     // then sits at the occupancy steps — 52.9 KB (3 workgroups/CU), 80.5 KB (2/CU), ≈ 124 KB and ≈ 163 KB (1/CU each)
     int cus = 256;
-    // A small call (one frame per call is the reference's own pattern) gives every class a handful of workgroups whose time is
-    // one cluster's dependency chain: the classes then run side by side on their own streams instead of one after the other.
-    static const int force_par = getenv("CK_FIT_PAR") ? atoi(getenv("CK_FIT_PAR")) : 0;
-    const bool side_by_side = n <= CK_FIT_PARALLEL_MAX_FRAMES || force_par;
     // three lanes of similar length for a typical frame: {S, M1} on the handle's stream, {L1} and {M2, L2} on the side streams
     // (more streams than that end up sharing hardware queues and wait for each other anyway)
     hipStream_t cs[CK_FIT_CLASSES] = {h->stream, h->stream, h->stream, h->stream, h->stream, h->stream, h->stream, h->stream};
@@ -1404,7 +1407,7 @@ int ck_launch_fit_quads(ck_handle *h, const uint8_t *qframes, int qstride, size_
             break;
         }
     };
-    if (side_by_side) { launch(3); launch(2); launch(4); launch(7); launch(0); launch(6); launch(1); launch(5); } // the side lanes first, then the handle's own
+    if (side_by_side) { launch(3); launch(2); launch(4); launch(0); launch(1); launch(5); } // the side lanes first, then the handle's own
     else if (tails_aside) { launch(4); launch(5); launch(3); launch(7); launch(0); launch(6); launch(1); launch(2); }
     else { launch(7); launch(0); launch(6); for (int c = 1; c < 6; c++) launch(c); }
     if (side_by_side || tails_aside)
