@@ -1,5 +1,5 @@
 """Randomised check that a frame's result does not depend on the call that carries it: whole batches (one stream, or split over
-two with CK_STREAMS=2 / CK_PARTS), calls of at most four frames (their fit classes run side by side on three streams) and
+two with CK_STREAMS=2 / CK_PARTS), calls of at most four frames (calls of up to 16 run their fit classes side by side on three streams) and
 single-frame calls must return the same bytes per frame — detections and 64-byte pose records.
 usage: [CK_STREAMS=2 CK_PARTS=3] python tests/stress_batch.py [cases] [seed]"""
 import os, sys, json
@@ -19,7 +19,7 @@ def run(cases, seed):
     bad = 0
     for c in range(cases):
         w = int(rng.integers(320, 1040)); h = int(rng.integers(240, 720))   # any width and height, odd ones included
-        n = int(rng.integers(2, 13))
+        n = int(rng.integers(2, 41))   # up to 16 frames run the fit classes side by side, more on one lane plus the tail stream
         dec = int(rng.choice([1, 2]))
         frames, gyro, layout, calib, r2c = scenes.bench_stream(3, n, w, h, int(rng.integers(1, 7)), stream=int(rng.integers(0, 50)), unique=n,
                                                                noise_amp=int(rng.choice([0, 1, 3])))
