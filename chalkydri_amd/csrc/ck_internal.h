@@ -46,7 +46,7 @@ struct ck_dev_family {
 // point, so the small ones run on small workgroups, many per CU)
 constexpr int CK_FIT_CLASSES = 8;
 constexpr int CK_HUGE_CAP = 65536, CK_HUGE_WGS = 256; // largest class: points per cluster (3 * 4 * 4095 < 65536), workgroups in its grid
-constexpr int CK_FIT_PARALLEL_MAX_FRAMES = 16; // calls with at most this many frames run the classes side by side (measured at 1280x800: faster up to 16 frames at quad_decimate 1 and 2, at 32 only at 2)
+constexpr int CK_FIT_PARALLEL_MAX_FRAMES = 16; // calls with at most this many frames (twice as many at quad_decimate >= 2) run the classes side by side
 constexpr int CK_FIT_SIDE_STREAMS = 2;         // ... on the handle's stream and this many more (a process has few hardware queues)
 constexpr int CK_LSCRATCH_PER_WG = 16384, CK_LSCRATCH_WGS = 1024; // large class: points per cluster, workgroups in its grid (at most)
 

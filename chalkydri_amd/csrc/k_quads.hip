@@ -1347,7 +1347,8 @@ int ck_launch_fit_quads(ck_handle *h, const uint8_t *qframes, int qstride, size_
     // and without the two youngest classes, which exist for throughput (more clusters in flight per CU) and would only add two
     // more chains to the handle's lane (0.64 -> 0.70 ms per 1280x800 frame at quad_decimate 2).
     static const int force_par = getenv("CK_FIT_PAR") ? atoi(getenv("CK_FIT_PAR")) : 0;
-    const bool side_by_side = n <= CK_FIT_PARALLEL_MAX_FRAMES || force_par;
+    // (measured at 1280x800: side by side wins up to 16 frames at quad_decimate 1, up to 32 at 2, where the clusters are fewer)
+    const bool side_by_side = n <= (h->cfg.quad_decimate > 1 ? 2 * CK_FIT_PARALLEL_MAX_FRAMES : CK_FIT_PARALLEL_MAX_FRAMES) || force_par;
     const int split = side_by_side ? 0 : fit_split;
     hipLaunchKernelGGL(k_classify, dim3((unsigned)n), dim3(1024), 0, h->stream, ws, n, lists, list_counts, list_cap, split);
     FitArgs a;
