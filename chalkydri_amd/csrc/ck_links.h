@@ -113,4 +113,39 @@ CK_HD ck_word_links ck_links_of_word(bool white, uint32_t M, uint32_t U, uint32_
     return L;
 }
 
+// ---- nodes over PAIRS of rows ----------------------------------------------------------------------------------------------
+// k_tile's union-find nodes are the components of 2 x 32 pixel blocks (rows 2p and 2p + 1 of a tile, one 32-pixel word, one
+// colour): dense binary noise has about half as many of them as it has one-row runs, and every per-node phase of the kernel
+// (adoption, sweep, unions, flatten, sizes) shrinks with them.  Inside two rows the components are a chain: with the pixels
+// of the frame's two NON-ORIGIN columns (0 and w - 1, which initiate no join) taken out of the masks, the two pixels of a
+// column are always joined (the lower one joins up), so a column is a unit and the block's components are the maximal
+// stretches of columns in which every column is joined to the one on its left:
+//     black (4-connected): the two columns share a row                       (Mt & Mt<<1) | (Mb & Mb<<1)
+//     white (8-connected): both are occupied (any two pixels of neighbouring columns are at most one row apart)
+// A node's entries in the kernel's parent array sit at two pixels: its LOOKUP pixel — the pixel of its first column, the top
+// one when that column has both — which every pixel of the node finds with a count-leading-zeros on the start mask, and its
+// MIN pixel (its first top-row pixel when it has one, else the lookup pixel), which orders the union-find: the root of a
+// component is the node with the smallest min pixel, i.e. the component's smallest pixel index, the canonical label.  Where the
+// two differ the lookup pixel's entry simply points at the min pixel (it lies in the row above: parent < self holds).
+// The pixels of the non-origin columns are single-pixel nodes of their own, joined by what the rule lets their origin
+// neighbours do; only tiles at the frame's left / right edge have them.
+// All masks passed to these functions are already ANDed with the word's origin flags.
+CK_HD uint32_t ck_pair_link32(bool white, uint32_t Mt, uint32_t Mb, bool lt31, bool lb31) { // bit x: column x continues column x - 1 (bit 0: pixel 31 of the word on the left)
+    const uint32_t Lt = (Mt << 1) | (lt31 ? 1u : 0u), Lb = (Mb << 1) | (lb31 ? 1u : 0u);
+    return white ? ((Mt | Mb) & (Lt | Lb)) : ((Mt & Lt) | (Mb & Lb));
+}
+CK_HD uint32_t ck_pair_starts32(uint32_t Mt, uint32_t Mb, uint32_t link) { return (Mt | Mb) & ~(link & ~1u); } // column 0 starts a node of the word (bit 0 of link: joined across the word boundary)
+// the columns of the node that starts at column s: up to the next start (trailing empty columns included: they hold no pixel)
+CK_HD uint32_t ck_span32(uint32_t S, int s) {
+    const uint32_t next = S & ~ck_upto32(s);
+    const uint32_t lim = next ? ((next & (0u - next)) - 1u) : 0xFFFFFFFFu;
+    return lim & ~((1u << s) - 1u);
+}
+// word-local pixel of a node's lookup entry / min entry: row (0 top, 1 bottom) << 5 | column
+CK_HD int ck_pair_lookup(uint32_t Mt, int s) { return (((Mt >> s) & 1u) ? 0 : 32) + s; }
+CK_HD int ck_pair_min(uint32_t Mt, uint32_t span, int s) {
+    const uint32_t T = Mt & span;
+    return T ? ck_ctz32(T) : 32 + s;
+}
+
 #endif

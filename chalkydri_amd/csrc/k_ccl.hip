@@ -36,13 +36,18 @@ constexpr int NWD = TW / 32;                     // 32-pixel words per tile row
 constexpr int IMG_PITCH = 160;                   // 16 left halo | 128 tile | 16 right halo (only 8 + 8 of the halo are used)
 constexpr int IMG_ROWS = TH + 8;
 constexpr int T4X = TW / 4 + 2, T4Y = TH / 4 + 2; // 4x4-tile min/max grid of the staged region (one ring around the tile's own)
-static_assert(TH * NWD * 2 == KNT, "k_tile thread mapping: row x word x colour");
+static_assert((TH / 2) * NWD == 64, "k_tile node phases: one wave per colour, one lane per (pair of rows, word)");
 static_assert(TH * 8 == KNT, "threshold / label passes: one 16-pixel chunk per thread");
 static_assert(TH * TW <= 4096, "run list entries keep the node in 12 bits, the colour in bit 12");
 static_assert(TW == 128, "a node index splits with >> 7 / & 127");
 
-// LDS of k_tile, 19.8 KB, so that eight workgroups (32 waves: all a CU can hold) share a CU:
-//   parent  u16[TH*TW]  one entry per node (nodes = first pixels of runs):
+// LDS of k_tile, 19.6 KB, so that eight workgroups (32 waves: all a CU can hold) share a CU:
+//   parent  u16[TH*TW]  the union-find's entries, indexed by tile pixel.  NODES are the components of 2 x 32 pixel blocks (a pair of
+//                       rows, one word, one colour: ck_links.h, "nodes over PAIRS of rows" — about half as many as one-row runs
+//                       on dense noise); a node owns the entry at its LOOKUP pixel (first column, top pixel if the column has
+//                       both: what its pixels find with one count-leading-zeros) and, when that is another pixel, at its MIN
+//                       pixel (the lookup entry then points at it); the pixels of the frame's two non-origin columns are nodes of
+//                       their own.  An entry:
 //                         non-root: tile-local index of the parent (bit 15 clear)
 //                         root:     CK_ROOT | pixel count of the component in bits 0..12 (a tile has 4096 pixels) | CK_RING when it
 //                                   touches the tile ring — the union-find's sizes live in the roots' own entries
@@ -50,18 +55,21 @@ static_assert(TW == 128, "a node index splits with >> 7 / & 127");
 //                       looks up at most two);
 //                       while the threshold is computed the same bytes hold the staged image and the 4x4 min/max (the
 //                       per-4x4 threshold words sit in the list's bytes, which is not alive yet)
-//   list    u16[TH*TW]  the tile's runs in scan order: node | colour << 12 (worst case one run per pixel)
-//   pool    u32[POOL_CAP]  links that need an atomic union (two u16 nodes each)
+//   list    u16[TH*TW]  the tile's nodes: lookup pixel | colour << 12; the white ones from the front, the black ones from the back (the
+//                       two waves that build it need not know each other's counts)
+//   pool    u32[POOL_CAP]  links that need an atomic union (two u16 entries each)
 //   masks   u32[TH][NWD][2]  colour bits of every row word (0 white, 1 black)
+//   starts  u32[TH/2][NWD][2]  node starts of every pair word
 constexpr int OFF_PARENT = 0;                              // u16[TH*TW] = 8192
 constexpr int OFF_IMG = 0;                                 // IMG_ROWS*IMG_PITCH = 6400
 constexpr int OFF_MINMAX = OFF_IMG + IMG_ROWS * IMG_PITCH; // u32[T4Y*T4X] = 1360 (one dword per 4x4 tile: the dilation's neighbour reads stay 4-byte aligned)
 constexpr int OFF_LIST = TH * TW * 2;                      // u16[TH*TW] = 8192
 constexpr int OFF_THR = OFF_LIST;                          // u16[(TH/4)*(TW/4)] = 512 (the run list is not alive yet)
-constexpr int POOL_CAP = 640;                              // dense binary noise leaves about 340 links per tile for the pool
-constexpr int OFF_POOL = OFF_LIST + TH * TW * 2;           // u32[POOL_CAP] = 2560
+constexpr int POOL_CAP = 512;                              // dense binary noise leaves about 150 links per tile for the pool
+constexpr int OFF_POOL = OFF_LIST + TH * TW * 2;           // u32[POOL_CAP] = 2048
 constexpr int OFF_MASK = OFF_POOL + POOL_CAP * 4;          // u32[TH][NWD][2] = 1024
-constexpr int OFF_MISC = OFF_MASK + TH * NWD * 2 * 4;      // u32[16]
+constexpr int OFF_S2 = OFF_MASK + TH * NWD * 2 * 4;        // u32[TH/2][NWD][2] = 512
+constexpr int OFF_MISC = OFF_S2 + (TH / 2) * NWD * 2 * 4;  // u32[16]
 constexpr int LDS_BYTES = OFF_MISC + 64;
 constexpr int RING_CAP = CK_RING_CAP;                      // ring-touching roots of a tile: at most one per ring pixel
 constexpr uint32_t CK_ROOT = 0x8000u, CK_RING = 0x4000u, CK_CLAIM = 0x2000u, CK_COUNT = 0x1FFFu;
@@ -130,52 +138,92 @@ __device__ __forceinline__ uint32_t msb_nibble(uint32_t v) {
     return (((v >> 7) & 0x01010101u) * 0x01020408u) >> 24 & 0xFu;
 }
 
-// One run of the tile as its lane sees it: where it is, its links to earlier runs (ck_links.h) and what it takes to name
-// the runs at the other end.  All reads are of the row-word masks in LDS; the code is branch-free (every lane of a wave looks
-// at a different run): words that do not exist (first row / first or last word of the tile) are read at a safe index and
-// masked to zero.
-struct RunView {
-    uint32_t p, wbase;   // node (tile pixel index of the run's first bit), tile pixel index of bit 0 of its word
-    uint32_t R, G, flags; // ck_run_links
-    uint32_t Su;         // run starts of the upper word
-    uint32_t up_l, left; // nodes of the last run of the upper-left word / of the word on the left (used when the link exists)
+// One pair word of the tile (rows 2p and 2p + 1, one 32-pixel word, one colour) as its lane sees it: its nodes, the nodes of the
+// pair word above, and the links between them that have not been used yet (ck_links.h: the links of the two facing rows, keyed by
+// the lower pixel; here every mask is already ANDed with the origin flags, so the rule's origin tests are all true).  Read from
+// the row masks and node starts in LDS; words that do not exist (first pair / first or last word of the tile) are read at a
+// safe index and masked to zero.
+struct PairCtx {
+    uint32_t Mt, S2;            // top-row pixels and node starts of this pair word
+    uint32_t Ut, S2u;           // the same of the pair word above
+    uint32_t base;              // tile pixel of bit 0 of this pair word's top row (the row below: + TW; the pair above: - 2 * TW)
+    uint32_t left, up_l, up_r;  // lookup pixels: last node of the pair word on the left / of the upper-left one, first node of the upper-right one
+    uint32_t Ev, DL, DR, flags; // links still to be used (DL without bit 0, DR without bit 31: those two cross a word boundary and are flags)
 };
-__device__ __forceinline__ RunView view_run(const uint32_t *mk, uint32_t e, int tx0, int w) {
-    RunView v;
-    const uint32_t p = e & 0xFFFu, c = e >> 12;
-    const int r = (int)(p >> 7), wd = (int)(p >> 5) & 3, i = (int)(p & 31u);
-    const int mrow = (int)((p >> 5) << 1) + (int)c; // (r * NWD + wd) * 2 + c
+__device__ __forceinline__ uint32_t pair_entry(uint32_t Mt, uint32_t base, int s) { return base + (((Mt >> s) & 1u) ? 0u : (uint32_t)TW) + (uint32_t)s; }
+__device__ __forceinline__ uint32_t lower_node(const PairCtx &v, int x) { return pair_entry(v.Mt, v.base, ck_run_start32(v.S2, x)); }
+__device__ __forceinline__ uint32_t upper_node(const PairCtx &v, int x) { return pair_entry(v.Ut, v.base - 2u * TW, ck_run_start32(v.S2u, x)); }
+__device__ __forceinline__ PairCtx load_pair(const uint32_t *mk, const uint32_t *s2w, int p, int wd, int c, int tx0, int w) {
+    PairCtx v;
+    const int mi = ((2 * p) * NWD + wd) * 2 + c; // the top row's word; the bottom row's: + 2 * NWD; the rows of the pair above: - 4 * NWD, - 2 * NWD
+    const int si = (p * NWD + wd) * 2 + c;
+    const bool has_l = wd > 0, has_u = p > 0, has_r = wd < NWD - 1, white = c == 0;
     const int x0 = tx0 + 32 * wd;
-    const bool has_l = wd > 0, has_u = r > 0, has_r = wd < NWD - 1, white = c == 0;
-    const uint32_t O = ck_origin32(x0, w), Op = ck_origin32(x0 - 32, w);
-    const uint32_t M = mk[mrow];
-    uint32_t Mp = mk[has_l ? mrow - 2 : mrow];
-    uint32_t U = mk[has_u ? mrow - 2 * NWD : mrow];
-    uint32_t Up = mk[(has_u && has_l) ? mrow - 2 * NWD - 2 : mrow];
-    uint32_t Un = mk[(has_u && has_r) ? mrow - 2 * NWD + 2 : mrow];
-    Mp = has_l ? Mp : 0u; U = has_u ? U : 0u;
-    Up = (has_u && has_l) ? Up : 0u; Un = (has_u && has_r) ? Un : 0u;
-    const bool on0 = (x0 + 32 >= 1) && (x0 + 32 <= w - 2);
-    const ck_run_links L = ck_links_of_run(white, M, U, O, i, (Mp >> 31) != 0, (Up >> 31) != 0, (Un & 1u) != 0, on0);
-    v.p = p; v.wbase = p - (uint32_t)i;
-    v.R = L.R; v.G = L.G; v.flags = L.flags;
-    v.Su = ck_starts32(U, O);
-    v.left = v.wbase - 32u + (uint32_t)ck_last_start32(ck_starts32(Mp, Op));
-    v.up_l = v.wbase - (uint32_t)TW - 32u + (uint32_t)ck_last_start32(ck_starts32(Up, Op));
+    const uint32_t O = ck_origin32(x0, w), Op = ck_origin32(x0 - 32, w), On = ck_origin32(x0 + 32, w);
+    const uint32_t Mt = mk[mi] & O, Mb = mk[mi + 2 * NWD] & O;
+    uint32_t Mtl = mk[has_l ? mi - 2 : mi] & Op, Mbl = mk[has_l ? mi + 2 * NWD - 2 : mi] & Op, S2l = s2w[has_l ? si - 2 : si];
+    uint32_t Ut = mk[has_u ? mi - 4 * NWD : mi] & O, Ub = mk[has_u ? mi - 2 * NWD : mi] & O, S2u = s2w[has_u ? si - 2 * NWD : si];
+    uint32_t Utl = mk[(has_u && has_l) ? mi - 4 * NWD - 2 : mi] & Op, Ubl = mk[(has_u && has_l) ? mi - 2 * NWD - 2 : mi] & Op;
+    uint32_t S2ul = s2w[(has_u && has_l) ? si - 2 * NWD - 2 : si];
+    uint32_t Utr = mk[(has_u && has_r) ? mi - 4 * NWD + 2 : mi] & On, Ubr = mk[(has_u && has_r) ? mi - 2 * NWD + 2 : mi] & On;
+    Mtl = has_l ? Mtl : 0u; Mbl = has_l ? Mbl : 0u;
+    Ut = has_u ? Ut : 0u; Ub = has_u ? Ub : 0u; S2u = has_u ? S2u : 0u;
+    Ubl = (has_u && has_l) ? Ubl : 0u; Ubr = (has_u && has_r) ? Ubr : 0u;
+    v.Mt = Mt; v.S2 = s2w[si]; v.Ut = Ut; v.S2u = S2u;
+    v.base = (uint32_t)((2 * p) * TW + 32 * wd);
+    v.left = pair_entry(Mtl, v.base - 32u, ck_last_start32(S2l));
+    v.up_l = pair_entry(Utl, v.base - 2u * TW - 32u, ck_last_start32(S2ul));
+    v.up_r = v.base - 2u * TW + 32u + ((Utr & 1u) ? 0u : (uint32_t)TW);
+    const uint32_t hl = ck_pair_link32(white, Mt, Mb, (Mtl >> 31) != 0, (Mbl >> 31) != 0) & 1u;
+    const ck_word_links K = ck_links_of_word(white, Mt, Ub, 0xFFFFFFFFu, false, (Ubl >> 31) != 0, (Ubr & 1u) != 0, true);
+    v.Ev = K.Ev; v.DL = K.DL & ~1u; v.DR = K.DR & 0x7FFFFFFFu;
+    v.flags = (hl ? CK_LINK_HLEFT : 0u) | ((K.DL & 1u) ? CK_LINK_CROSS_L : 0u) | ((K.DR >> 31) ? CK_LINK_CROSS_R : 0u);
     return v;
 }
-__device__ __forceinline__ uint32_t links_left(const RunView &v) { return (uint32_t)__popc(v.G) + (uint32_t)__popc(v.flags); }
-// takes one link out of the view and returns the node at its other end; `self` when none is left.  Order: the links to the
-// upper word from left to right, then hleft, cross_l, cross_r (the flag bits in ascending order).
-__device__ __forceinline__ uint32_t take_link(RunView &v, uint32_t self) {
-    const bool has_g = v.G != 0;
-    const int j = __builtin_ctz(v.G | 0x80000000u);
-    const uint32_t t_up = v.wbase - (uint32_t)TW + (uint32_t)ck_run_start32(v.Su, j);
-    const uint32_t f = v.flags & (0u - v.flags); // lowest flag
-    const uint32_t t_flag = f == CK_LINK_HLEFT ? v.left : (f == CK_LINK_CROSS_L ? v.up_l : (f ? v.wbase - (uint32_t)TW + 32u : self));
-    v.flags = has_g ? v.flags : (v.flags & (v.flags - 1u));
-    v.G &= v.G - 1u; // (0 stays 0)
-    return has_g ? t_up : t_flag;
+__device__ __forceinline__ uint32_t links_left(const PairCtx &v) {
+    return (uint32_t)__popc(v.Ev) + (uint32_t)__popc(v.DL) + (uint32_t)__popc(v.DR) + (uint32_t)__popc(v.flags);
+}
+// takes one link out of the context: a = an entry of the lower node, b = an entry of the node at the other end (links_left(v) > 0).
+// Order: Ev, DL, DR (the compares are on the masks, the rest is branch-free), then the flags in ascending order.
+__device__ __forceinline__ void take_link(PairCtx &v, uint32_t &a, uint32_t &b) {
+    const uint32_t E = v.Ev ? v.Ev : (v.DL ? v.DL : v.DR);
+    if (E) {
+        const int x = __builtin_ctz(E);
+        const int ux = v.Ev ? x : (v.DL ? x - 1 : x + 1);
+        const uint32_t clr = ~(1u << x);
+        const bool ev = v.Ev != 0, dl = v.DL != 0;
+        v.Ev &= ev ? clr : 0xFFFFFFFFu;
+        v.DL &= (!ev && dl) ? clr : 0xFFFFFFFFu;
+        v.DR &= (!ev && !dl) ? clr : 0xFFFFFFFFu;
+        a = lower_node(v, x); b = upper_node(v, ux);
+    } else {
+        const uint32_t f = v.flags & (0u - v.flags);
+        v.flags &= v.flags - 1u;
+        a = f == CK_LINK_CROSS_R ? lower_node(v, 31) : pair_entry(v.Mt, v.base, 0); // column 0 of a word always starts a node
+        // (as masks: from a chain of selects over the struct's fields the compiler makes an indexed load from a copy in scratch memory)
+        b = (v.left & (0u - (f & 1u))) | (v.up_l & (0u - ((f >> 1) & 1u))) | (v.up_r & (0u - ((f >> 2) & 1u)));
+    }
+}
+// tile pixel of the entry that origin pixel (row r, word wd, bit i) of colour c finds: the lookup pixel of its node
+__device__ __forceinline__ uint32_t node_lookup(const uint32_t *mk, const uint32_t *s2w, int r, int wd, int i, uint32_t c, uint32_t O) {
+    const int p = r >> 1;
+    const uint32_t S2 = s2w[(p * NWD + wd) * 2 + (int)c];
+    const uint32_t Mt = mk[((2 * p) * NWD + wd) * 2 + (int)c] & O;
+    return pair_entry(Mt, (uint32_t)((2 * p) * TW + 32 * wd), ck_run_start32(S2, i));
+}
+// The frame's two non-origin columns (0 and w - 1) inside a tile: lanes 0..31 of `q` (a 6-bit index) stand for the rows of column
+// 0, lanes 32..63 for those of column w - 1.  Returns false when the tile does not hold that pixel or it has no colour; else the
+// pixel's tile-local column and colour.
+__device__ __forceinline__ bool edge_pixel(const uint32_t *mk, int q, int tx0, int ty0, int w, int h, int &r, int &xl, uint32_t &c) {
+    r = q & 31;
+    const int side = q >> 5;
+    const int xf = side ? w - 1 : 0;
+    if ((side && w == 1) || xf < tx0 || xf >= tx0 + TW || ty0 + r >= h) return false;
+    xl = xf - tx0;
+    const uint32_t Wm = mk[(r * NWD + (xl >> 5)) * 2], Bm = mk[(r * NWD + (xl >> 5)) * 2 + 1];
+    const uint32_t wh = (Wm >> (xl & 31)) & 1u, bl = (Bm >> (xl & 31)) & 1u;
+    c = wh ? 0u : 1u;
+    return (wh | bl) != 0;
 }
 
 // Diagnostic build only (-DCK_TILE_PROFILE): per-phase cycle totals of k_tile in a buffer of their own.
@@ -194,7 +242,7 @@ __device__ unsigned long long g_tile_prof[16];
 // PRE = true : `frames` already hold a tri-state map (0 / 127 / 255), e.g. CAT's class map, and only the
 //              segmentation runs (the map is copied through to `thresh` for the merge kernel).
 template <bool PRE>
-__global__ __launch_bounds__(KNT) void k_tile(const uint8_t *__restrict__ frames, size_t frame_pitch, int stride,
+__global__ __launch_bounds__(KNT) __attribute__((amdgpu_num_sgpr(80))) void k_tile(const uint8_t *__restrict__ frames, size_t frame_pitch, int stride,
                                              int w, int h, int tiles_x, int tiles_y, int n_frames, int xcd_map, int min_diff, int min_comp,
                                              uint8_t *__restrict__ thresh, uint32_t *__restrict__ labels,
                                              ck_border_root *__restrict__ broots, uint32_t *__restrict__ tile_count,
@@ -217,8 +265,8 @@ __global__ __launch_bounds__(KNT) void k_tile(const uint8_t *__restrict__ frames
     uint32_t *parent32 = reinterpret_cast<uint32_t *>(lds + OFF_PARENT);
     uint16_t *list = reinterpret_cast<uint16_t *>(lds + OFF_LIST);
     uint32_t *mk = reinterpret_cast<uint32_t *>(lds + OFF_MASK);
-    uint32_t *misc = reinterpret_cast<uint32_t *>(lds + OFF_MISC); // [0..3] wave run counts, [5] pooled links, [6] / [7] white / black ring-touching roots, [8] some 4x4 tile has contrast, [9] some pixel has a colour
-    if (tid == 0) { misc[6] = 0; misc[7] = 0; misc[8] = 0; misc[9] = 0; } // (the barrier after P0 publishes them)
+    uint32_t *misc = reinterpret_cast<uint32_t *>(lds + OFF_MISC); // [0] / [1] white / black nodes, [5] pooled links, [6] / [7] white / black ring-touching roots, [8] some 4x4 tile has contrast, [9] some pixel has a colour
+    if (tid == 0) { misc[5] = 0; misc[6] = 0; misc[7] = 0; misc[8] = 0; misc[9] = 0; } // (the barrier after P0 publishes them)
 
     // Whole 4x4 tiles only enter the min/max (the oracle's rule); pixels right of / below the last whole one take its
     // threshold.  Normally the threshold grid of a workgroup tile starts at its own first 4x4 column / row (c4x, c4y); when the
@@ -369,92 +417,84 @@ __global__ __launch_bounds__(KNT) void k_tile(const uint8_t *__restrict__ frames
     TPROF(2);
 
     if (stop_after == 2) return; // diagnostics (CK_TILE_STOP_AFTER)
-    uint32_t nruns = 0;
+    uint32_t nruns = 0; // nodes in the tile's list
     uint32_t ring_root[2] = {0xFFFFFFFFu, 0xFFFFFFFFu}, ring_white[2] = {0, 0}; // P6b: roots under this lane's ring pixels
+    uint32_t nwhite = 0; // white nodes: list[0 .. nwhite); the black ones are list[TH * TW - (nruns - nwhite) .. TH * TW)
+    auto list_at = [&](uint32_t j) -> uint32_t { return list[j < nwhite ? j : j + (uint32_t)(TH * TW) - nruns]; };
+    uint32_t *s2w = reinterpret_cast<uint32_t *>(lds + OFF_S2);
     if (tile_has_runs) {
-    // ---- P4: thread = (colour, row, word): waves 0-1 hold the white words, waves 2-3 the black ones, so that the black waves skip
-    // the diagonal links altogether (a scalar branch).  (a) The word's runs go to the tile's run list, in scan order (the balanced phases
-    // P5b and P6 take one lane per run from it).  (b) Adoption: the lane walks its runs with the word's link masks in registers
-    // (ck_links_of_word) and gives every run ONE earlier run as parent with a plain store — only the owner writes the entry and
-    // nothing reads parent[] in this phase, so no find and no atomic is needed; the target has a smaller index, which keeps the
-    // forest invariant parent <= self.  (c) The links that are left over go to the pool for the atomic unions of P5c.
+    // ---- P4: the nodes (ck_links.h, "nodes over PAIRS of rows").  One lane per (pair of rows, word) and one wave per colour: wave 0
+    // the white pair words, wave 1 the black ones (which have no diagonal links: scalar branches).  A lane gets what it needs of its
+    // neighbours (the word on its left: lane - 1; the pair above: lanes - 5, - 4, - 3) from their registers.  Meanwhile a lane per
+    // pixel of the frame's non-origin columns (wave 2; only the tiles at the frame's left and right edge have such pixels) makes
+    // those pixels nodes of their own.
+    // (a) The node starts of every pair word go to LDS (the later phases find a pixel's node with them).
+    // (b) Adoption: every node takes ONE node of the pair above as parent — the one its first link leads to; which link that is
+    // comes out of the word's link masks without a loop (first set bit of every segment of a word: one subtraction) — with a plain
+    // store to the node's min entry: only the owner writes an entry and nothing reads parent[] in this phase, so no find and no atomic
+    // is needed; the target lies in an earlier row, which keeps the forest invariant parent < self.  The node's lookup entry, when it
+    // is another pixel, points at the min entry; the lookup pixel goes to the tile's node list.
+    // (c) The links that are left over go to the pool for the atomic unions of P5c: one reservation per wave.
     uint32_t *pool = reinterpret_cast<uint32_t *>(lds + OFF_POOL);
-    {
-        const int c = __builtin_amdgcn_readfirstlane(tid >> 7); // wave-uniform
-        const int r = (tid >> 2) & (TH - 1), wd = tid & 3;
-        const int mi = (r * NWD + wd) * 2 + c;                   // this word in the mask array
-        const bool has_l = wd > 0, has_u = r > 0, has_r = wd < NWD - 1, white = c == 0;
-        const int x0 = tx0 + 32 * wd;
-        const uint32_t O = ck_origin32(x0, w), Op = ck_origin32(x0 - 32, w);
-        const uint32_t M = mk[mi];
-        uint32_t Mp = mk[has_l ? mi - 2 : mi], U = mk[has_u ? mi - 2 * NWD : mi];
-        uint32_t Up = 0, Un = 0;
-        if (white) { // (scalar branch)
-            Up = mk[(has_u && has_l) ? mi - 2 * NWD - 2 : mi]; Un = mk[(has_u && has_r) ? mi - 2 * NWD + 2 : mi];
-            Up = (has_u && has_l) ? Up : 0u; Un = (has_u && has_r) ? Un : 0u;
-        }
-        Mp = has_l ? Mp : 0u; U = has_u ? U : 0u;
-        const bool on0 = (x0 + 32 >= 1) && (x0 + 32 <= w - 2);
-        const uint32_t S = ck_starts32(M, O), Su = ck_starts32(U, O);
-        ck_word_links K = ck_links_of_word(white, M, U, O, (Mp >> 31) != 0, (Up >> 31) != 0, (Un & 1u) != 0, on0);
-        const uint32_t wbase = (uint32_t)(r * TW + 32 * wd), upbase = wbase - (uint32_t)TW;
-        const uint32_t left = wbase - 32u + (uint32_t)ck_last_start32(ck_starts32(Mp, Op));       // last run of the word on the left
-        const uint32_t up_l = upbase - 32u + (uint32_t)ck_last_start32(ck_starts32(Up, Op));      // last run of the upper-left word
-        // (a) the list
-        const uint32_t cnt = (uint32_t)__popc(S);
+    const int c = __builtin_amdgcn_readfirstlane(tid >> 6); // wave-uniform
+    const int p = (tid >> 2) & (TH / 2 - 1), wd = tid & 3;
+    if (tid < 2 * 64) {
+        const bool white = c == 0, has_l = wd > 0, has_u = p > 0, has_r = wd < NWD - 1;
+        const int mi = ((2 * p) * NWD + wd) * 2 + c;
+        const uint32_t O = ck_origin32(tx0 + 32 * wd, w);
+        const uint32_t Mt = mk[mi] & O, Mb = mk[mi + 2 * NWD] & O;
+        const uint32_t base = (uint32_t)((2 * p) * TW + 32 * wd), upbase = base - 2u * TW;
+        const int lane4 = (tid & 63) * 4;
+        uint32_t l31 = dpp0<0x111, 0xF>((Mt >> 31) | ((Mb >> 31) << 1)); // lane - 1 (the same group of four lanes when it is used)
+        l31 = has_l ? l31 : 0u;
+        const uint32_t link = ck_pair_link32(white, Mt, Mb, (l31 & 1u) != 0, (l31 & 2u) != 0);
+        const uint32_t S2 = ck_pair_starts32(Mt, Mb, link);
+        s2w[(p * NWD + wd) * 2 + c] = S2;
+        // what the neighbours need of this word: the lookup pixel of its last node, pixel 31 / pixel 0 of its bottom row, pixel 0 of its top row
+        const uint32_t info = pair_entry(Mt, base, ck_last_start32(S2)) | ((Mb >> 31) << 12) | ((Mb & 1u) << 13) | ((Mt & 1u) << 14);
+        const uint32_t info_l = dpp0<0x111, 0xF>(info);
+        uint32_t info_ul = (uint32_t)__builtin_amdgcn_ds_bpermute(lane4 - 20, (int)info), info_ur = (uint32_t)__builtin_amdgcn_ds_bpermute(lane4 - 12, (int)info);
+        uint32_t Ut = (uint32_t)__builtin_amdgcn_ds_bpermute(lane4 - 16, (int)Mt), Ub = (uint32_t)__builtin_amdgcn_ds_bpermute(lane4 - 16, (int)Mb);
+        uint32_t S2u = (uint32_t)__builtin_amdgcn_ds_bpermute(lane4 - 16, (int)S2);
+        Ut = has_u ? Ut : 0u; Ub = has_u ? Ub : 0u; S2u = has_u ? S2u : 0u;
+        info_ul = (has_u && has_l) ? info_ul : 0u; info_ur = (has_u && has_r) ? info_ur : 0u;
+        const ck_word_links K = ck_links_of_word(white, Mt, Ub, 0xFFFFFFFFu, false, ((info_ul >> 12) & 1u) != 0, ((info_ur >> 13) & 1u) != 0, true);
+        const uint32_t Ev = K.Ev, DL = K.DL & ~1u, DR = K.DR & 0x7FFFFFFFu; // (the two links across a word boundary are flags)
+        // the first link of every node: the lowest set bit of every segment [start, next start) of E — with a stopper at every
+        // segment's last column, subtracting the start bits runs a borrow up to exactly that bit
+        const uint32_t E = Ev | DL | DR;
+        const uint32_t Ep = E | (S2 >> 1) | 0x80000000u;
+        const uint32_t F = Ep & ~(Ep - S2) & E;
+        // (a), (b)
+        const uint32_t cnt = (uint32_t)__popc(S2);
         const uint32_t incl = wave_scan_u32(cnt);
-        if ((tid & 63) == 63) misc[tid >> 6] = incl;
-        if (tid == 0) misc[5] = 0;
-        // (b) adoption, meanwhile
-        uint32_t Ev = K.Ev, DL = K.DL, DR = K.DR, hl = K.hleft ? 1u : 0u;
-        if (white) {
-            for (uint32_t St = S; St;) {
-                const uint32_t low = St & (0u - St);
-                const int i = __builtin_ctz(low);
-                St ^= low;
-                const uint32_t span = ((St & (0u - St)) - 1u) & ~(low - 1u); // the run's pixels-to-be: bit i up to the next start
-                const uint32_t e = (Ev | DL | DR) & span;
-                const int x = __builtin_ctz(e | 0x80000000u);
-                const uint32_t bit = 1u << x;
-                const bool is_ev = (Ev & bit) != 0, is_dl = (DL & bit) != 0;
-                const uint32_t t_ev = upbase + (uint32_t)ck_run_start32(Su, x);
-                const uint32_t t_dl = x > 0 ? upbase + (uint32_t)ck_run_start32(Su, x - 1) : up_l;
-                const uint32_t t_dr = upbase + (uint32_t)x + 1u;
-                const bool use_left = !e && i == 0 && hl;
-                const uint32_t tgt = e ? (is_ev ? t_ev : (is_dl ? t_dl : t_dr)) : (use_left ? left : CK_ROOT); // no earlier run: a root (count 0 for now)
-                const uint32_t clr = e ? ~bit : 0xFFFFFFFFu;
-                Ev &= is_ev ? clr : 0xFFFFFFFFu;
-                DL &= (!is_ev && is_dl) ? clr : 0xFFFFFFFFu;
-                DR &= (!is_ev && !is_dl) ? clr : 0xFFFFFFFFu;
-                hl = use_left ? 0u : hl;
-                parent[wbase + (uint32_t)i] = (uint16_t)tgt;
-            }
-        } else { // black: vertical links only
-            for (uint32_t St = S; St;) {
-                const uint32_t low = St & (0u - St);
-                const int i = __builtin_ctz(low);
-                St ^= low;
-                const uint32_t span = ((St & (0u - St)) - 1u) & ~(low - 1u);
-                const uint32_t e = Ev & span;
-                const int x = __builtin_ctz(e | 0x80000000u);
-                const bool use_left = !e && i == 0 && hl;
-                const uint32_t tgt = e ? upbase + (uint32_t)ck_run_start32(Su, x) : (use_left ? left : CK_ROOT);
-                Ev &= e ? ~(1u << x) : 0xFFFFFFFFu;
-                hl = use_left ? 0u : hl;
-                parent[wbase + (uint32_t)i] = (uint16_t)tgt;
-            }
+        if ((tid & 63) == 63) misc[c] = incl;
+        uint32_t li = c ? (uint32_t)(TH * TW - 1) - (incl - cnt) : incl - cnt; // white from the front, black from the back
+        const uint32_t lstep = c ? 0xFFFFFFFFu : 1u, lcol = (uint32_t)c << 12;
+        for (uint32_t St = S2; St;) {
+            const uint32_t low = St & (0u - St);
+            const int s = __builtin_ctz(low);
+            St ^= low;
+            const uint32_t span = ((St & (0u - St)) - 1u) & ~(low - 1u); // the node's columns: bit s up to the next start
+            const uint32_t lk = pair_entry(Mt, base, s);
+            const uint32_t T = Mt & span;
+            const uint32_t mn = T ? base + (uint32_t)__builtin_ctz(T) : lk; // (a top pixel in column s: T's lowest bit is s, mn == lk)
+            const uint32_t e = F & span;
+            const int x = __builtin_ctz(e | 0x80000000u);
+            const int ux = ((Ev >> x) & 1u) ? x : (((DL >> x) & 1u) ? x - 1 : x + 1);
+            const uint32_t t_up = pair_entry(Ut, upbase, ck_run_start32(S2u, ux & 31));
+            parent[lk] = (uint16_t)mn;                       // (in this order: the two are one entry when the node's first column has a top pixel)
+            parent[mn] = (uint16_t)(e ? t_up : CK_ROOT);     // no link to an earlier node: a root (count 0 for now)
+            list[li] = (uint16_t)(lk | lcol);
+            li += lstep;
         }
-        __syncthreads();
-        uint32_t off = incl - cnt;
-        const int wv = tid >> 6;
-        if (wv > 0) off += misc[0];
-        if (wv > 1) off += misc[1];
-        if (wv > 2) off += misc[2];
-        nruns = misc[0] + misc[1] + misc[2] + misc[3];
-        const uint32_t ebase = wbase | ((uint32_t)c << 12);
-        for (uint32_t St = S; St; St &= St - 1u) list[off++] = (uint16_t)(ebase + (uint32_t)__builtin_ctz(St));
-        // (c) the links that are left: one reservation per wave
-        uint32_t extra = (uint32_t)__popc(Ev) + (uint32_t)__popc(DL) + (uint32_t)__popc(DR) + hl;
+        // (c)
+        PairCtx v;
+        v.Mt = Mt; v.S2 = S2; v.Ut = Ut; v.S2u = S2u; v.base = base;
+        v.left = info_l & 0xFFFu; v.up_l = info_ul & 0xFFFu; v.up_r = upbase + 32u + (((info_ur >> 14) & 1u) ? 0u : (uint32_t)TW);
+        v.Ev = Ev & ~F; v.DL = DL & ~F; v.DR = DR & ~(F & ~DL);
+        v.flags = ((link & 1u) ? CK_LINK_HLEFT : 0u) | ((K.DL & 1u) ? CK_LINK_CROSS_L : 0u) | ((K.DR >> 31) ? CK_LINK_CROSS_R : 0u);
+        uint32_t extra = links_left(v);
         const uint32_t xincl = wave_scan_u32(extra);
         const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)xincl, 63);
         if (total) {
@@ -462,29 +502,30 @@ __global__ __launch_bounds__(KNT) void k_tile(const uint8_t *__restrict__ frames
             if ((tid & 63) == 63) wb = atomicAdd(&misc[5], total);
             wb = (uint32_t)__builtin_amdgcn_readlane((int)wb, 63);
             uint32_t pos = wb + xincl - extra;
-            while (extra) {
+            for (; extra; extra--, pos++) {
                 uint32_t a_, b_;
-                if (Ev) { const int x = __builtin_ctz(Ev); Ev &= Ev - 1u; a_ = wbase + (uint32_t)ck_run_start32(S, x); b_ = upbase + (uint32_t)ck_run_start32(Su, x); }
-                else if (DL) { const int x = __builtin_ctz(DL); DL &= DL - 1u; a_ = wbase + (uint32_t)ck_run_start32(S, x); b_ = x > 0 ? upbase + (uint32_t)ck_run_start32(Su, x - 1) : up_l; }
-                else if (DR) { const int x = __builtin_ctz(DR); DR &= DR - 1u; a_ = wbase + (uint32_t)ck_run_start32(S, x); b_ = upbase + (uint32_t)x + 1u; }
-                else { hl = 0; a_ = wbase; b_ = left; }
+                take_link(v, a_, b_);
                 if (pos < (uint32_t)POOL_CAP) pool[pos] = a_ | (b_ << 16);
-                pos++; extra--;
             }
         }
+    } else if (tid < 3 * 64) {
+        int r, xl; uint32_t ec;
+        if (edge_pixel(mk, tid & 63, tx0, ty0, w, h, r, xl, ec)) parent[r * TW + xl] = (uint16_t)CK_ROOT;
     }
     __syncthreads();
+    nwhite = misc[0];
+    nruns = nwhite + misc[1];
     TPROF(4);
     if (stop_after == 4) return; // diagnostics (CK_TILE_STOP_AFTER)
-    // ---- P5b: one pointer-jumping sweep over the (static) adoption forest, in scan order: a run's parent lies in an earlier
-    // row (or earlier in its own), which the sweep has usually flattened by the time the run is reached, so the chains
-    // down a tag edge (one hop per row) collapse before the finds of the next two phases walk them
+    // ---- P5b: one pointer-jumping sweep over the (static) adoption forest: a node's parent lies in an earlier pair (or earlier in
+    // its own), so the chains down a tag edge (one hop per pair, two where a lookup entry sits in between) are shortened before
+    // the finds of the next two phases walk them
     for (int sweep = 0; sweep < sweeps; sweep++)
     for (uint32_t j = (uint32_t)tid; j < nruns; j += KNT) {
-        const uint32_t p = list[j] & 0xFFFu;
-        const uint32_t q = parent[p];
+        const uint32_t pe = list_at(j) & 0xFFFu;
+        const uint32_t q = parent[pe];
         const uint32_t g = parent[q & 0xFFFu]; // (a root's own entry has no parent to look at: the read is harmless, the result unused)
-        if (!(q & CK_ROOT) && !(g & CK_ROOT)) parent[p] = (uint16_t)g;
+        if (!(q & CK_ROOT) && !(g & CK_ROOT)) parent[pe] = (uint16_t)g;
     }
     __syncthreads();
     TPROF(5);
@@ -497,18 +538,38 @@ __global__ __launch_bounds__(KNT) void k_tile(const uint8_t *__restrict__ frames
             const uint32_t e = pool[j];
             lds_union(parent, e & 0xFFFFu, e >> 16);
         }
-        if (npool > (uint32_t)POOL_CAP) // more links than the pool holds (pathological maps): every run joins all its links again
-            for (uint32_t j = (uint32_t)tid; j < nruns; j += KNT) {
-                RunView v = view_run(mk, list[j], tx0, w);
-                for (uint32_t nl = links_left(v); nl; nl--) lds_union(parent, v.p, take_link(v, v.p));
+        if (npool > (uint32_t)POOL_CAP) // more links than the pool holds (pathological maps): every pair word joins all its links again
+            if (tid < 2 * 64) {
+                PairCtx v = load_pair(mk, s2w, p, wd, c, tx0, w);
+                for (uint32_t nl = links_left(v); nl; nl--) {
+                    uint32_t a_, b_;
+                    take_link(v, a_, b_);
+                    lds_union(parent, a_, b_);
+                }
             }
+        // the pixels of the frame's non-origin columns: joined by what the rule lets their origin neighbours do — (1, y) joins its left
+        // neighbour (0, y); white (1, y + 1) joins up-left (0, y); white (w - 2, y + 1) joins up-right (w - 1, y).  (A neighbour in the
+        // next tile is the merge stage's business.)
+        if (tid >= 3 * 64 && (tx0 == 0 || tx0 + TW >= w) && w >= 3) {
+            int r, xl; uint32_t ec;
+            if (edge_pixel(mk, tid & 63, tx0, ty0, w, h, r, xl, ec)) {
+                const uint32_t me = (uint32_t)(r * TW + xl);
+                const int xn = xl == 0 && tx0 == 0 ? 1 : xl - 1; // the origin column next to it (tile-local; -1: in the tile on the left)
+                if (xn >= 0) {
+                    const uint32_t On = ck_origin32(tx0 + (xn & ~31), w);
+                    if (xl == 0 && tx0 == 0 && ((mk[(r * NWD) * 2 + (int)ec] >> 1) & 1u)) lds_union(parent, me, node_lookup(mk, s2w, r, 0, 1, ec, On));
+                    if (ec == 0u && r + 1 < TH && ty0 + r + 1 < h && ((mk[((r + 1) * NWD + (xn >> 5)) * 2] >> (xn & 31)) & 1u))
+                        lds_union(parent, me, node_lookup(mk, s2w, r + 1, xn >> 5, xn & 31, 0u, On));
+                }
+            }
+        }
     }
     __syncthreads(); // halving stores must land before the owners publish final roots; the pool is dead
     TCOUNT(9, nruns); TCOUNT(10, npool);
     TPROF(6);
     if (stop_after == 6) return; // diagnostics (CK_TILE_STOP_AFTER)
-    // ---- P6: flatten the runs' entries and add their pixels (and ring flags) into their roots' entries; two runs per lane and
-    // round so that two root walks are in flight (a lane past the end walks run 0 again and writes nothing)
+    // ---- P6: flatten the nodes' lookup entries and add their pixels into their roots' entries; two nodes per lane and round so
+    // that two root walks are in flight (a lane past the end walks node 0 again and writes nothing)
     for (uint32_t j0 = 0; j0 < nruns; j0 += 2 * KNT) {
         uint32_t node[2], root[2], add[2];
         bool live[2];
@@ -516,13 +577,14 @@ __global__ __launch_bounds__(KNT) void k_tile(const uint8_t *__restrict__ frames
         for (int q = 0; q < 2; q++) {
             const uint32_t j = j0 + (uint32_t)(q * KNT + tid);
             live[q] = j < nruns;
-            const uint32_t e = list[live[q] ? j : 0u];
-            const uint32_t p = e & 0xFFFu, c = e >> 12;
-            const int wd = (int)(p >> 5) & 3, i = (int)(p & 31u);
-            const uint32_t M = mk[(int)((p >> 5) << 1) + (int)c];
-            const uint32_t R = ck_run_bits32(M, ck_starts32(M, ck_origin32(tx0 + 32 * wd, w)), i);
-            node[q] = p; root[q] = p;
-            add[q] = (uint32_t)__popc(R);
+            const uint32_t e = list_at(live[q] ? j : 0u);
+            const uint32_t pe = e & 0xFFFu, ec = e >> 12;
+            const int wdd = (int)(pe >> 5) & 3, s = (int)(pe & 31u), pp = (int)(pe >> 8);
+            const uint32_t O = ck_origin32(tx0 + 32 * wdd, w);
+            const int mi = ((2 * pp) * NWD + wdd) * 2 + (int)ec;
+            const uint32_t span = ck_span32(s2w[(pp * NWD + wdd) * 2 + (int)ec], s) & O;
+            node[q] = pe; root[q] = pe;
+            add[q] = (uint32_t)__popc(mk[mi] & span) + (uint32_t)__popc(mk[mi + 2 * NWD] & span);
         }
         for (int it = 0; it < TH * TW; it++) { // plain loads behind a compiler barrier: the two reads of a step go out together
             __asm__ volatile("" ::: "memory");
@@ -539,6 +601,16 @@ __global__ __launch_bounds__(KNT) void k_tile(const uint8_t *__restrict__ frames
                 // other half of the word)
                 atomicAdd(&parent32[root[q] >> 1], add[q] << ((root[q] & 1u) * 16u));
             }
+    }
+    if (tid >= 3 * 64 && (tx0 == 0 || tx0 + TW >= w)) { // the non-origin columns' pixels: one pixel each
+        int r, xl; uint32_t ec;
+        if (edge_pixel(mk, tid & 63, tx0, ty0, w, h, r, xl, ec)) {
+            const uint32_t me = (uint32_t)(r * TW + xl);
+            uint32_t root = me;
+            for (;;) { __asm__ volatile("" ::: "memory"); const uint32_t n0 = parent[root]; if (n0 & CK_ROOT) break; root = n0; }
+            if (root != me) parent[me] = (uint16_t)root;
+            atomicAdd(&parent32[root >> 1], 1u << ((root & 1u) * 16u));
+        }
     }
     __syncthreads();
     if (stop_after == 65) return; // diagnostics (CK_TILE_STOP_AFTER): flatten + sizes done, ids not yet
@@ -565,8 +637,8 @@ __global__ __launch_bounds__(KNT) void k_tile(const uint8_t *__restrict__ frames
             const uint32_t Wm = mk[(rr * NWD + wd) * 2], Bm = mk[(rr * NWD + wd) * 2 + 1];
             const uint32_t white = (Wm >> i) & 1u;
             if (!side || !(((Wm | Bm) >> i) & 1u)) continue;
-            const uint32_t M = white ? Wm : Bm;
-            const uint32_t node = (uint32_t)(rr * TW + 32 * wd + ck_run_start32(ck_starts32(M, ck_origin32(tx0 + 32 * wd, w)), i));
+            const uint32_t Oo = ck_origin32(tx0 + 32 * wd, w);
+            const uint32_t node = ((Oo >> i) & 1u) ? node_lookup(mk, s2w, rr, wd, i, white ^ 1u, Oo) : (uint32_t)(rr * TW + xx); // (a non-origin column's pixel is a node of its own)
             const uint32_t e = parent[node];
             const uint32_t root = (e & CK_ROOT) ? node : e; // flat since P6
             ring_root[rnd] = root; ring_white[rnd] = white;
@@ -608,74 +680,89 @@ __global__ __launch_bounds__(KNT) void k_tile(const uint8_t *__restrict__ frames
         if (tile_has_runs && ring_root[rnd] != 0xFFFFFFFFu) val = ((uint32_t)parent[ring_root[rnd]] & 0x1FFu) | (ring_white[rnd] << 15);
         ring_f[dst] = (uint16_t)val;
     }
-    // ---- P7: write label words.  Four passes; in pass q lane L owns the 4-pixel group q*256 + L of the tile's 1024, so that a
-    // wave's store instruction covers 1 KiB of contiguous label words and its LDS lookups spread over the banks.  A pixel's run
-    // entry is either its component's root entry (CK_ROOT | flags | count or id) or the root's node: at most two lookups.
+    // ---- P7: write label words.  Two passes; in pass q lane L owns the 4-column group L & 31 of pair q * 8 + (L >> 5): both rows, so
+    // that the search for a column's node (per colour: the nearest node start at or below it, then the row of that node's lookup
+    // entry) is shared by the column's two pixels; a wave's store instruction covers two stretches of 512 contiguous bytes.  A
+    // pixel's entry is either its component's root entry (CK_ROOT | flags | count or id) or the root's pixel: at most two lookups.
     {
-        const int g = tid & 31, wd = g >> 3, sh = 4 * (g & 7);       // the same for the lane's four passes
+        const int g = tid & 31, wd = g >> 3, sh = 4 * (g & 7);       // the same for the lane's two passes
         const int gx = tx0 + 4 * g;
         const uint32_t Oo = ck_origin32(tx0 + 32 * wd, w);
         const uint32_t below = (1u << sh) - 1u;
         const uint32_t gbase = (uint32_t)ty0 * (uint32_t)w + (uint32_t)tx0;
         const uint32_t slot0 = CK_LBL_BORDER | ((uint32_t)tile * RING_CAP);
         const uint32_t w24 = (uint32_t)w & 0xFFFFFFu; // (the compiler then sees two 24-bit factors: a full-rate multiply instead of a 64-bit one)
+        const uint32_t edge4 = (~Oo >> sh) & 15u;     // columns of the group that are non-origin columns of the frame: their pixels are nodes of their own
         if (gx < w)
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const int rr = q * (KNT / 32) + (tid >> 5);
-            const int gy = ty0 + rr;
+        for (int q = 0; q < 2; q++) {
+            const int pr = q * (KNT / 32) + (tid >> 5);
+            const int gy = ty0 + 2 * pr;
             if (gy >= h) continue;
-            const uint32_t wbase = (uint32_t)(rr * TW + 32 * wd), cbase = wbase + (uint32_t)sh;
-            uint32_t outw[4] = {CK_LBL_INVALID, CK_LBL_INVALID, CK_LBL_INVALID, CK_LBL_INVALID};
-            uint32_t any4 = 0;
+            const uint32_t pbase = (uint32_t)((2 * pr) * TW + 32 * wd), cbase = pbase + (uint32_t)sh;
+            uint32_t outw[2][4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) outw[0][k] = outw[1][k] = CK_LBL_INVALID;
             if (tile_has_runs) {
-                const uint2 wb = *reinterpret_cast<const uint2 *>(&mk[(rr * NWD + wd) * 2]);
-                const uint32_t Wm = wb.x, Bm = wb.y;
-                const uint32_t w4 = (Wm >> sh) & 15u, b4 = (Bm >> sh) & 15u;
-                any4 = w4 | b4;
-                if (any4) {
-                    const uint32_t SW = ck_starts32(Wm, Oo), SB = ck_starts32(Bm, Oo);
-                    const uint32_t st4 = ((SW | SB) >> sh) & 15u;
-                    // the run that is already open when the group begins: nearest start below it in the word, per colour
-                    const uint32_t carryW = wbase + (uint32_t)ck_last_start32(SW & below), carryB = wbase + (uint32_t)ck_last_start32(SB & below);
-                    // a pixel's run starts at the nearest start bit of EITHER colour at or below it (a start of the other colour cannot
-                    // lie inside a run), or before the group (then the run has the colour of pixel 0 and the carried node of that
-                    // colour).  An uncoloured pixel looks up a harmless in-range node; its word is not used.
-                    uint32_t cur = (w4 & 1u) ? carryW : carryB;
-                    uint32_t nodev[4], ev[4], rv[4];
+                const uint2 m4 = *reinterpret_cast<const uint2 *>(&mk[((2 * pr) * NWD + wd) * 2]);          // top row: white, black word ...
+                const uint2 b4 = *reinterpret_cast<const uint2 *>(&mk[((2 * pr + 1) * NWD + wd) * 2]);      // ... and the bottom row's
+                const uint32_t col4[2][2] = {{(m4.x >> sh) & 15u, (m4.y >> sh) & 15u}, {(b4.x >> sh) & 15u, (b4.y >> sh) & 15u}}; // [row][colour]
+                if (col4[0][0] | col4[0][1] | col4[1][0] | col4[1][1]) {
+                    const uint2 s2 = *reinterpret_cast<const uint2 *>(&s2w[(pr * NWD + wd) * 2]);
+                    const uint32_t Wt = m4.x & Oo, Bt = m4.y & Oo;
+                    uint32_t cw = (uint32_t)ck_last_start32(s2.x & below), cb = (uint32_t)ck_last_start32(s2.y & below);
+                    const uint32_t sw4 = (s2.x >> sh) & 15u, sb4 = (s2.y >> sh) & 15u;
+                    uint32_t nodev[2][4], ev[2][4], rv[2][4];
 #pragma unroll
                     for (int k = 0; k < 4; k++) {
-                        cur = ((st4 >> k) & 1u) ? cbase + (uint32_t)k : cur;
-                        nodev[k] = cur;
+                        cw = ((sw4 >> k) & 1u) ? (uint32_t)(sh + k) : cw;
+                        cb = ((sb4 >> k) & 1u) ? (uint32_t)(sh + k) : cb;
+                        const uint32_t atw = pbase + cw + (((Wt >> cw) & 1u) ? 0u : (uint32_t)TW), atb = pbase + cb + (((Bt >> cb) & 1u) ? 0u : (uint32_t)TW);
+                        const bool edge = ((edge4 >> k) & 1u) != 0;
+#pragma unroll
+                        for (int r = 0; r < 2; r++) { // an uncoloured pixel looks up a harmless in-range entry; its word is not used
+                            const uint32_t at = ((col4[r][0] >> k) & 1u) ? atw : atb;
+                            nodev[r][k] = edge ? cbase + (uint32_t)(r * TW + k) : at;
+                        }
                     }
 #pragma unroll
-                    for (int k = 0; k < 4; k++) ev[k] = parent[nodev[k]];
+                    for (int r = 0; r < 2; r++)
 #pragma unroll
-                    for (int k = 0; k < 4; k++) rv[k] = parent[ev[k] & (uint32_t)(TH * TW - 1)]; // the root's entry when ev[k] is a node (harmless otherwise)
+                        for (int k = 0; k < 4; k++) ev[r][k] = parent[nodev[r][k]];
 #pragma unroll
-                    for (int k = 0; k < 4; k++) {
-                        const bool is_root = (ev[k] & CK_ROOT) != 0;
-                        const uint32_t node = is_root ? nodev[k] : ev[k];      // the component's root node
-                        const uint32_t c = is_root ? ev[k] : rv[k];           // its entry
-                        // interior component: the root's pixel index, final; ring-touching: the component's slot in the frame's tables
-                        // (as a branch: formed both ways and bit-selected it measured 1.2 % slower)
-                        const uint32_t word = (c & CK_RING) ? slot0 + (c & 0x1FFu)
-                                                            : ((gbase + ((node >> 7) & (uint32_t)(TH - 1)) * w24 + (node & (TW - 1))) | ((int)(c & CK_COUNT) < min_comp ? CK_LBL_SMALL : 0u));
-                        outw[k] = ((any4 >> k) & 1u) ? word : CK_LBL_INVALID;
-                    }
+                    for (int r = 0; r < 2; r++)
+#pragma unroll
+                        for (int k = 0; k < 4; k++) rv[r][k] = parent[ev[r][k] & (uint32_t)(TH * TW - 1)]; // the root's entry when ev is a pixel (harmless otherwise)
+#pragma unroll
+                    for (int r = 0; r < 2; r++)
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            const bool is_root = (ev[r][k] & CK_ROOT) != 0;
+                            const uint32_t node = is_root ? nodev[r][k] : ev[r][k]; // the component's root pixel
+                            const uint32_t ce = is_root ? ev[r][k] : rv[r][k];      // its entry
+                            // interior component: the root's pixel index, final; ring-touching: the component's slot in the frame's tables
+                            // (as a branch: formed both ways and bit-selected it measured 1.2 % slower)
+                            const uint32_t word = (ce & CK_RING) ? slot0 + (ce & 0x1FFu)
+                                                                 : ((gbase + ((node >> 7) & (uint32_t)(TH - 1)) * w24 + (node & (TW - 1))) | ((int)(ce & CK_COUNT) < min_comp ? CK_LBL_SMALL : 0u));
+                            outw[r][k] = (((col4[r][0] | col4[r][1]) >> k) & 1u) ? word : CK_LBL_INVALID;
+                        }
                 }
             }
-            uint32_t *dst = labels + fbase + (size_t)gy * w + gx;
-            if (packed_rows) {
-                // (the empty asm keeps the compiler from merging this store with the per-pixel ones of the other branch: merged, it
-                // became a 12-byte store plus a 4-byte one)
-                __asm__ volatile("" ::: "memory");
-                *reinterpret_cast<uint4 *>(dst) = make_uint4(outw[0], outw[1], outw[2], outw[3]);
-                __asm__ volatile("" ::: "memory");
-            } else {
 #pragma unroll
-                for (int k = 0; k < 4; k++)
-                    if (gx + k < w) dst[k] = outw[k];
+            for (int r = 0; r < 2; r++) {
+                if (gy + r >= h) continue;
+                uint32_t *dst = labels + fbase + (size_t)(gy + r) * w + gx;
+                if (packed_rows) {
+                    // (the empty asm keeps the compiler from merging this store with the per-pixel ones of the other branch: merged, it
+                    // became a 12-byte store plus a 4-byte one)
+                    __asm__ volatile("" ::: "memory");
+                    *reinterpret_cast<uint4 *>(dst) = make_uint4(outw[r][0], outw[r][1], outw[r][2], outw[r][3]);
+                    __asm__ volatile("" ::: "memory");
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; k++)
+                        if (gx + k < w) dst[k] = outw[r][k];
+                }
             }
         }
     }

@@ -35,6 +35,104 @@ static void uf_union(std::vector<uint32_t> &p, uint32_t a, uint32_t b) {
     if (a < b) p[b] = a; else p[a] = b;
 }
 
+static size_t g_pair_nodes, g_pair_links, g_runs;
+
+// ---- the PAIR formulation (nodes = components of 2 x 32 blocks; ck_links.h, "nodes over PAIRS of rows") ---------------------
+// Replays exactly what k_tile does with it: every node gets a lookup entry and a min entry, the pixels of a node find its
+// lookup entry, pairs are joined by the word-level links of their facing rows (ck_links_of_word on origin-masked words) with
+// the targets resolved to the upper pair's nodes, the non-origin columns are single-pixel nodes.
+static int check_pairs(const std::vector<uint8_t> &t, int w, int h, const std::vector<uint32_t> &m, const std::vector<uint32_t> &lab,
+                       const char *what, size_t n_runs) {
+    const int nw = (w + 31) / 32, np = (h + 1) / 2;
+    auto mask = [&](int y, int wd, int c) -> uint32_t {
+        if (y < 0 || y >= h || wd < 0 || wd >= nw) return 0u;
+        return m[((size_t)y * nw + wd) * 2 + c] & ck_origin32(wd * 32, w);
+    };
+    struct PW { uint32_t Mt, Mb, link, S2; };
+    auto pw = [&](int p, int wd, int c) -> PW {
+        PW r;
+        r.Mt = mask(2 * p, wd, c); r.Mb = mask(2 * p + 1, wd, c);
+        r.link = ck_pair_link32(c == 0, r.Mt, r.Mb, (mask(2 * p, wd - 1, c) >> 31) != 0, (mask(2 * p + 1, wd - 1, c) >> 31) != 0);
+        r.S2 = ck_pair_starts32(r.Mt, r.Mb, r.link);
+        return r;
+    };
+    // frame pixel of a word-local entry (row << 5 | column) of pair p, word wd
+    auto pix = [&](int p, int wd, int e) -> uint32_t { return (uint32_t)((2 * p + (e >> 5)) * w + wd * 32 + (e & 31)); };
+    // lookup pixel of the node of pair p, word wd, colour c that holds column x (the column must be occupied)
+    auto lookup_of = [&](int p, int wd, int c, int x) -> uint32_t {
+        const PW r = pw(p, wd, c);
+        return pix(p, wd, ck_pair_lookup(r.Mt, ck_run_start32(r.S2, x)));
+    };
+    auto last_lookup = [&](int p, int wd, int c) -> uint32_t {
+        const PW r = pw(p, wd, c);
+        return pix(p, wd, ck_pair_lookup(r.Mt, ck_last_start32(r.S2)));
+    };
+    std::vector<uint32_t> parent((size_t)w * h), node_of((size_t)w * h, 0xFFFFFFFFu);
+    for (size_t i = 0; i < parent.size(); i++) parent[i] = (uint32_t)i;
+    size_t n_nodes = 0, n_links = 0;
+    for (int p = 0; p < np; p++)
+        for (int wd = 0; wd < nw; wd++)
+            for (int c = 0; c < 2; c++) {
+                const PW r = pw(p, wd, c);
+                for (uint32_t S = r.S2; S; S &= S - 1) {
+                    const int s = ck_ctz32(S);
+                    const uint32_t span = ck_span32(r.S2, s);
+                    const uint32_t lk = pix(p, wd, ck_pair_lookup(r.Mt, s)), mn = pix(p, wd, ck_pair_min(r.Mt, span, s));
+                    if (mn > lk) { fprintf(stderr, "FAIL(pairs) %s: min entry behind the lookup entry\n", what); return 1; }
+                    uf_union(parent, lk, mn);
+                    n_nodes++;
+                    for (uint32_t R = r.Mt & span; R; R &= R - 1) node_of[(size_t)(2 * p) * w + wd * 32 + ck_ctz32(R)] = lk;
+                    for (uint32_t R = r.Mb & span; R; R &= R - 1) node_of[(size_t)(2 * p + 1) * w + wd * 32 + ck_ctz32(R)] = lk;
+                }
+                if ((r.link & 1u) && ((r.Mt | r.Mb) & 1u)) { uf_union(parent, lookup_of(p, wd, c, 0), last_lookup(p, wd - 1, c)); n_links++; }
+                if (p == 0 || !r.Mt) continue;
+                const uint32_t U = mask(2 * p - 1, wd, c);
+                const bool up31 = (mask(2 * p - 1, wd - 1, c) >> 31) != 0, un0 = (mask(2 * p - 1, wd + 1, c) & 1u) != 0;
+                const ck_word_links L = ck_links_of_word(c == 0, r.Mt, U, 0xFFFFFFFFu, false, up31, un0, true);
+                for (uint32_t E = L.Ev; E; E &= E - 1) {
+                    const int x = ck_ctz32(E);
+                    uf_union(parent, lookup_of(p, wd, c, x), lookup_of(p - 1, wd, c, x)); n_links++;
+                }
+                for (uint32_t E = L.DL; E; E &= E - 1) {
+                    const int x = ck_ctz32(E);
+                    uf_union(parent, lookup_of(p, wd, c, x), x > 0 ? lookup_of(p - 1, wd, c, x - 1) : last_lookup(p - 1, wd - 1, c)); n_links++;
+                }
+                for (uint32_t E = L.DR; E; E &= E - 1) {
+                    const int x = ck_ctz32(E);
+                    uf_union(parent, lookup_of(p, wd, c, x), x < 31 ? lookup_of(p - 1, wd, c, x + 1) : lookup_of(p - 1, wd + 1, c, 0)); n_links++;
+                }
+            }
+    // the non-origin columns: single-pixel nodes, joined by what the rule lets their origin neighbours do
+    for (int y = 0; y < h; y++)
+        for (int side = 0; side < 2; side++) {
+            const int xn = side ? w - 1 : 0;
+            if (side && w == 1) continue;
+            const size_t i = (size_t)y * w + xn;
+            const uint8_t v = t[i];
+            if (v == 127) continue;
+            node_of[i] = (uint32_t)i;
+            if (w < 3) continue;
+            if (xn == 0 && t[i + 1] == v) uf_union(parent, (uint32_t)i, node_of[i + 1]);                       // (1, y) joins left
+            if (v == 255 && y + 1 < h) {
+                const size_t j = (size_t)(y + 1) * w + (xn == 0 ? 1 : w - 2);                                   // (1, y + 1) joins up-left, (w - 2, y + 1) up-right
+                if (t[j] == 255) uf_union(parent, (uint32_t)i, node_of[j]);
+            }
+        }
+    for (size_t i = 0; i < lab.size(); i++) {
+        const uint32_t mine = t[i] == 127 ? 0xFFFFFFFFu : uf_find(parent, node_of[i]);
+        if (mine != lab[i]) {
+            fprintf(stderr, "FAIL(pairs) %s %dx%d: pixel (%d,%d) label %u, oracle %u\n", what, w, h, (int)(i % w), (int)(i / w), mine, lab[i]);
+            return 1;
+        }
+    }
+    if (n_nodes > n_runs) { fprintf(stderr, "FAIL(pairs) %s: more nodes (%zu) than one-row runs (%zu)\n", what, n_nodes, n_runs); return 1; }
+    // (the links between two pairs are one per pair of facing ONE-ROW runs: several of them can join the same two nodes — those are
+    // unions that find one root twice on the GPU — but never more than the one-row formulation has)
+    if (n_links > 2 * n_runs + 8) { fprintf(stderr, "FAIL(pairs) %s: %zu links for %zu one-row runs\n", what, n_links, n_runs); return 1; }
+    g_pair_nodes += n_nodes; g_pair_links += n_links; g_runs += n_runs;
+    return 0;
+}
+
 static int check(const std::vector<uint8_t> &t, int w, int h, const char *what) {
     const int nw = (w + 31) / 32;
     // per row, per word, per colour (0 white, 1 black)
@@ -149,7 +247,7 @@ static int check(const std::vector<uint8_t> &t, int w, int h, const char *what) 
     // soundness of the economy: never more links than runs + upper runs touched would justify (every run at most one link
     // per distinct earlier run); a gross over-count would mean duplicated links, i.e. wasted unions on the GPU
     if (n_links > 2 * n_runs + 8) { fprintf(stderr, "FAIL %s: %zu links for %zu runs\n", what, n_links, n_runs); return 1; }
-    return 0;
+    return check_pairs(t, w, h, m, lab, what, n_runs);
 }
 
 int main(int argc, char **argv) {
@@ -179,6 +277,6 @@ int main(int argc, char **argv) {
         cases++;
     }
     if (fails) return 1;
-    printf("OK %d maps\n", cases);
+    printf("OK %d maps (%zu one-row runs, %zu pair nodes, %zu pair links)\n", cases, g_runs, g_pair_nodes, g_pair_links);
     return 0;
 }
