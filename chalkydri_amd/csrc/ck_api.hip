@@ -79,7 +79,8 @@ extern "C" int ck_create(const ck_config_t *cfg, ck_handle_t **out) {
     if (cfg->max_batch < 1 || cfg->n_families < 1 || cfg->n_families > CK_MAX_FAMILIES) return CK_EINVAL;
     if (cfg->quad_decimate != 1 && cfg->quad_decimate != 2) return CK_EUNSUPPORTED;
     for (int i = 0; i < cfg->n_families; i++)
-        if (!cfg->families[i] || cfg->families[i]->nbits > 64 || cfg->families[i]->total_width > 16) return CK_EINVAL;
+        if (!cfg->families[i] || cfg->families[i]->nbits > 64 || cfg->families[i]->total_width > 16 ||
+            cfg->families[i]->n_upstream > cfg->families[i]->ncodes) return CK_EINVAL;
     int qw = cfg->width / cfg->quad_decimate, qh = cfg->height / cfg->quad_decimate;
     if (qw < 8 || qh < 8) return CK_EINVAL;
     if (cfg->min_component_px < 1 || cfg->min_component_px > 0x3FFFFFFF) return CK_EINVAL;
@@ -89,6 +90,7 @@ extern "C" int ck_create(const ck_config_t *cfg, ck_handle_t **out) {
     memset(h, 0, sizeof *h);
     h->cfg = *cfg;
     h->device = cfg->device;
+    h->n_last_pose = -1;
     h->w = cfg->width; h->h = cfg->height; h->qw = qw; h->qh = qh;
     h->npix = (size_t)qw * qh;
     h->tiles_x = (qw + CK_TW - 1) / CK_TW; h->tiles_y = (qh + CK_TH - 1) / CK_TH;

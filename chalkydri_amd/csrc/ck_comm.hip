@@ -11,6 +11,7 @@
 #include <dlfcn.h>
 #include <string.h>
 
+#include <mutex>
 #include <new>
 
 #include "ck_internal.h"
@@ -35,18 +36,14 @@ struct rccl_api {
     fn_error_string error_string = nullptr;
 };
 
-rccl_api *rccl() {
-    static rccl_api api;
-    static bool tried = false;
-    if (tried) return api.so ? &api : nullptr;
-    tried = true;
+rccl_api *rccl_load(rccl_api &api, char *err, size_t err_len) {
     const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     for (const char *nm : names) {
         api.so = dlopen(nm, RTLD_NOW | RTLD_LOCAL);
         if (api.so) break;
     }
     if (!api.so) {
-        snprintf(ck_err_text, sizeof ck_err_text, "librccl could not be loaded: %s", dlerror());
+        snprintf(err, err_len, "librccl could not be loaded: %s", dlerror());
         return nullptr;
     }
     api.get_unique_id = (fn_get_unique_id)dlsym(api.so, "ncclGetUniqueId");
@@ -55,11 +52,21 @@ rccl_api *rccl() {
     api.all_gather = (fn_all_gather)dlsym(api.so, "ncclAllGather");
     api.error_string = (fn_error_string)dlsym(api.so, "ncclGetErrorString");
     if (!api.get_unique_id || !api.comm_init_rank || !api.comm_destroy || !api.all_gather) {
-        snprintf(ck_err_text, sizeof ck_err_text, "librccl lacks ncclGetUniqueId/ncclCommInitRank/ncclCommDestroy/ncclAllGather");
+        snprintf(err, err_len, "librccl lacks ncclGetUniqueId/ncclCommInitRank/ncclCommDestroy/ncclAllGather");
         dlclose(api.so);
         api.so = nullptr;
         return nullptr;
     }
+    return &api;
+}
+// one host thread per GPU may arrive here at once: the table is filled exactly once (std::call_once), and every later caller
+// sees it complete or not at all
+rccl_api *rccl() {
+    static rccl_api api;
+    static std::once_flag once;
+    static char load_err[256];
+    std::call_once(once, [] { rccl_load(api, load_err, sizeof load_err); });
+    if (!api.so) { snprintf(ck_err_text, sizeof ck_err_text, "%s", load_err); return nullptr; }
     return &api;
 }
 
@@ -72,7 +79,9 @@ int rccl_fail(rccl_api *r, const char *what, int rc) {
 
 struct ck_comm {
     rccl_comm_t comm;
-    ck_handle *h;
+    ck_handle *h;       // compared with the caller's handle; never dereferenced by ck_comm_destroy / ck_comm_sync (the handle may be gone)
+    int device;         // copies of the handle's device and stream, taken at creation
+    hipStream_t stream;
     int world, rank;
     ck_vision_measurement_t *d_all; // [world][max_batch] records, device
     size_t cap_records;
@@ -99,7 +108,7 @@ extern "C" int ck_comm_create(ck_handle_t *h, const uint8_t *id_in, int32_t worl
     CK_HIP(hipSetDevice(h->device));
     ck_comm *c = new (std::nothrow) ck_comm();
     if (!c) return CK_ENOMEM;
-    c->h = h; c->world = world; c->rank = rank;
+    c->h = h; c->device = h->device; c->stream = h->stream; c->world = world; c->rank = rank;
     c->cap_records = (size_t)world * (size_t)h->cfg.max_batch;
     if (hipMalloc(&c->d_all, sizeof(ck_vision_measurement_t) * c->cap_records) != hipSuccess) { delete c; return CK_ENOMEM; }
     rccl_unique_id id;
@@ -113,34 +122,41 @@ extern "C" int ck_comm_create(ck_handle_t *h, const uint8_t *id_in, int32_t worl
 extern "C" void ck_comm_destroy(ck_comm_t *c) {
     if (!c) return;
     rccl_api *r = rccl();
-    (void)hipSetDevice(c->h->device);
-    (void)hipStreamSynchronize(c->h->stream);
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream); // (destroy the communicator BEFORE its handle: the stream is the handle's)
     if (r) (void)r->comm_destroy(c->comm);
     (void)hipFree(c->d_all);
     delete c;
 }
 
-// All-gather of the n records the last ck_process_* call of this handle left on the device (ws.d_meas), in rank order.
-// `out` may be a host or a device pointer to world*n records; with sync == 0 and a device pointer the call only enqueues
-// (the caller's next operation on the handle's stream, or ck_comm_sync, orders after it).
-extern "C" int ck_gather_poses(ck_handle_t *h, ck_comm_t *c, int32_t n, ck_vision_measurement_t *out, int32_t sync) {
-    if (!h || !c || c->h != h || !out || n < 0) return CK_EINVAL;
-    if (n > h->cfg.max_batch) return CK_ECAPACITY;
-    if (n == 0) return CK_OK;
+// All-gather of the records the last ck_process_* call of this handle left on the device (ws.d_meas), in rank order.  Every rank
+// sends `rows` records: its own n_valid (which must be what that call produced) and, behind them, empty ones (all zero: tag_count 0),
+// so that a ragged last shard needs no padding by the caller — the send buffer is the handle's own.  `out` may be a host or a device
+// pointer to world*rows records; with sync == 0 and a device pointer the call only enqueues (the caller's next operation on the
+// handle's stream, or ck_comm_sync, orders after it).
+extern "C" int ck_gather_poses(ck_handle_t *h, ck_comm_t *c, int32_t n_valid, int32_t rows, ck_vision_measurement_t *out, int32_t sync) {
+    if (!h || !c || c->h != h || !out || n_valid < 0 || rows < n_valid) return CK_EINVAL;
+    if (rows > h->cfg.max_batch) return CK_ECAPACITY;
+    if (n_valid != (h->n_last_pose < 0 ? 0 : h->n_last_pose)) {
+        snprintf(ck_err_text, sizeof ck_err_text, "ck_gather_poses: n_valid = %d, but the handle's last ck_process_* call left %d records", n_valid, h->n_last_pose);
+        return CK_EINVAL;
+    }
+    if (rows == 0) return CK_OK;
     rccl_api *r = rccl();
     if (!r) return CK_EUNSUPPORTED;
-    CK_HIP(hipSetDevice(h->device));
-    const size_t bytes = sizeof(ck_vision_measurement_t) * (size_t)n;
-    int rc = r->all_gather(h->ws.d_meas, c->d_all, bytes, /*ncclChar*/ 0, c->comm, h->stream);
+    CK_HIP(hipSetDevice(c->device));
+    if (rows > n_valid) CK_HIP(hipMemsetAsync(h->ws.d_meas + n_valid, 0, sizeof(ck_vision_measurement_t) * (size_t)(rows - n_valid), c->stream));
+    const size_t bytes = sizeof(ck_vision_measurement_t) * (size_t)rows;
+    int rc = r->all_gather(h->ws.d_meas, c->d_all, bytes, /*ncclChar*/ 0, c->comm, c->stream);
     if (rc != 0) return rccl_fail(r, "ncclAllGather", rc);
-    CK_HIP(hipMemcpyAsync(out, c->d_all, bytes * (size_t)c->world, hipMemcpyDefault, h->stream));
-    if (sync) CK_HIP(hipStreamSynchronize(h->stream));
+    CK_HIP(hipMemcpyAsync(out, c->d_all, bytes * (size_t)c->world, hipMemcpyDefault, c->stream));
+    if (sync) CK_HIP(hipStreamSynchronize(c->stream));
     return CK_OK;
 }
 
 extern "C" int ck_comm_sync(ck_comm_t *c) {
     if (!c) return CK_EINVAL;
-    CK_HIP(hipSetDevice(c->h->device));
-    CK_HIP(hipStreamSynchronize(c->h->stream));
+    CK_HIP(hipSetDevice(c->device));
+    CK_HIP(hipStreamSynchronize(c->stream));
     return CK_OK;
 }

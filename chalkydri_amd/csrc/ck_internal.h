@@ -150,6 +150,7 @@ struct ck_handle {
     ck_stage_ms_t last_ms;
     ck_dev_family *d_fams;
     int n_staged;        // frames currently staged in d_frames
+    int n_last_pose;     // records the last ck_process_* call left in ws.d_meas (what ck_gather_poses may send); -1: none yet
     bool fmerge_lds_allowed; // k_fmerge's dynamic LDS limit has been raised on this handle's device
 };
 

@@ -62,7 +62,7 @@ int ck_stage_alloc(ck_handle *h) {
         const ck_family_t *src = cfg.families[f];
         ck_dev_family &d = fams[(size_t)f];
         memset(&d, 0, sizeof d);
-        d.nbits = src->nbits; d.ncodes = src->ncodes; d.n_upstream = src->n_upstream; d.width_at_border = src->width_at_border;
+        d.nbits = src->nbits; d.ncodes = src->ncodes; d.n_upstream = src->n_upstream ? src->n_upstream : src->ncodes; /* 0 (a table built against ABI v1, or zero-initialised): the caller vouches for all of it */ d.width_at_border = src->width_at_border;
         d.total_width = src->total_width; d.reversed_border = src->reversed_border;
         for (uint32_t i = 0; i < src->nbits; i++) { d.bit_x[i] = src->bit_x[i]; d.bit_y[i] = src->bit_y[i]; }
         uint64_t *dc = nullptr;
@@ -334,6 +334,7 @@ static int process_common(ck_handle *h, const uint8_t *frames, int stride, size_
         rc = ck_run_pose(p ? &sp.view[p] : h, cnt, pp, gyro + f0, has_gyro + f0, out + f0, valid + f0, false, false);
     }
     if (rc == CK_OK) rc = join_split(h, sp, n);
+    h->n_last_pose = rc == CK_OK ? n : -1;
     CK_HIP(hipEventRecord(h->ev[6], h->stream));
     CK_HIP(hipStreamSynchronize(h->stream));
     ck_stage_ms_t &ms = h->last_ms;

@@ -418,6 +418,12 @@ __global__ __launch_bounds__(KNT) __attribute__((amdgpu_num_sgpr(80))) void k_ti
 
     if (stop_after == 2) return; // diagnostics (CK_TILE_STOP_AFTER)
     uint32_t nruns = 0; // nodes in the tile's list
+    constexpr int NPL = 8;                       // nodes per lane a tile may have for its label words to go through the table
+    constexpr uint32_t KEEP_NONE = 0xFFFFFFFFu;
+    uint32_t keep[NPL], ekeep = KEEP_NONE;       // per node this lane flattened: lookup pixel | root pixel << 16 (ekeep: its pixel of a non-origin column)
+#pragma unroll
+    for (int k = 0; k < NPL; k++) keep[k] = KEEP_NONE;
+    bool tabled = false;
     uint32_t ring_root[2] = {0xFFFFFFFFu, 0xFFFFFFFFu}, ring_white[2] = {0, 0}; // P6b: roots under this lane's ring pixels
     uint32_t nwhite = 0; // white nodes: list[0 .. nwhite); the black ones are list[TH * TW - (nruns - nwhite) .. TH * TW)
     auto list_at = [&](uint32_t j) -> uint32_t { return list[j < nwhite ? j : j + (uint32_t)(TH * TW) - nruns]; };
@@ -569,8 +575,11 @@ __global__ __launch_bounds__(KNT) __attribute__((amdgpu_num_sgpr(80))) void k_ti
     TPROF(6);
     if (stop_after == 6) return; // diagnostics (CK_TILE_STOP_AFTER)
     // ---- P6: flatten the nodes' lookup entries and add their pixels into their roots' entries; two nodes per lane and round so
-    // that two root walks are in flight (a lane past the end walks node 0 again and writes nothing)
-    for (uint32_t j0 = 0; j0 < nruns; j0 += 2 * KNT) {
+    // that two root walks are in flight (a lane past the end walks node 0 again and writes nothing).  A tile with at most NPL
+    // nodes per lane (every tile of a natural image; dense binary noise has four) keeps each node's lookup pixel and root in
+    // registers: its label words are formed once per NODE after the ring-touching roots have their ids (P6c) and the label pass
+    // reads them from a table (P7).
+    auto flatten2 = [&](uint32_t j0, uint32_t &keep0, uint32_t &keep1) {
         uint32_t node[2], root[2], add[2];
         bool live[2];
 #pragma unroll
@@ -601,7 +610,16 @@ __global__ __launch_bounds__(KNT) __attribute__((amdgpu_num_sgpr(80))) void k_ti
                 // other half of the word)
                 atomicAdd(&parent32[root[q] >> 1], add[q] << ((root[q] & 1u) * 16u));
             }
-    }
+        keep0 = live[0] ? (node[0] | (root[0] << 16)) : KEEP_NONE;
+        keep1 = live[1] ? (node[1] | (root[1] << 16)) : KEEP_NONE;
+    };
+    tabled = nruns <= (uint32_t)(NPL * KNT);
+    if (tabled) {
+#pragma unroll
+        for (int k = 0; k < NPL / 2; k++)
+            if ((uint32_t)(k * 2 * KNT) < nruns) flatten2((uint32_t)(k * 2 * KNT), keep[2 * k], keep[2 * k + 1]);
+    } else
+        for (uint32_t j0 = 0; j0 < nruns; j0 += 2 * KNT) { uint32_t k0, k1; flatten2(j0, k0, k1); }
     if (tid >= 3 * 64 && (tx0 == 0 || tx0 + TW >= w)) { // the non-origin columns' pixels: one pixel each
         int r, xl; uint32_t ec;
         if (edge_pixel(mk, tid & 63, tx0, ty0, w, h, r, xl, ec)) {
@@ -610,6 +628,7 @@ __global__ __launch_bounds__(KNT) __attribute__((amdgpu_num_sgpr(80))) void k_ti
             for (;;) { __asm__ volatile("" ::: "memory"); const uint32_t n0 = parent[root]; if (n0 & CK_ROOT) break; root = n0; }
             if (root != me) parent[me] = (uint16_t)root;
             atomicAdd(&parent32[root >> 1], 1u << ((root & 1u) * 16u));
+            ekeep = me | (root << 16);
         }
     }
     __syncthreads();
@@ -680,7 +699,107 @@ __global__ __launch_bounds__(KNT) __attribute__((amdgpu_num_sgpr(80))) void k_ti
         if (tile_has_runs && ring_root[rnd] != 0xFFFFFFFFu) val = ((uint32_t)parent[ring_root[rnd]] & 0x1FFu) | (ring_white[rnd] << 15);
         ring_f[dst] = (uint16_t)val;
     }
+    const uint32_t gbase = (uint32_t)ty0 * (uint32_t)w + (uint32_t)tx0;
+    const uint32_t slot0 = CK_LBL_BORDER | ((uint32_t)tile * RING_CAP);
+    const uint32_t w24 = (uint32_t)w & 0xFFFFFFu; // (the compiler then sees two 24-bit factors: a full-rate multiply instead of a 64-bit one)
+    if (!tile_has_runs || tabled) {
+    // ---- P6c: the label word of every node, formed once per node from its root's entry (interior component: the root's pixel index,
+    // final; ring-touching: the component's slot in the frame's tables) and, behind a barrier — every read of the union-find is done —
+    // written to a table of 32-bit words over the parent and list arrays, indexed by the node's lookup pixel.
+    uint32_t *tab32 = reinterpret_cast<uint32_t *>(lds);
+    if (tile_has_runs) {
+        auto label_word = [&](uint32_t kp) -> uint32_t {
+            const uint32_t root = kp >> 16;
+            const uint32_t ce = parent[root & (uint32_t)(TH * TW - 1)]; // (KEEP_NONE: a harmless in-range read, the word is not used)
+            return (ce & CK_RING) ? slot0 + (ce & 0x1FFu)
+                                  : ((gbase + (root >> 7) * w24 + (root & (TW - 1))) | ((int)(ce & CK_COUNT) < min_comp ? CK_LBL_SMALL : 0u));
+        };
+        uint32_t lw[NPL], elw;
+#pragma unroll
+        for (int k = 0; k < NPL; k++) lw[k] = label_word(keep[k]);
+        elw = label_word(ekeep);
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < NPL; k++)
+            if (keep[k] != KEEP_NONE) tab32[keep[k] & 0xFFFu] = lw[k];
+        if (ekeep != KEEP_NONE) tab32[ekeep & 0xFFFu] = elw;
+        __syncthreads();
+    }
     // ---- P7: write label words.  Two passes; in pass q lane L owns the 4-column group L & 31 of pair q * 8 + (L >> 5): both rows, so
+    // that the search for a column's node (per colour: the nearest node start at or below it, then the row of that node's lookup
+    // pixel) is shared by the column's two pixels; a wave's store instruction covers two stretches of 512 contiguous bytes.  One
+    // table lookup per pixel.
+    {
+        const int g = tid & 31, wd = g >> 3, sh = 4 * (g & 7);       // the same for the lane's two passes
+        const int gx = tx0 + 4 * g;
+        const uint32_t Oo = ck_origin32(tx0 + 32 * wd, w);
+        const uint32_t edge4 = (~Oo >> sh) & 15u;     // columns of the group that are non-origin columns of the frame: their pixels are nodes of their own
+        if (gx < w)
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const int pr = q * (KNT / 32) + (tid >> 5);
+            const int gy = ty0 + 2 * pr;
+            if (gy >= h) continue;
+            const uint32_t pbase = (uint32_t)((2 * pr) * TW + 32 * wd), cbase = pbase + (uint32_t)sh;
+            uint32_t outw[2][4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) outw[0][k] = outw[1][k] = CK_LBL_INVALID;
+            if (tile_has_runs) {
+                const uint2 m4 = *reinterpret_cast<const uint2 *>(&mk[((2 * pr) * NWD + wd) * 2]);          // top row: white, black word ...
+                const uint2 b4 = *reinterpret_cast<const uint2 *>(&mk[((2 * pr + 1) * NWD + wd) * 2]);      // ... and the bottom row's
+                const uint32_t any_t = ((m4.x | m4.y) >> sh) & 15u, any_b = ((b4.x | b4.y) >> sh) & 15u;
+                if (any_t | any_b) {
+                    const uint2 s2 = *reinterpret_cast<const uint2 *>(&s2w[(pr * NWD + wd) * 2]);
+                    // node starts whose lookup pixel is in the bottom row: the first column has no top pixel
+                    const uint32_t lowW = s2.x & ~(m4.x & Oo), lowB = s2.y & ~(m4.y & Oo);
+                    uint32_t at[2][4];
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const uint32_t upto = (2u << (sh + k)) - 1u;
+                        const uint32_t cw = 31u - (uint32_t)__builtin_clz((s2.x & upto) | 1u), cb = 31u - (uint32_t)__builtin_clz((s2.y & upto) | 1u);
+                        const uint32_t atw = pbase + cw + (((lowW >> cw) & 1u) << 7), atb = pbase + cb + (((lowB >> cb) & 1u) << 7);
+                        // (a pixel without a colour looks up a harmless in-range word that is not used)
+                        const uint32_t wt = 0u - ((m4.x >> (sh + k)) & 1u), wbm = 0u - ((b4.x >> (sh + k)) & 1u);
+                        at[0][k] = (atw & wt) | (atb & ~wt);
+                        at[1][k] = (atw & wbm) | (atb & ~wbm);
+                    }
+                    if (edge4) // (only the lanes at the frame's first and last column)
+#pragma unroll
+                        for (int k = 0; k < 4; k++)
+                            if ((edge4 >> k) & 1u) { at[0][k] = cbase + (uint32_t)k; at[1][k] = cbase + (uint32_t)(TW + k); }
+                    uint32_t lwv[2][4];
+#pragma unroll
+                    for (int r = 0; r < 2; r++)
+#pragma unroll
+                        for (int k = 0; k < 4; k++) lwv[r][k] = tab32[at[r][k]];
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        outw[0][k] = ((any_t >> k) & 1u) ? lwv[0][k] : CK_LBL_INVALID;
+                        outw[1][k] = ((any_b >> k) & 1u) ? lwv[1][k] : CK_LBL_INVALID;
+                    }
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 2; r++) {
+                if (gy + r >= h) continue;
+                uint32_t *dst = labels + fbase + (size_t)(gy + r) * w + gx;
+                if (packed_rows) {
+                    // (the empty asm keeps the compiler from merging this store with the per-pixel ones of the other branch: merged, it
+                    // became a 12-byte store plus a 4-byte one)
+                    __asm__ volatile("" ::: "memory");
+                    *reinterpret_cast<uint4 *>(dst) = make_uint4(outw[r][0], outw[r][1], outw[r][2], outw[r][3]);
+                    __asm__ volatile("" ::: "memory");
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; k++)
+                        if (gx + k < w) dst[k] = outw[r][k];
+                }
+            }
+        }
+    }
+    } else {
+    // a tile with more nodes than its lanes keep (one-pixel patterns): the label pass looks every pixel's root up itself
+    // ---- P7 (direct): Two passes; in pass q lane L owns the 4-column group L & 31 of pair q * 8 + (L >> 5): both rows, so
     // that the search for a column's node (per colour: the nearest node start at or below it, then the row of that node's lookup
     // entry) is shared by the column's two pixels; a wave's store instruction covers two stretches of 512 contiguous bytes.  A
     // pixel's entry is either its component's root entry (CK_ROOT | flags | count or id) or the root's pixel: at most two lookups.
@@ -689,9 +808,6 @@ __global__ __launch_bounds__(KNT) __attribute__((amdgpu_num_sgpr(80))) void k_ti
         const int gx = tx0 + 4 * g;
         const uint32_t Oo = ck_origin32(tx0 + 32 * wd, w);
         const uint32_t below = (1u << sh) - 1u;
-        const uint32_t gbase = (uint32_t)ty0 * (uint32_t)w + (uint32_t)tx0;
-        const uint32_t slot0 = CK_LBL_BORDER | ((uint32_t)tile * RING_CAP);
-        const uint32_t w24 = (uint32_t)w & 0xFFFFFFu; // (the compiler then sees two 24-bit factors: a full-rate multiply instead of a 64-bit one)
         const uint32_t edge4 = (~Oo >> sh) & 15u;     // columns of the group that are non-origin columns of the frame: their pixels are nodes of their own
         if (gx < w)
 #pragma unroll
@@ -765,6 +881,7 @@ __global__ __launch_bounds__(KNT) __attribute__((amdgpu_num_sgpr(80))) void k_ti
                 }
             }
         }
+    }
     }
     TPROF(8);
 }
@@ -1260,7 +1377,7 @@ int ck_launch_threshold_segment(ck_handle *h, const uint8_t *frames, int stride,
         hipLaunchKernelGGL(k_tile<false>, dim3(grid), dim3(KNT), 0, h->stream, frames, frame_pitch, stride, h->qw, h->qh,
                            h->tiles_x, h->tiles_y, n, xcd_map, h->cfg.min_white_black_diff, h->cfg.min_component_px, h->d_thresh, h->d_labels,
                            h->d_broots, h->d_tile_count, h->d_ring, h->ring_len, stop_after, sweeps);
-    {
+    if (stop_after == 99) { // (a k_tile cut short by the diagnostics knob leaves tile counts or ring entries unwritten: nothing for the merge to read)
         static const int fm_stop = getenv("CK_FMERGE_STOP_AFTER") ? atoi(getenv("CK_FMERGE_STOP_AFTER")) : 99;
         const char *cap_env = getenv("CK_FMERGE_CAP"); // tests force the global-memory path with a small value (read per call)
         // roots the LDS path of one workgroup holds (dense binary noise has about 90 per tile).  A frame whose roots fit is joined by ONE

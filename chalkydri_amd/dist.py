@@ -91,7 +91,7 @@ class PoseComm:
         L.ck_comm_create.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]
         L.ck_comm_destroy.argtypes = [C.c_void_p]
         L.ck_comm_destroy.restype = None
-        L.ck_gather_poses.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32]
+        L.ck_gather_poses.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32]
         L.ck_comm_sync.argtypes = [C.c_void_p]
         L.ck_backend.argtypes = [C.c_void_p]
         self._L, self._det, self.world, self.rank = L, detector, world, rank
@@ -109,15 +109,18 @@ class PoseComm:
         self._c = c
         self._A = A
 
-    def gather(self, n, out_ptr=None, sync=True):
-        """All-gather of the n records of the handle's last process call.  out_ptr: device or host address of world*n records
-        (default: a fresh host array, returned as a structured numpy array)."""
+    def gather(self, n, out_ptr=None, sync=True, rows=None):
+        """All-gather of the n records of the handle's last process call.  rows (default n): the common row count of the
+        collective, the same on every rank; a rank whose shard is shorter (n < rows) sends empty records behind its own — the
+        library pads, the send buffer being the handle's.  out_ptr: device or host address of world*rows records (default: a
+        fresh host array, returned as [world*rows, 64] uint8)."""
         from ._lib import check
+        rows = n if rows is None else rows
         if out_ptr is not None:
-            check(self._L.ck_gather_poses(self._det._h, self._c, n, out_ptr, 1 if sync else 0), "ck_gather_poses")
+            check(self._L.ck_gather_poses(self._det._h, self._c, n, rows, out_ptr, 1 if sync else 0), "ck_gather_poses")
             return None
-        buf = np.zeros((self.world * n, RECORD_BYTES), np.uint8)
-        check(self._L.ck_gather_poses(self._det._h, self._c, n, buf.ctypes.data, 1), "ck_gather_poses")
+        buf = np.zeros((self.world * rows, RECORD_BYTES), np.uint8)
+        check(self._L.ck_gather_poses(self._det._h, self._c, n, rows, buf.ctypes.data, 1), "ck_gather_poses")
         return buf
 
     def sync(self):

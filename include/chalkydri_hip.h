@@ -82,7 +82,9 @@ typedef struct ck_family {
     uint32_t n_upstream;      /* IDs 0..n_upstream-1 are known to equal the upstream AprilTag table of this name.  A caller
                                * that passes upstream's own table sets n_upstream = ncodes.  Detections with a larger id
                                * raise CK_FRAME_UNVERIFIED_ID and are ignored by the pose glue unless
-                               * ck_process_params_t.allow_unverified_ids is set. */
+                               * ck_process_params_t.allow_unverified_ids is set.  0 (a zero-initialised table, or one
+                               * built against ABI version 1, which had no such field) means ncodes: the caller vouches
+                               * for its table; a value above ncodes is refused by ck_create (CK_EINVAL). */
 } ck_family_t;
 
 /* Built-in tables.  "tag16h5": all 30 upstream codes (n_upstream = 30).  "tag36h11": upstream layout, 587 codes of which
@@ -102,7 +104,7 @@ typedef struct ck_config {
     /* AprilTag-3 detector defaults the reference inherits unchanged */
     int32_t quad_decimate;        /* 1 (full resolution) or 2 (AT3 default) */
     int32_t min_white_black_diff; /* 5 */
-    int32_t min_component_px;     /* 25: components smaller than this emit no boundary points (1..127) */
+    int32_t min_component_px;     /* 25: components smaller than this emit no boundary points (>= 1) */
     int32_t min_cluster_pixels;   /* 24: smallest cluster handed to the quad fitter */
     int32_t max_nmaxima;          /* 10 */
     double cos_critical_rad;      /* cos(10 deg) */
@@ -139,9 +141,10 @@ const char *ck_strerror(int code);
 const char *ck_last_error(void); /* text of the most recent CK_EDEVICE on this thread */
 int ck_device_count(void);       /* 0 when no HIP device is visible */
 
-/* Frame geometry accepted by ck_create (checked on the image the front end works on, i.e. after quad_decimate): 16..4095
- * pixels per side, width a multiple of 4, any height except 64k+1..64k+3 (CK_EUNSUPPORTED otherwise); quad_decimate 1 or 2;
- * min_component_px 1..127.  Arguments are validated before a device is looked for (CK_ENODEVICE). */
+/* Frame geometry accepted by ck_create: any width and height of 16..4095 pixels (at least 8 after quad_decimate) — what an
+ * image_u8_t can describe within the 13-bit half-pixel coordinates of the boundary points; quad_decimate 1 or 2
+ * (CK_EUNSUPPORTED otherwise); min_component_px >= 1; 1..CK_MAX_FAMILIES families, each with n_upstream <= ncodes.
+ * CK_EINVAL for everything else.  Arguments are validated before a device is looked for (CK_ENODEVICE). */
 int ck_create(const ck_config_t *cfg, ck_handle_t **out);
 void ck_destroy(ck_handle_t *h);
 
@@ -346,11 +349,14 @@ int ck_backend(const ck_handle_t *h);                      /* CK_BACKEND_HIP: th
 int ck_comm_unique_id(uint8_t *id_out);                    /* rank 0: id_out[CK_COMM_ID_BYTES] */
 int ck_comm_create(ck_handle_t *h, const uint8_t *id, int32_t world, int32_t rank, ck_comm_t **out); /* collective: every rank calls it */
 void ck_comm_destroy(ck_comm_t *comm);
-/* Gathers the n records the handle's last ck_process_* call produced (they are still on the device) from every rank into
- * out[world*n] in rank order; n must be the same on every rank (pad a ragged last shard with tag_count = 0 records, which
- * is what a frame without a pose publishes anyway: crates/apriltags/src/lib.rs:365-376).  `out` may be a host or a device
- * pointer.  sync = 0 only enqueues on the handle's stream; ck_comm_sync (or the next synchronous call) completes it. */
-int ck_gather_poses(ck_handle_t *h, ck_comm_t *comm, int32_t n, ck_vision_measurement_t *out, int32_t sync);
+/* Gathers the records the handle's last ck_process_* call produced (they are still on the device) from every rank into
+ * out[world*rows] in rank order.  n_valid = the frames of that call (CK_EINVAL when it is not: the send buffer is the handle's
+ * own, so a wrong count would ship stale records); rows = the common row count of the collective, the same on every rank,
+ * n_valid <= rows <= max_batch: the library pads a ragged last shard with empty records (all zero, tag_count = 0 — what a
+ * frame without a pose publishes anyway: crates/apriltags/src/lib.rs:365-376).  `out` may be a host or a device pointer.
+ * sync = 0 only enqueues on the handle's stream; ck_comm_sync (or the next synchronous call) completes it.  Destroy a
+ * communicator before the handle it was made for. */
+int ck_gather_poses(ck_handle_t *h, ck_comm_t *comm, int32_t n_valid, int32_t rows, ck_vision_measurement_t *out, int32_t sync);
 int ck_comm_sync(ck_comm_t *comm);
 
 /* OpenCVModel5 unprojection of pixel points to bearings (x,y,1)/norm; ok[i]=0 when it does not converge. */

@@ -235,7 +235,12 @@ comm.gather(n, out_ptr=d_out.data_ptr(), sync=False)
 comm.sync()
 for i in range(n):
     assert bytes(host[i]) == bytes(want[i]) == bytes(d_out[i].cpu().numpy())
-assert task.detector._L.ck_gather_poses(task.detector._h, comm._c, n + 1, d_out.data_ptr(), 1) == -5      # CK_ECAPACITY
+assert task.detector._L.ck_gather_poses(task.detector._h, comm._c, n, n + 1, d_out.data_ptr(), 1) == -5      # CK_ECAPACITY: rows beyond max_batch
+assert task.detector._L.ck_gather_poses(task.detector._h, comm._c, n - 1, n, d_out.data_ptr(), 1) == -1      # CK_EINVAL: not what the last call produced
+# a ragged shard: the last process call produced n - 1 records, the collective's row count is n: the library pads with an empty record
+task.process_uploaded_into(n - 1, d_gyro.data_ptr(), d_has.data_ptr(), d_rec.data_ptr(), d_valid.data_ptr())
+ragged = comm.gather(n - 1, rows=n)
+assert ragged.shape == (n, 64) and all(bytes(ragged[i]) == bytes(want[i]) for i in range(n - 1)) and not ragged[n - 1].any()
 comm.close()
 tdist.destroy_process_group()
 print("GATHER OK")
