@@ -138,6 +138,12 @@ __device__ __forceinline__ uint32_t msb_nibble(uint32_t v) {
     return (((v >> 7) & 0x01010101u) * 0x01020408u) >> 24 & 0xFu;
 }
 
+// v_ffbl_b32: index of the lowest set bit, 0xFFFFFFFF for 0 (what __builtin_ctz leaves undefined)
+__device__ __forceinline__ uint32_t ffbl_raw(uint32_t v) {
+    uint32_t r;
+    __asm__("v_ffbl_b32 %0, %1" : "=v"(r) : "v"(v));
+    return r;
+}
 // One pair word of the tile (rows 2p and 2p + 1, one 32-pixel word, one colour) as its lane sees it: its nodes, the nodes of the
 // pair word above, and the links between them that have not been used yet (ck_links.h: the links of the two facing rows, keyed by
 // the lower pixel; here every mask is already ANDed with the origin flags, so the rule's origin tests are all true).  Read from
@@ -465,32 +471,39 @@ __global__ __launch_bounds__(KNT) __attribute__((amdgpu_num_sgpr(80))) void k_ti
         Ut = has_u ? Ut : 0u; Ub = has_u ? Ub : 0u; S2u = has_u ? S2u : 0u;
         info_ul = (has_u && has_l) ? info_ul : 0u; info_ur = (has_u && has_r) ? info_ur : 0u;
         const ck_word_links K = ck_links_of_word(white, Mt, Ub, 0xFFFFFFFFu, false, ((info_ul >> 12) & 1u) != 0, ((info_ur >> 13) & 1u) != 0, true);
-        const uint32_t Ev = K.Ev, DL = K.DL & ~1u, DR = K.DR & 0x7FFFFFFFu; // (the two links across a word boundary are flags)
-        // the first link of every node: the lowest set bit of every segment [start, next start) of E — with a stopper at every
-        // segment's last column, subtracting the start bits runs a borrow up to exactly that bit
+        const uint32_t DL = K.DL & ~1u, DR = K.DR & 0x7FFFFFFFu; // (the two links across a word boundary are flags)
+        // Several one-row runs of a node can face the same node of the pair above: of the vertical links between one pair of nodes
+        // only the first is kept — the first set bit of every segment of the two start masks taken together.  (First set bit of
+        // every segment [start, next start) of a word: with a stopper at every segment's last column, subtracting the start bits
+        // runs a borrow up to exactly that bit.)
+        const uint32_t Sc = S2 | S2u;
+        const uint32_t Evp = K.Ev | (Sc >> 1) | 0x80000000u;
+        const uint32_t Ev = Evp & ~(Evp - Sc) & K.Ev;
+        // the first link of every node: the one it adopts its parent through
         const uint32_t E = Ev | DL | DR;
         const uint32_t Ep = E | (S2 >> 1) | 0x80000000u;
         const uint32_t F = Ep & ~(Ep - S2) & E;
+        const uint32_t Fm = F & DL, Fp = F & DR & ~DL; // ... goes up-left / up-right (else straight up)
         // (a), (b)
         const uint32_t cnt = (uint32_t)__popc(S2);
         const uint32_t incl = wave_scan_u32(cnt);
         if ((tid & 63) == 63) misc[c] = incl;
         uint32_t li = c ? (uint32_t)(TH * TW - 1) - (incl - cnt) : incl - cnt; // white from the front, black from the back
-        const uint32_t lstep = c ? 0xFFFFFFFFu : 1u, lcol = (uint32_t)c << 12;
+        const uint32_t lstep = c ? 0xFFFFFFFFu : 1u, lcol = ((uint32_t)c << 12) | base;
+        const uint32_t nMt = ~Mt, nUt = ~Ut;
         for (uint32_t St = S2; St;) {
             const uint32_t low = St & (0u - St);
-            const int s = __builtin_ctz(low);
+            const uint32_t s = ffbl_raw(low);
             St ^= low;
-            const uint32_t span = ((St & (0u - St)) - 1u) & ~(low - 1u); // the node's columns: bit s up to the next start
-            const uint32_t lk = pair_entry(Mt, base, s);
-            const uint32_t T = Mt & span;
-            const uint32_t mn = T ? base + (uint32_t)__builtin_ctz(T) : lk; // (a top pixel in column s: T's lowest bit is s, mn == lk)
-            const uint32_t e = F & span;
-            const int x = __builtin_ctz(e | 0x80000000u);
-            const int ux = ((Ev >> x) & 1u) ? x : (((DL >> x) & 1u) ? x - 1 : x + 1);
-            const uint32_t t_up = pair_entry(Ut, upbase, ck_run_start32(S2u, ux & 31));
-            parent[lk] = (uint16_t)mn;                       // (in this order: the two are one entry when the node's first column has a top pixel)
-            parent[mn] = (uint16_t)(e ? t_up : CK_ROOT);     // no link to an earlier node: a root (count 0 for now)
+            const uint32_t span = ((St & (0u - St)) - 1u) & ~(low - 1u);     // the node's columns: bit s up to the next start
+            const uint32_t lk = s | (((nMt >> s) & 1u) << 7);                 // word-local: + TW for the bottom row
+            const uint32_t mn = min(ffbl_raw(Mt & span), lk);                 // its first top pixel, if it has one (ffbl of 0 is 0xFFFFFFFF)
+            const uint32_t e = F & span;                                      // the link it adopts through (at most one bit)
+            const uint32_t ue = (e & ~(Fm | Fp)) | ((e & Fm) >> 1) | ((e & Fp) << 1); // the pixel of the row above at its other end
+            const uint32_t su = 31u - (uint32_t)__builtin_clz((S2u & ((ue << 1) - 1u)) | 1u);
+            const uint32_t t_up = upbase + su + (((nUt >> su) & 1u) << 7);
+            parent[base + lk] = (uint16_t)(base + mn);           // (in this order: the two are one entry when the node's first column has a top pixel)
+            parent[base + mn] = (uint16_t)(e ? t_up : CK_ROOT);  // no link to an earlier node: a root (count 0 for now)
             list[li] = (uint16_t)(lk | lcol);
             li += lstep;
         }
