@@ -38,7 +38,7 @@ constexpr int IMG_ROWS = TH + 8;
 constexpr int T4X = TW / 4 + 2, T4Y = TH / 4 + 2; // 4x4-tile min/max grid of the staged region (one ring around the tile's own)
 static_assert((TH / 2) * NWD == 64, "k_tile node phases: one wave per colour, one lane per (pair of rows, word)");
 static_assert(TH * 8 == KNT, "threshold / label passes: one 16-pixel chunk per thread");
-static_assert(TH * TW <= 4096, "run list entries keep the node in 12 bits, the colour in bit 12");
+static_assert(TH * TW <= 4096, "list entries keep the node in 12 bits, the colour in bit 12");
 static_assert(TW == 128, "a node index splits with >> 7 / & 127");
 
 // LDS of k_tile, 19.6 KB, so that eight workgroups (32 waves: all a CU can hold) share a CU:
@@ -55,15 +55,18 @@ static_assert(TW == 128, "a node index splits with >> 7 / & 127");
 //                       looks up at most two);
 //                       while the threshold is computed the same bytes hold the staged image and the 4x4 min/max (the
 //                       per-4x4 threshold words sit in the list's bytes, which is not alive yet)
-//   list    u16[TH*TW]  the tile's nodes: lookup pixel | colour << 12; the white ones from the front, the black ones from the back (the
-//                       two waves that build it need not know each other's counts)
+//   list    u32[LIST_CAP]  the tile's nodes: lookup pixel | colour << 12 | pixel count << 16; the white ones from the front, the black ones
+//                       from the back (the two waves that build it need not know each other's counts); a tile with more nodes
+//                       (one-pixel patterns) does without the list
 //   pool    u32[POOL_CAP]  links that need an atomic union (two u16 entries each)
 //   masks   u32[TH][NWD][2]  colour bits of every row word (0 white, 1 black)
 //   starts  u32[TH/2][NWD][2]  node starts of every pair word
 constexpr int OFF_PARENT = 0;                              // u16[TH*TW] = 8192
 constexpr int OFF_IMG = 0;                                 // IMG_ROWS*IMG_PITCH = 6400
 constexpr int OFF_MINMAX = OFF_IMG + IMG_ROWS * IMG_PITCH; // u32[T4Y*T4X] = 1360 (one dword per 4x4 tile: the dilation's neighbour reads stay 4-byte aligned)
-constexpr int OFF_LIST = TH * TW * 2;                      // u16[TH*TW] = 8192
+constexpr int OFF_LIST = TH * TW * 2;                      // u32[LIST_CAP] = 8192
+constexpr int LIST_CAP = 2048;                             // nodes the list holds (dense binary noise has about 800 per tile)
+static_assert(LIST_CAP % (2 * KNT) == 0 && LIST_CAP * 4 == TH * TW * 2, "the list fills the 8 KB behind the parent array");
 constexpr int OFF_THR = OFF_LIST;                          // u16[(TH/4)*(TW/4)] = 512 (the run list is not alive yet)
 constexpr int POOL_CAP = 512;                              // dense binary noise leaves about 150 links per tile for the pool
 constexpr int OFF_POOL = OFF_LIST + TH * TW * 2;           // u32[POOL_CAP] = 2048
@@ -269,7 +272,7 @@ __global__ __launch_bounds__(KNT) __attribute__((amdgpu_num_sgpr(80))) void k_ti
     const size_t fbase = (size_t)frame * (size_t)w * (size_t)h;
     uint16_t *parent = reinterpret_cast<uint16_t *>(lds + OFF_PARENT);
     uint32_t *parent32 = reinterpret_cast<uint32_t *>(lds + OFF_PARENT);
-    uint16_t *list = reinterpret_cast<uint16_t *>(lds + OFF_LIST);
+    uint32_t *list = reinterpret_cast<uint32_t *>(lds + OFF_LIST); // [LIST_CAP]
     uint32_t *mk = reinterpret_cast<uint32_t *>(lds + OFF_MASK);
     uint32_t *misc = reinterpret_cast<uint32_t *>(lds + OFF_MISC); // [0] / [1] white / black nodes, [5] pooled links, [6] / [7] white / black ring-touching roots, [8] some 4x4 tile has contrast, [9] some pixel has a colour
     if (tid == 0) { misc[5] = 0; misc[6] = 0; misc[7] = 0; misc[8] = 0; misc[9] = 0; } // (the barrier after P0 publishes them)
@@ -424,15 +427,15 @@ __global__ __launch_bounds__(KNT) __attribute__((amdgpu_num_sgpr(80))) void k_ti
 
     if (stop_after == 2) return; // diagnostics (CK_TILE_STOP_AFTER)
     uint32_t nruns = 0; // nodes in the tile's list
-    constexpr int NPL = 8;                       // nodes per lane a tile may have for its label words to go through the table
+    constexpr int NPL = LIST_CAP / KNT;          // nodes per lane a tile may have for its label words to go through the table
     constexpr uint32_t KEEP_NONE = 0xFFFFFFFFu;
     uint32_t keep[NPL], ekeep = KEEP_NONE;       // per node this lane flattened: lookup pixel | root pixel << 16 (ekeep: its pixel of a non-origin column)
 #pragma unroll
     for (int k = 0; k < NPL; k++) keep[k] = KEEP_NONE;
     bool tabled = false;
     uint32_t ring_root[2] = {0xFFFFFFFFu, 0xFFFFFFFFu}, ring_white[2] = {0, 0}; // P6b: roots under this lane's ring pixels
-    uint32_t nwhite = 0; // white nodes: list[0 .. nwhite); the black ones are list[TH * TW - (nruns - nwhite) .. TH * TW)
-    auto list_at = [&](uint32_t j) -> uint32_t { return list[j < nwhite ? j : j + (uint32_t)(TH * TW) - nruns]; };
+    uint32_t nwhite = 0; // white nodes: list[0 .. nwhite); the black ones are list[LIST_CAP - (nruns - nwhite) .. LIST_CAP)
+    auto list_at = [&](uint32_t j) -> uint32_t { return list[j < nwhite ? j : j + (uint32_t)LIST_CAP - nruns]; };
     uint32_t *s2w = reinterpret_cast<uint32_t *>(lds + OFF_S2);
     if (tile_has_runs) {
     // ---- P4: the nodes (ck_links.h, "nodes over PAIRS of rows").  One lane per (pair of rows, word) and one wave per colour: wave 0
@@ -488,7 +491,7 @@ __global__ __launch_bounds__(KNT) __attribute__((amdgpu_num_sgpr(80))) void k_ti
         const uint32_t cnt = (uint32_t)__popc(S2);
         const uint32_t incl = wave_scan_u32(cnt);
         if ((tid & 63) == 63) misc[c] = incl;
-        uint32_t li = c ? (uint32_t)(TH * TW - 1) - (incl - cnt) : incl - cnt; // white from the front, black from the back
+        uint32_t li = c ? (uint32_t)(LIST_CAP - 1) - (incl - cnt) : incl - cnt; // white from the front, black from the back
         const uint32_t lstep = c ? 0xFFFFFFFFu : 1u, lcol = ((uint32_t)c << 12) | base;
         const uint32_t nMt = ~Mt, nUt = ~Ut;
         for (uint32_t St = S2; St;) {
@@ -504,7 +507,9 @@ __global__ __launch_bounds__(KNT) __attribute__((amdgpu_num_sgpr(80))) void k_ti
             const uint32_t t_up = upbase + su + (((nUt >> su) & 1u) << 7);
             parent[base + lk] = (uint16_t)(base + mn);           // (in this order: the two are one entry when the node's first column has a top pixel)
             parent[base + mn] = (uint16_t)(e ? t_up : CK_ROOT);  // no link to an earlier node: a root (count 0 for now)
-            list[li] = (uint16_t)(lk | lcol);
+            // the list entry: lookup pixel | colour << 12 | pixel count << 16.  (A tile with more nodes than the list holds — one-pixel
+            // patterns — does without it: the index then runs past either end and nothing is stored.)
+            if (li < (uint32_t)LIST_CAP) list[li] = lk | lcol | (((uint32_t)__popc(Mt & span) + (uint32_t)__popc(Mb & span)) << 16);
             li += lstep;
         }
         // (c)
@@ -539,6 +544,8 @@ __global__ __launch_bounds__(KNT) __attribute__((amdgpu_num_sgpr(80))) void k_ti
     // ---- P5b: one pointer-jumping sweep over the (static) adoption forest: a node's parent lies in an earlier pair (or earlier in
     // its own), so the chains down a tag edge (one hop per pair, two where a lookup entry sits in between) are shortened before
     // the finds of the next two phases walk them
+    tabled = nruns <= (uint32_t)LIST_CAP;
+    if (tabled)
     for (int sweep = 0; sweep < sweeps; sweep++)
     for (uint32_t j = (uint32_t)tid; j < nruns; j += KNT) {
         const uint32_t pe = list_at(j) & 0xFFFu;
@@ -546,7 +553,7 @@ __global__ __launch_bounds__(KNT) __attribute__((amdgpu_num_sgpr(80))) void k_ti
         const uint32_t g = parent[q & 0xFFFu]; // (a root's own entry has no parent to look at: the read is harmless, the result unused)
         if (!(q & CK_ROOT) && !(g & CK_ROOT)) parent[pe] = (uint16_t)g;
     }
-    __syncthreads();
+    if (sweeps) __syncthreads(); // (uniform)
     TPROF(5);
     if (stop_after == 5) return; // diagnostics (CK_TILE_STOP_AFTER)
     // ---- P5c: the pooled links, one lane per link, through the atomic union ------------------------------------------
@@ -588,10 +595,11 @@ __global__ __launch_bounds__(KNT) __attribute__((amdgpu_num_sgpr(80))) void k_ti
     TPROF(6);
     if (stop_after == 6) return; // diagnostics (CK_TILE_STOP_AFTER)
     // ---- P6: flatten the nodes' lookup entries and add their pixels into their roots' entries; two nodes per lane and round so
-    // that two root walks are in flight (a lane past the end walks node 0 again and writes nothing).  A tile with at most NPL
-    // nodes per lane (every tile of a natural image; dense binary noise has four) keeps each node's lookup pixel and root in
-    // registers: its label words are formed once per NODE after the ring-touching roots have their ids (P6c) and the label pass
-    // reads them from a table (P7).
+    // that two root walks are in flight (a lane past the end walks node 0 again and writes nothing).  The lane keeps each node's
+    // lookup pixel and root in registers: the label words are formed once per NODE after the ring-touching roots have their ids
+    // (P6c) and the label pass reads them from a table (P7).  A tile with more nodes than the list holds (LIST_CAP = NPL nodes per
+    // lane: one-pixel patterns; dense binary noise has four per lane) walks its nodes per pair word instead, and its label pass
+    // looks every pixel's root up itself.
     auto flatten2 = [&](uint32_t j0, uint32_t &keep0, uint32_t &keep1) {
         uint32_t node[2], root[2], add[2];
         bool live[2];
@@ -600,13 +608,8 @@ __global__ __launch_bounds__(KNT) __attribute__((amdgpu_num_sgpr(80))) void k_ti
             const uint32_t j = j0 + (uint32_t)(q * KNT + tid);
             live[q] = j < nruns;
             const uint32_t e = list_at(live[q] ? j : 0u);
-            const uint32_t pe = e & 0xFFFu, ec = e >> 12;
-            const int wdd = (int)(pe >> 5) & 3, s = (int)(pe & 31u), pp = (int)(pe >> 8);
-            const uint32_t O = ck_origin32(tx0 + 32 * wdd, w);
-            const int mi = ((2 * pp) * NWD + wdd) * 2 + (int)ec;
-            const uint32_t span = ck_span32(s2w[(pp * NWD + wdd) * 2 + (int)ec], s) & O;
-            node[q] = pe; root[q] = pe;
-            add[q] = (uint32_t)__popc(mk[mi] & span) + (uint32_t)__popc(mk[mi + 2 * NWD] & span);
+            node[q] = e & 0xFFFu; root[q] = node[q];
+            add[q] = e >> 16;
         }
         for (int it = 0; it < TH * TW; it++) { // plain loads behind a compiler barrier: the two reads of a step go out together
             __asm__ volatile("" ::: "memory");
@@ -626,13 +629,25 @@ __global__ __launch_bounds__(KNT) __attribute__((amdgpu_num_sgpr(80))) void k_ti
         keep0 = live[0] ? (node[0] | (root[0] << 16)) : KEEP_NONE;
         keep1 = live[1] ? (node[1] | (root[1] << 16)) : KEEP_NONE;
     };
-    tabled = nruns <= (uint32_t)(NPL * KNT);
     if (tabled) {
 #pragma unroll
         for (int k = 0; k < NPL / 2; k++)
             if ((uint32_t)(k * 2 * KNT) < nruns) flatten2((uint32_t)(k * 2 * KNT), keep[2 * k], keep[2 * k + 1]);
-    } else
-        for (uint32_t j0 = 0; j0 < nruns; j0 += 2 * KNT) { uint32_t k0, k1; flatten2(j0, k0, k1); }
+    } else if (tid < 2 * 64) { // one lane per pair word, as in P4
+        const uint32_t O = ck_origin32(tx0 + 32 * wd, w);
+        const int mi = ((2 * p) * NWD + wd) * 2 + c;
+        const uint32_t Mt = mk[mi] & O, Mb = mk[mi + 2 * NWD] & O, S2 = s2w[(p * NWD + wd) * 2 + c];
+        const uint32_t base = (uint32_t)((2 * p) * TW + 32 * wd);
+        for (uint32_t St = S2; St; St &= St - 1u) {
+            const int s = __builtin_ctz(St);
+            const uint32_t span = ck_span32(S2, s);
+            const uint32_t node = pair_entry(Mt, base, s);
+            uint32_t root = node;
+            for (;;) { __asm__ volatile("" ::: "memory"); const uint32_t n0 = parent[root]; if (n0 & CK_ROOT) break; root = n0; }
+            if (root != node) parent[node] = (uint16_t)root;
+            atomicAdd(&parent32[root >> 1], ((uint32_t)__popc(Mt & span) + (uint32_t)__popc(Mb & span)) << ((root & 1u) * 16u));
+        }
+    }
     if (tid >= 3 * 64 && (tx0 == 0 || tx0 + TW >= w)) { // the non-origin columns' pixels: one pixel each
         int r, xl; uint32_t ec;
         if (edge_pixel(mk, tid & 63, tx0, ty0, w, h, r, xl, ec)) {
@@ -794,7 +809,7 @@ __global__ __launch_bounds__(KNT) __attribute__((amdgpu_num_sgpr(80))) void k_ti
             }
 #pragma unroll
             for (int r = 0; r < 2; r++) {
-                if (gy + r >= h) continue;
+                if (gy + r >= h || stop_after == 98) continue; // (98: diagnostics, everything but the label stores)
                 uint32_t *dst = labels + fbase + (size_t)(gy + r) * w + gx;
                 if (packed_rows) {
                     // (the empty asm keeps the compiler from merging this store with the per-pixel ones of the other branch: merged, it
@@ -1377,7 +1392,7 @@ __global__ __launch_bounds__(NT) void k_decimate(const uint8_t *__restrict__ src
 int ck_launch_threshold_segment(ck_handle *h, const uint8_t *frames, int stride, size_t frame_pitch, int n, bool precomputed) {
     const int tiles = h->tiles_x * h->tiles_y;
     static const int stop_after = getenv("CK_TILE_STOP_AFTER") ? atoi(getenv("CK_TILE_STOP_AFTER")) : 99;
-    static const int sweeps = getenv("CK_TILE_SWEEPS") ? atoi(getenv("CK_TILE_SWEEPS")) : 1;
+    static const int sweeps = getenv("CK_TILE_SWEEPS") ? atoi(getenv("CK_TILE_SWEEPS")) : 0; // (pointer-jumping sweeps before the pooled unions: 0, 1 and 2 time the same since the nodes are pair components)
     // frames dealt to XCDs (a frame's tiles share one L2): worth it once there are frames for all eight (CK_TILE_XCD=0/1 forces it)
     static const int xcd_env = getenv("CK_TILE_XCD") ? atoi(getenv("CK_TILE_XCD")) : -1;
     const int xcd_map = xcd_env >= 0 ? xcd_env : (n >= 16 ? 1 : 0);
@@ -1390,7 +1405,7 @@ int ck_launch_threshold_segment(ck_handle *h, const uint8_t *frames, int stride,
         hipLaunchKernelGGL(k_tile<false>, dim3(grid), dim3(KNT), 0, h->stream, frames, frame_pitch, stride, h->qw, h->qh,
                            h->tiles_x, h->tiles_y, n, xcd_map, h->cfg.min_white_black_diff, h->cfg.min_component_px, h->d_thresh, h->d_labels,
                            h->d_broots, h->d_tile_count, h->d_ring, h->ring_len, stop_after, sweeps);
-    if (stop_after == 99) { // (a k_tile cut short by the diagnostics knob leaves tile counts or ring entries unwritten: nothing for the merge to read)
+    if (stop_after >= 98) { // (a k_tile cut short by the diagnostics knob leaves tile counts or ring entries unwritten: nothing for the merge to read)
         static const int fm_stop = getenv("CK_FMERGE_STOP_AFTER") ? atoi(getenv("CK_FMERGE_STOP_AFTER")) : 99;
         const char *cap_env = getenv("CK_FMERGE_CAP"); // tests force the global-memory path with a small value (read per call)
         // roots the LDS path of one workgroup holds (dense binary noise has about 90 per tile).  A frame whose roots fit is joined by ONE
