@@ -118,6 +118,9 @@ extern "C" int ck_create(const ck_config_t *cfg, ck_handle_t **out) {
     CK_TRY(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
     CK_TRY(hipEventCreateWithFlags(&h->ev_fit_fork, hipEventDisableTiming));
     for (auto &st : h->fit_stream) CK_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    CK_TRY(hipStreamCreateWithFlags(&h->seg_stream, hipStreamNonBlocking));
+    for (auto &e : h->ev_seg) CK_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    CK_TRY(hipEventCreateWithFlags(&h->ev_seg_join, hipEventDisableTiming));
     for (auto &e : h->ev_fit_join) CK_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     CK_TRY(ck_malloc_dev(&h->d_frames, h->frame_pitch * nb));
     if (cfg->quad_decimate > 1) CK_TRY(ck_malloc_dev(&h->d_qframes, (size_t)round_up(qw, 16) * qh * nb));
@@ -142,6 +145,7 @@ extern "C" void ck_destroy(ck_handle_t *h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->stream2) (void)hipStreamSynchronize(h->stream2);
     for (auto &st : h->fit_stream) if (st) (void)hipStreamSynchronize(st);
+    if (h->seg_stream) (void)hipStreamSynchronize(h->seg_stream);
     ck_stage_free(h);
     (void)ck_free_dev(h->d_frames); (void)ck_free_dev(h->d_qframes); (void)ck_free_dev(h->d_thresh); (void)ck_free_dev(h->d_labels);
     (void)ck_free_dev(h->d_groot); (void)ck_free_dev(h->d_gsize); (void)ck_free_dev(h->d_gscratch); (void)ck_free_dev(h->d_broots); (void)ck_free_dev(h->d_tile_count); (void)ck_free_dev(h->d_ring);
@@ -150,6 +154,9 @@ extern "C" void ck_destroy(ck_handle_t *h) {
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     if (h->ev_fit_fork) (void)hipEventDestroy(h->ev_fit_fork);
     for (auto &e : h->ev_fit_join) if (e) (void)hipEventDestroy(e);
+    for (auto &e : h->ev_seg) if (e) (void)hipEventDestroy(e);
+    if (h->ev_seg_join) (void)hipEventDestroy(h->ev_seg_join);
+    if (h->seg_stream) (void)hipStreamDestroy(h->seg_stream);
     for (auto &st : h->fit_stream) if (st) (void)hipStreamDestroy(st);
     if (h->stream2) (void)hipStreamDestroy(h->stream2);
     if (h->stream) (void)hipStreamDestroy(h->stream);

@@ -47,6 +47,7 @@ struct ck_dev_family {
 constexpr int CK_FIT_CLASSES = 8;
 constexpr int CK_HUGE_CAP = 65536, CK_HUGE_WGS = 256; // largest class: points per cluster (3 * 4 * 4095 < 65536), workgroups in its grid
 constexpr int CK_FIT_PARALLEL_MAX_FRAMES = 16; // calls with at most this many frames (twice as many at quad_decimate >= 2) run the classes side by side
+constexpr int CK_SEG_CHUNKS_MAX = 8;           // pieces a batch's threshold + segmentation is cut into at most
 constexpr int CK_FIT_SIDE_STREAMS = 2;         // ... on the handle's stream and this many more (a process has few hardware queues)
 constexpr int CK_LSCRATCH_PER_WG = 16384, CK_LSCRATCH_WGS = 1024; // large class: points per cluster, workgroups in its grid (at most)
 
@@ -122,6 +123,10 @@ struct ck_handle {
     // a call with a few frames runs the size classes of the quad fit side by side (k_quads.hip): each class is then a handful of
     // workgroups whose time is one cluster's dependency chain, and five chains in a row were a quarter of a one-frame call
     hipStream_t fit_stream[CK_FIT_SIDE_STREAMS];
+    // threshold + segmentation of a large batch runs in chunks of frames: k_fmerge of chunk i (one workgroup per frame, bound by
+    // chains of dependent steps) on seg_stream beside k_tile of chunk i + 1 on the handle's stream (k_ccl.hip)
+    hipStream_t seg_stream;
+    hipEvent_t ev_seg[CK_SEG_CHUNKS_MAX], ev_seg_join;
     hipEvent_t ev_fit_fork, ev_fit_join[CK_FIT_SIDE_STREAMS];
     int w, h;            // full-resolution frame
     int qw, qh;          // geometry of the image the quad stages run on (w/decimate)

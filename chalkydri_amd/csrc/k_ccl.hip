@@ -252,7 +252,7 @@ __device__ unsigned long long g_tile_prof[16];
 //              segmentation runs (the map is copied through to `thresh` for the merge kernel).
 template <bool PRE>
 __global__ __launch_bounds__(KNT) __attribute__((amdgpu_num_sgpr(80))) void k_tile(const uint8_t *__restrict__ frames, size_t frame_pitch, int stride,
-                                             int w, int h, int tiles_x, int tiles_y, int n_frames, int xcd_map, int min_diff, int min_comp,
+                                             int w, int h, int tiles_x, int tiles_y, int frame0, int n_frames, int xcd_map, int min_diff, int min_comp,
                                              uint8_t *__restrict__ thresh, uint32_t *__restrict__ labels,
                                              ck_border_root *__restrict__ broots, uint32_t *__restrict__ tile_count,
                                              uint16_t *__restrict__ ring, size_t ring_len, int stop_after, int sweeps) {
@@ -263,9 +263,9 @@ __global__ __launch_bounds__(KNT) __attribute__((amdgpu_num_sgpr(80))) void k_ti
     if (xcd_map) { // workgroups b and b + 8 share an XCD (their L2): deal whole frames to XCDs, so that the halo rows a tile shares
                    // with its neighbours are read from HBM once
         const int x = blockIdx.x & 7, j = blockIdx.x >> 3;
-        frame = (j / tiles) * 8 + x; tile = j % tiles;
+        frame = frame0 + (j / tiles) * 8 + x; tile = j % tiles;
         if (frame >= n_frames) return;
-    } else { frame = blockIdx.x / tiles; tile = blockIdx.x - frame * tiles; }
+    } else { frame = blockIdx.x / tiles; tile = blockIdx.x - frame * tiles; frame += frame0; } // (frames [frame0, n_frames) of the batch)
     const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
     const int tx0 = tx * TW, ty0 = ty * TH;
     const uint8_t *img = frames + (size_t)frame * frame_pitch;
@@ -1195,7 +1195,7 @@ __device__ __forceinline__ void fm_global_path(const FmFrame &f, const ck_border
 __global__ __launch_bounds__(FM_NT, 8) __attribute__((amdgpu_num_sgpr(80))) void k_fmerge(ck_border_root *__restrict__ broots, const uint32_t *__restrict__ tile_count,
                                                   const uint16_t *__restrict__ ring, size_t ring_len, uint32_t *__restrict__ groot_all,
                                                   uint32_t *__restrict__ gsize_all, uint32_t *__restrict__ gscratch, size_t npix, int w, int h,
-                                                  int tiles_x, int tiles_y, int n_frames, int min_comp, int lds_cap, int stop_after) {
+                                                  int tiles_x, int tiles_y, int frame0, int n_frames, int min_comp, int lds_cap, int stop_after) {
     extern __shared__ __attribute__((aligned(16))) uint8_t fm_lds[];
     __shared__ uint32_t wsum[2 * (FM_NT / 64)];
     __shared__ uint32_t segn[2];
@@ -1205,7 +1205,7 @@ __global__ __launch_bounds__(FM_NT, 8) __attribute__((amdgpu_num_sgpr(80))) void
     // dealt to XCDs).
     const int half = (int)(gridDim.x >> 1); // a multiple of 8
     const uint32_t col = (int)blockIdx.x < half ? 1u : 0u; // 1 = white
-    const int frame = (int)blockIdx.x - (col ? 0 : half), tid = threadIdx.x;
+    const int frame = frame0 + (int)blockIdx.x - (col ? 0 : half), tid = threadIdx.x; // (frames [frame0, n_frames) of the batch)
     if (frame >= n_frames) return;
     const int tiles = tiles_x * tiles_y;
     uint16_t *parent = reinterpret_cast<uint16_t *>(fm_lds);
@@ -1395,38 +1395,60 @@ int ck_launch_threshold_segment(ck_handle *h, const uint8_t *frames, int stride,
     static const int sweeps = getenv("CK_TILE_SWEEPS") ? atoi(getenv("CK_TILE_SWEEPS")) : 0; // (pointer-jumping sweeps before the pooled unions: 0, 1 and 2 time the same since the nodes are pair components)
     // frames dealt to XCDs (a frame's tiles share one L2): worth it once there are frames for all eight (CK_TILE_XCD=0/1 forces it)
     static const int xcd_env = getenv("CK_TILE_XCD") ? atoi(getenv("CK_TILE_XCD")) : -1;
-    const int xcd_map = xcd_env >= 0 ? xcd_env : (n >= 16 ? 1 : 0);
-    const unsigned grid = xcd_map ? (unsigned)(((n + 7) / 8) * 8 * tiles) : (unsigned)(tiles * n);
-    if (precomputed)
-        hipLaunchKernelGGL(k_tile<true>, dim3(grid), dim3(KNT), 0, h->stream, frames, frame_pitch, stride, h->qw, h->qh,
-                           h->tiles_x, h->tiles_y, n, xcd_map, h->cfg.min_white_black_diff, h->cfg.min_component_px, h->d_thresh, h->d_labels,
-                           h->d_broots, h->d_tile_count, h->d_ring, h->ring_len, stop_after, sweeps);
-    else
-        hipLaunchKernelGGL(k_tile<false>, dim3(grid), dim3(KNT), 0, h->stream, frames, frame_pitch, stride, h->qw, h->qh,
-                           h->tiles_x, h->tiles_y, n, xcd_map, h->cfg.min_white_black_diff, h->cfg.min_component_px, h->d_thresh, h->d_labels,
-                           h->d_broots, h->d_tile_count, h->d_ring, h->ring_len, stop_after, sweeps);
-    if (stop_after >= 98) { // (a k_tile cut short by the diagnostics knob leaves tile counts or ring entries unwritten: nothing for the merge to read)
-        static const int fm_stop = getenv("CK_FMERGE_STOP_AFTER") ? atoi(getenv("CK_FMERGE_STOP_AFTER")) : 99;
-        const char *cap_env = getenv("CK_FMERGE_CAP"); // tests force the global-memory path with a small value (read per call)
-        // roots the LDS path of one workgroup holds (dense binary noise has about 90 per tile).  A frame whose roots fit is joined by ONE
-        // workgroup, both colours in one sweep; a larger one by two, one per colour (1920 x 1080 of dense noise: 23 000 each); a
-        // workgroup with more takes the global-memory path.
-        int cap = tiles * 120;
-        cap = cap < 4096 ? 4096 : (cap > FM_CAP ? FM_CAP : cap);
-        if (cap_env && atoi(cap_env) < cap) cap = atoi(cap_env);
-        // (the per-tile arrays and the join queues come first: very large frames leave less room for roots)
-        const size_t fixed = (size_t)((tiles + 1 + 3) & ~3) * 4 + (size_t)(FM_NT / 64) * FM_WQ * 4 + (size_t)((tiles + 7) & ~7) * 2 * 3 + (size_t)tiles * 8;
-        const size_t lds_max = 160 * 1024 - 512;
-        if ((size_t)cap * 4 + fixed > lds_max) cap = (int)((lds_max - fixed) / 4);
-        cap &= ~1;
-        const size_t lds = (size_t)cap * 4 + fixed;
-        if (!h->fmerge_lds_allowed) { // per handle, i.e. per device: a process may hold handles on several GPUs
-            CK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_fmerge), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512));
-            h->fmerge_lds_allowed = true;
+    static const int fm_stop = getenv("CK_FMERGE_STOP_AFTER") ? atoi(getenv("CK_FMERGE_STOP_AFTER")) : 99;
+    // CK_SEG_CHUNKS=k cuts the batch into k chunks of frames (multiples of 8: the XCD dealing) and runs chunk i's k_fmerge — one
+    // workgroup per frame, bound by chains of dependent steps — on a side stream beside chunk i + 1's k_tile.  Measured on the
+    // bench batch (1280 x 800 x 256, same box): 1.07 ms whole, 1.10 in two chunks, 1.22 in four, 1.77 in eight: the merge's
+    // workgroups (16 waves and most of a CU's LDS each) displace more of k_tile than their waiting hides.  So the default is one chunk.
+    static const int chunks_env = getenv("CK_SEG_CHUNKS") ? atoi(getenv("CK_SEG_CHUNKS")) : 0;
+    int chunks = chunks_env > 0 ? chunks_env : 1;
+    if (chunks > CK_SEG_CHUNKS_MAX) chunks = CK_SEG_CHUNKS_MAX;
+    const int per = ((n + chunks - 1) / chunks + 7) & ~7;
+    const char *cap_env = getenv("CK_FMERGE_CAP"); // tests force the global-memory path with a small value (read per call)
+    // roots the LDS path of one workgroup holds (dense binary noise has about 90 per tile).  A frame whose roots fit is joined by ONE
+    // workgroup, both colours in one sweep; a larger one by two, one per colour (1920 x 1080 of dense noise: 23 000 each); a
+    // workgroup with more takes the global-memory path.
+    int cap = tiles * 120;
+    cap = cap < 4096 ? 4096 : (cap > FM_CAP ? FM_CAP : cap);
+    if (cap_env && atoi(cap_env) < cap) cap = atoi(cap_env);
+    // (the per-tile arrays and the join queues come first: very large frames leave less room for roots)
+    const size_t fixed = (size_t)((tiles + 1 + 3) & ~3) * 4 + (size_t)(FM_NT / 64) * FM_WQ * 4 + (size_t)((tiles + 7) & ~7) * 2 * 3 + (size_t)tiles * 8;
+    const size_t lds_max = 160 * 1024 - 512;
+    if ((size_t)cap * 4 + fixed > lds_max) cap = (int)((lds_max - fixed) / 4);
+    cap &= ~1;
+    const size_t lds = (size_t)cap * 4 + fixed;
+    if (!h->fmerge_lds_allowed) { // per handle, i.e. per device: a process may hold handles on several GPUs
+        CK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_fmerge), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512));
+        h->fmerge_lds_allowed = true;
+    }
+    bool forked = false;
+    for (int f0 = 0, ci = 0; f0 < n; f0 += per, ci++) {
+        const int f1 = f0 + per < n ? f0 + per : n, cn = f1 - f0;
+        const int xcd_map = xcd_env >= 0 ? xcd_env : (cn >= 16 ? 1 : 0);
+        const unsigned grid = xcd_map ? (unsigned)(((cn + 7) / 8) * 8 * tiles) : (unsigned)(tiles * cn);
+        if (precomputed)
+            hipLaunchKernelGGL(k_tile<true>, dim3(grid), dim3(KNT), 0, h->stream, frames, frame_pitch, stride, h->qw, h->qh,
+                               h->tiles_x, h->tiles_y, f0, f1, xcd_map, h->cfg.min_white_black_diff, h->cfg.min_component_px, h->d_thresh, h->d_labels,
+                               h->d_broots, h->d_tile_count, h->d_ring, h->ring_len, stop_after, sweeps);
+        else
+            hipLaunchKernelGGL(k_tile<false>, dim3(grid), dim3(KNT), 0, h->stream, frames, frame_pitch, stride, h->qw, h->qh,
+                               h->tiles_x, h->tiles_y, f0, f1, xcd_map, h->cfg.min_white_black_diff, h->cfg.min_component_px, h->d_thresh, h->d_labels,
+                               h->d_broots, h->d_tile_count, h->d_ring, h->ring_len, stop_after, sweeps);
+        if (stop_after < 98) continue; // (a k_tile cut short by the diagnostics knob leaves tile counts or ring entries unwritten: nothing for the merge to read)
+        hipStream_t ms = h->stream;
+        if (f1 < n) { // not the last chunk: its merge goes beside the next chunk's k_tile
+            CK_HIP(hipEventRecord(h->ev_seg[ci], h->stream));
+            CK_HIP(hipStreamWaitEvent(h->seg_stream, h->ev_seg[ci], 0));
+            ms = h->seg_stream;
+            forked = true;
         }
-        hipLaunchKernelGGL(k_fmerge, dim3((unsigned)(((n + 7) / 8) * 16)), dim3(FM_NT), lds, h->stream, h->d_broots, h->d_tile_count, h->d_ring, h->ring_len,
-                           h->d_groot, h->d_gsize, h->d_gscratch, h->npix, h->qw, h->qh, h->tiles_x, h->tiles_y, n, h->cfg.min_component_px, cap,
+        hipLaunchKernelGGL(k_fmerge, dim3((unsigned)(((cn + 7) / 8) * 16)), dim3(FM_NT), lds, ms, h->d_broots, h->d_tile_count, h->d_ring, h->ring_len,
+                           h->d_groot, h->d_gsize, h->d_gscratch, h->npix, h->qw, h->qh, h->tiles_x, h->tiles_y, f0, f1, h->cfg.min_component_px, cap,
                            fm_stop);
+    }
+    if (forked) {
+        CK_HIP(hipEventRecord(h->ev_seg_join, h->seg_stream));
+        CK_HIP(hipStreamWaitEvent(h->stream, h->ev_seg_join, 0));
     }
     CK_HIP(hipGetLastError());
     return CK_OK;
