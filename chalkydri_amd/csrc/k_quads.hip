@@ -1392,7 +1392,9 @@ int ck_launch_fit_quads(ck_handle *h, const uint8_t *qframes, int qstride, size_
         CK_HIP(hipEventRecord(h->ev_fit_fork, h->stream));
         for (int k = 0; k < CK_FIT_SIDE_STREAMS; k++) CK_HIP(hipStreamWaitEvent(h->fit_stream[k], h->ev_fit_fork, 0));
     }
+    static const int skip_mask = getenv("CK_FIT_SKIP") ? atoi(getenv("CK_FIT_SKIP")) : 0; // (diagnostics: bit c set = class c is not launched)
     auto launch = [&](int c) {
+        if ((skip_mask >> c) & 1) return;
         a.list = lists + (size_t)c * list_cap; a.list_count = list_counts + c; a.head = heads + c;
         switch (c) {
         case 0: { static const int s_wgs = getenv("CK_FIT_S_WGS") ? atoi(getenv("CK_FIT_S_WGS")) : 12; // (diagnostics: workgroups per CU of the small class)

@@ -188,6 +188,38 @@ def test_detect_matches_oracle_and_truth(oracle, w, h, n_tags, fams, bits, kw):
     det.close()
 
 
+def test_config5_full_size_batch_properties(oracle):
+    """BASELINE config 5 at full size: 2448x2048 x 256 frames, 20 tags of mixed families (a 60 GB handle, the per-colour split of
+    the merge kernel and the largest fit class at batch scale).  8 distinct frames in shuffled positions: every copy of a frame
+    gives the same detections (bytes) wherever it sits, no frame reports an overflow, and the 8 distinct results equal the oracle's."""
+    from chalkydri_amd.detector import AprilTagDetector
+    w, h, n, uniq, fams, bits = 2448, 2048, 256, 8, ("tag16h5", "tag36h11"), 1
+    frames8, truths = synth.render_batch(55, uniq, w, h, 20, fams, family_mode=1)
+    rng = np.random.default_rng(5)
+    which = rng.permutation(np.repeat(np.arange(uniq), n // uniq))
+    det = AprilTagDetector(w, h, max_batch=n, families=fams, bits_corrected=bits)
+    got, status = det.detect_batch(frames8[which], cap=64, return_status=True)
+    status = np.asarray(status, np.uint32)
+    assert not np.any(status & np.uint32(~A.CK_FRAME_UNVERIFIED_ID & 0xFFFFFFFF)), "a frame reported an overflow"
+    key = lambda ds: [(d.family(), d.id(), d.hamming(), np.float32(d.decision_margin()).tobytes(), d.corners().tobytes()) for d in ds]
+    first = {}
+    for i in range(n):
+        k = int(which[i])
+        if k in first:
+            assert key(got[i]) == key(got[first[k]]) and status[i] == status[first[k]], f"frame copy {i} of {k} differs"
+        else:
+            first[k] = i
+    cfg = default_config(w, h, families=fams, max_hamming=bits)
+    found = 0
+    for k in range(uniq):
+        want, st = oracle.detect(frames8[k], cfg)
+        assert status[first[k]] == st
+        _same_dets(got[first[k]], want)
+        found += len(want)
+    assert found >= 8 * 10   # most of the 20 rendered tags per frame decode
+    det.close()
+
+
 def test_detect_is_deterministic_and_batch_invariant(oracle):
     from chalkydri_amd.detector import AprilTagDetector
     w, h = 640, 480

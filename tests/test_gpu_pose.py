@@ -166,6 +166,50 @@ def test_dense_1080p_full_pipeline(oracle):
     task.detector.close()
 
 
+def test_config3_full_size_batch_properties(oracle):
+    """BASELINE config 3 at full size: 1920x1080 x 512 frames, 30 tags per frame, the whole pipeline incl. SQPnP (a 50 GB handle,
+    frame indices above 255 at 1080p, two merge workgroups per frame, every fit class at batch scale).  The oracle cannot run 512
+    such frames in seconds, so the batch is 8 distinct frames in shuffled positions: every copy of a frame gives the same record
+    wherever it sits, no frame reports an overflow, and the 8 distinct records equal the oracle's (and recover the rendered pose)."""
+    from chalkydri_amd.apriltags import AprilTags
+    w, h, f, n, uniq = 1920, 1080, 1000.0, 512, 8
+    layout = scenes.wall_layout(30, cols=10)
+    r2c = {"roll": 0.0, "pitch": 0.0, "yaw": 0.0, "x": 0.2, "y": 0.0, "z": 0.6}
+    calib = scenes.pinhole_calib(f, w / 2.0, h / 2.0)
+    rng = np.random.default_rng(33)
+    frames8, truths, gyro8 = [], [], []
+    for i in range(uniq):
+        pose = (rng.uniform(0.9, 1.3), rng.uniform(-0.2, 0.2), rng.uniform(-0.05, 0.05))
+        fr, tr = scenes.render_view(3300 + i, w, h, f, layout, pose, r2c, noise_amp=3)
+        frames8.append(fr); truths.append(tr); gyro8.append(pose[2] + rng.uniform(-0.02, 0.02))
+    frames8 = np.stack(frames8)
+    which = rng.permutation(np.repeat(np.arange(uniq), n // uniq))
+    task = AprilTags(w, h, layout, calib, r2c, cam_id=3, max_batch=n)
+    recs, valid = task.process_batch(frames8[which], [float(gyro8[k]) for k in which])
+    assert valid.all()
+    dets, status = task.detector.detect_batch(None, n=n, return_status=True)   # the frames are still staged: their status words
+    status = np.asarray(status, np.uint32)
+    assert not np.any(status & np.uint32(~A.CK_FRAME_UNVERIFIED_ID & 0xFFFFFFFF)), "a frame reported an overflow"
+    first = {}
+    for i in range(n):
+        k = int(which[i])
+        if k in first:
+            assert bytes(recs[i]) == first[k], f"frame copy {i} of {k} differs"
+        else:
+            first[k] = bytes(recs[i])
+    cfg = default_config(w, h)
+    for k in range(uniq):
+        out = A.VisionMeasurement()
+        v = C.c_int(0)
+        oracle.lib().ora_process_frame(C.c_void_p(frames8[k].ctypes.data), w, h, w, C.byref(cfg), C.byref(task._pp),
+                                       C.c_double(float(gyro8[k])), 1, C.byref(out), C.byref(v))
+        r = A.VisionMeasurement.from_buffer_copy(first[k])
+        assert v.value == 1 and r.tag_count == out.tag_count and 30 <= r.tag_count <= 31   # (the noise may decode to one more field tag: both sides then count it)
+        assert abs(r.pose_x - out.pose_x) < 1e-6 and abs(r.pose_y - out.pose_y) < 1e-6 and abs(r.pose_rot - out.pose_rot) < 1e-7
+        assert abs(r.pose_x - truths[k]["twr"][0]) < 0.03 and abs(r.pose_y - truths[k]["twr"][1]) < 0.03
+    task.detector.close()
+
+
 def test_sqpnp_golden_vectors(built):
     """The HIP solver against the committed vectors directly (no oracle in the loop), tolerance 1e-9."""
     import golden_util as G
