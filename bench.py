@@ -26,29 +26,68 @@ HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md)
 ALG_BYTES_PER_PX = 7.0  # threshold 1R+1W, segment 1R+4W
 
 
-def cpu_baseline(frames, gyro, task, cfg, seconds_hint=1.5):
-    """Oracle (oracle/libck_oracle.so, kind 'port') on the host cores, on a bounded sample of the same frames."""
-    from concurrent.futures import ThreadPoolExecutor
+def physical_cores():
+    """Distinct (package, core) pairs of /proc/cpuinfo (hardware threads / SMT siblings counted once); 0 when unknown."""
+    seen, phys, core = set(), None, None
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("physical id"):
+                phys = line.split(":", 1)[1].strip()
+            elif line.startswith("core id"):
+                core = line.split(":", 1)[1].strip()
+            elif not line.strip():
+                if phys is not None and core is not None:
+                    seen.add((phys, core))
+                phys = core = None
+    except OSError:
+        return 0
+    return len(seen)
+
+
+def cpu_share():
+    """CPUs this process may use at once: the affinity mask, cut down by the cgroup's CPU quota (v2 cpu.max, v1 cfs_quota_us)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(p) + 0.5)))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, int(q / p + 0.5)))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
+def cpu_baseline(frames, gyro, task, cfg, budget_s=10.0):
+    """Oracle (oracle/libck_oracle.so, kind 'port') on the host cores, on a bounded sample of the same frames: the C driver
+    oracle/bench_threads.c runs ora_process_frame on T POSIX threads (frames handed out by an atomic counter, the threads' malloc
+    arenas reused from frame to frame) for T in {1, 16, physical cores, nproc}, each capped at the CPUs the box grants this process; `value` is the best of them, `cores` its T."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import pyoracle
-    from chalkydri_amd import _abi as A
     L = pyoracle.lib()
-    h, w = frames.shape[1:]
-    cores = max(1, os.cpu_count() or 1)      # T = hardware concurrency (SURVEY.md §8d); 16 threads reported beside it
+    L.ora_bench_process.restype = C.c_double
+    L.ora_bench_process.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                    C.c_int, C.POINTER(C.c_int)]
+    nf = min(len(frames), 64)
+    fr = np.ascontiguousarray(frames[:nf])
+    gy = np.ascontiguousarray(np.asarray(gyro[:nf], np.float64))
+    h, w = fr.shape[1:]
 
-    def one(i):
-        out = A.VisionMeasurement()
-        v = C.c_int(0)
-        f = np.ascontiguousarray(frames[i])
-        L.ora_process_frame(C.c_void_p(f.ctypes.data), w, h, w, C.byref(cfg), C.byref(task._pp), C.c_double(float(gyro[i])), 1,
-                            C.byref(out), C.byref(v))
-        return v.value
+    def run(threads, n_work):
+        nv = C.c_int(0)
+        dt = L.ora_bench_process(fr.ctypes.data, w, h, w, w * h, nf, n_work, C.addressof(cfg), C.addressof(task._pp), gy.ctypes.data, threads,
+                                 C.byref(nv))
+        if dt <= 0:
+            raise RuntimeError("ora_bench_process failed")
+        return dt, nv.value
 
-    t0 = time.perf_counter()
-    ns = min(4, len(frames))
-    for i in range(ns):                       # single-thread rate on a few frames (BASELINE.md §4 (a))
-        one(i)
-    per = (time.perf_counter() - t0) / ns
+    nproc = max(1, os.cpu_count() or 1)
+    phys = physical_cores() or nproc
+    share = cpu_share() or nproc                # CPUs this process may actually use (affinity mask, cgroup quota)
     model = "unknown"
     try:
         for line in open("/proc/cpuinfo"):
@@ -57,36 +96,60 @@ def cpu_baseline(frames, gyro, task, cfg, seconds_hint=1.5):
                 break
     except OSError:
         pass
-    def timed(threads):
-        n = int(max(threads, seconds_hint * threads / max(per, 1e-3)))  # ~seconds_hint of wall time = threads * seconds_hint of CPU work
-        n = max(threads, (n // threads) * threads)
-        idx = [i % len(frames) for i in range(n)]
-        t0 = time.perf_counter()
-        with ThreadPoolExecutor(threads) as ex:
-            valid = list(ex.map(one, idx))
-        return n, time.perf_counter() - t0, sum(valid)
+    run(1, 1)                                  # (first touch of the allocator arenas and of the frames)
+    dt1, _ = run(1, 4)
+    per = dt1 / 4                              # CPU seconds per frame, one thread
+    # T = 1, 16, the physical cores and the hardware threads — as far as the box lets this process have them: beyond its CPU
+    # share (a one-GPU box of the pool grants 16 of the host's 256 hardware threads) more threads only take turns on the same
+    # CPUs (round 2's 256-thread figure BELOW its 16-thread one was that, not the allocator)
+    counts = sorted({1, min(16, share), min(phys, share), min(nproc, share)})
+    each = budget_s / len(counts)              # wall seconds each thread count may take
+    rates, sample = {}, []
+    for t in counts:
+        n_work = max(t, min(4096, int(each * t / max(per, 1e-4)) // t * t))   # a whole number of frames per thread
+        dt, nvalid = run(t, n_work)
+        rates[t] = n_work / dt
+        sample.append(f"T={t}: {n_work} frames in {dt:.2f} s")
+    best = max(rates, key=rates.get)
+    return {"value": round(rates[best], 2), "unit": "frames/s", "cores": best, "kind": "port",
+            "by_threads": {str(t): round(r, 2) for t, r in rates.items()}, "single_thread_value": round(rates[1], 2),
+            "physical_cores": phys, "nproc": nproc, "cpu_share": share, "cpu_model": model,
+            "sample": f"the same {w}x{h} workload ({nf} distinct frames, cycled) through oracle/ (C restatement of the path; the reference's "
+                      f"Rust path cannot be built here), detect+pose, POSIX threads over frames (oracle/bench_threads.c); " + "; ".join(sample)}
 
-    n, dt, nvalid = timed(cores)
-    out = {"value": round(n / dt, 2), "unit": "frames/s", "cores": cores, "kind": "port",
-           "single_thread_value": round(1.0 / per, 2), "nproc": os.cpu_count(), "cpu_model": model,
-           "sample": f"{n} frames of the same {w}x{h} workload through oracle/ (C restatement of the path; the reference's Rust path "
-                     f"cannot be built here), detect+pose, {cores} threads, {nvalid} valid poses, {dt:.1f} s"}
-    if cores > 16:
-        n16, dt16, _ = timed(16)
-        out["value_16_threads"] = round(n16 / dt16, 2)
-    return out
+
+def visible_gpus():
+    """GPUs of this host counted WITHOUT touching HIP (the parent of the ranks must not initialise the GPU before it starts
+    them): KFD topology nodes that have SIMDs (CPU nodes have simd_count 0), narrowed by ROCR/HIP_VISIBLE_DEVICES when set;
+    falls back to the DRM render nodes."""
+    import glob
+    n = 0
+    for path in glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties"):
+        try:
+            for line in open(path):
+                k, _, v = line.partition(" ")
+                if k == "simd_count" and int(v) > 0:
+                    n += 1
+        except (OSError, ValueError):
+            pass
+    if n == 0:
+        n = len(glob.glob("/dev/dri/renderD*"))
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+    return n
 
 
 def self_launch(n_gpus):
     """`python bench.py --gpus N` without a launcher: start the N ranks as a CHILD torch.distributed.run (one process per GPU,
-    RCCL over xGMI) before this process touches the GPU, and hand back its exit code.  Never an exec: a process that has
-    initialised the GPU must not be replaced (and this one has not initialised it: device_count() does not)."""
+    RCCL over xGMI) and hand back its exit code.  The parent never touches HIP (devices are counted from sysfs) and never
+    execs: the ranks are spawned."""
     import socket
     import subprocess
-    import torch
-    have = torch.cuda.device_count()
+    have = visible_gpus()
     if have < n_gpus:
-        print(f"bench.py: --gpus {n_gpus} but only {have} HIP device(s) are visible", file=sys.stderr)
+        print(f"bench.py: --gpus {n_gpus} but only {have} GPU(s) are visible", file=sys.stderr)
         return 2
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
@@ -148,13 +211,15 @@ def main():
     # its communicator cannot be made on some rank, EVERY rank uses the Python mirror's torch.distributed all_gather instead
     # (same bytes, same layout) and the JSON line says which one ran.
     comm, gather_kind = None, "none (1 GPU)"
-    if world > 1:
+    force_comm = os.environ.get("CK_BENCH_FORCE_COMM") == "1"   # (tests: the C ABI's collective inside this loop on ONE rank)
+    if world > 1 or force_comm:
         try:
             comm = dist.PoseComm(task.detector, rank, world, dev)
         except Exception as e:  # noqa: BLE001
             print(f"[rank {rank}] ck_comm_create failed ({e}); falling back to torch.distributed", file=sys.stderr)
         ok = torch.tensor([1 if comm is not None else 0], dtype=torch.int32, device=dev)
-        tdist.all_reduce(ok, op=tdist.ReduceOp.MIN)
+        if world > 1:
+            tdist.all_reduce(ok, op=tdist.ReduceOp.MIN)
         if not int(ok.item()):
             if comm is not None:
                 comm.close()
@@ -193,6 +258,18 @@ def main():
         tdist.all_reduce(tmax, op=tdist.ReduceOp.MAX)
     dt = float(tmax.item())
 
+    # the collective alone, after the timed region: enqueue + completion of one gather of this batch's records, wall clock
+    gather_us = None
+    if comm is not None:
+        comm.sync()
+        ts = []
+        for _ in range(20):
+            t1 = time.perf_counter()
+            comm.gather(n, out_ptr=d_all.data_ptr(), sync=False)
+            comm.sync()
+            ts.append((time.perf_counter() - t1) * 1e6)
+        gather_us = {"median": round(float(np.median(ts)), 1), "min": round(float(np.min(ts)), 1), "bytes_per_rank": n * 64,
+                     "what": "ck_gather_poses(sync=0) + ck_comm_sync, host wall clock, 20 repeats after the timed region"}
     if rank == 0:
         stage = task.detector.stage_ms()
         recs = dist.records_to_numpy(gathered)
@@ -220,6 +297,13 @@ def main():
                 tj = json.load(open(tpath))
                 traffic = tj.get("hbm_bytes_per_launch")
                 traffic_src = {k: tj.get(k) for k in ("round", "commit", "note") if tj.get(k) is not None}
+                # the figure belongs to the kernels it was measured on: the file carries the hash of their source
+                import hashlib
+                now = hashlib.sha256(open(os.path.join(ROOT, "chalkydri_amd", "csrc", "k_ccl.hip"), "rb").read()).hexdigest()[:16]
+                if tj.get("k_ccl_sha16") != now:
+                    traffic_src["stale"] = True
+                    print(f"bench.py: profiles/traffic_latest.json was measured on another k_ccl.hip ({tj.get('k_ccl_sha16')} != {now}): "
+                          "re-run tools/collect_profiles.sh", file=sys.stderr)
             except Exception:
                 traffic = None
         out = {
@@ -229,7 +313,7 @@ def main():
             "dtype": "u8 (threshold/segment/clusters: integer; quad fit/decode/SQPnP: f64)", "data": "synthetic",
             "config": {"workload": f"{w}x{h} mono8 batch={n}/GPU, tag36h11, {args.tags} field tags/frame (3-D scenes), background ramp+-24 "
                                    f"noise+-{args.noise}, quad_decimate={args.decimate}, detect+pose, one stream per GPU",
-                       "frames_with_pose": round(valid_frac, 4), "post_segment_streams": int(os.environ.get("CK_STREAMS", "1")), "gather": gather_kind},
+                       "frames_with_pose": round(valid_frac, 4), "post_segment_streams": int(os.environ.get("CK_STREAMS", "1")), "gather": gather_kind, "gather_us": gather_us},
             "roofline": {"bound": "hbm", "kernel": "threshold+segment (k_tile + k_fmerge)", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_src, "measured_copy_GBps": round(copy_gbps, 1),
                          "algorithmic_bytes_per_launch": ALG_BYTES_PER_PX * w * h * n, "avg_launch_ms": round(ms_thr, 4),

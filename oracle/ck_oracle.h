@@ -68,6 +68,11 @@ int ora_process_frame(const uint8_t *img, int w, int h, int stride, const ck_con
                       const ck_process_params_t *pp, double gyro, int has_gyro, ck_vision_measurement_t *out,
                       int *valid);
 
+/* bench_threads.c: n_work frames (cycling through n_frames) through ora_process_frame on `threads` POSIX threads; returns the
+ * wall seconds of the threaded region (negative on failure), *n_valid = frames that produced a pose.  bench.py's cpu_baseline leg. */
+double ora_bench_process(const uint8_t *frames, int w, int h, int stride, size_t frame_pitch, int n_frames, int n_work,
+                         const ck_config_t *cfg, const ck_process_params_t *pp, const double *gyro, int threads, int *n_valid);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,6 +1,9 @@
 """GPU parity for SQPnP and the AprilTags::process glue: HIP vs oracle within the stated float tolerance
 (|dR|,|dt| <= 1e-9 for the solver; end-to-end pose: position 1e-6 m, yaw 1e-7 rad) and vs synthetic ground truth."""
 import ctypes as C
+import os
+import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -291,6 +294,23 @@ print("GATHER OK")
 """
     r = subprocess.run([sys.executable, "-c", script % (root, os.path.join(root, "tests"))], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "GATHER OK" in r.stdout, r.stdout[-1000:] + r.stderr[-3000:]
+
+
+def test_bench_loop_runs_the_c_abi_gather_on_one_rank(built):
+    """bench.py under torch.distributed.run with ONE rank and CK_BENCH_FORCE_COMM=1: ck_comm_create, a ck_gather_poses(sync=0) per
+    step and ck_comm_sync execute inside bench's own timed loop (the multi-GPU path of the round-end scaling run, on the one GPU
+    a test box has), and the JSON line says so."""
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, CK_BENCH_FORCE_COMM="1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1", "--master-port", "29561",
+           os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--batch", "16", "--no-cpu-baseline", "--no-extras"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-3000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["config"]["gather"].startswith("ck_gather_poses") and out["config"]["gather_us"]["bytes_per_rank"] == 16 * 64
+    assert out["config"]["frames_with_pose"] == 1.0 and out["n_gpus"] == 1
 
 
 def test_full_size_batch_properties(oracle):

@@ -5,7 +5,7 @@ definition on this image: TCC_EA0_RDREQ*64/1024); FETCH_SIZE is doubled (gfx950 
 Bytes are summed over the threshold+segment kernels and divided by the number of batch launches (= k_tile dispatches).
 
 usage: traffic_from_pmc.py <fetch_dir> <write_dir> [out.json]"""
-import csv, glob, json, os, re, sys
+import csv, glob, hashlib, json, os, re, sys
 
 KERNELS = ("k_tile", "k_fmerge")
 
@@ -44,7 +44,9 @@ def main():
            "note": "FETCH_SIZE is doubled for BOTH kernels (MI355X_MICROARCH.md: gfx950 tallies 128-byte requests at 64 bytes). That rule is "
                    "calibrated for k_tile's reads (16 bytes per lane, streaming); k_fmerge reads 2-byte ring entries and 8-byte list entries, "
                    "for which the counter is uncalibrated, so its share (a few per cent of the total) may be over-counted by up to 2x.",
-           "round": int(sys.argv[4]) if len(sys.argv) > 4 else 2, "commit": commit}
+           "round": int(sys.argv[4]) if len(sys.argv) > 4 else 3, "commit": commit,
+           # bench.py compares this with the k_ccl.hip it runs on and flags the figure as stale when the kernels have changed since
+           "k_ccl_sha16": hashlib.sha256(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "chalkydri_amd", "csrc", "k_ccl.hip"), "rb").read()).hexdigest()[:16]}
     json.dump(rec, open(out, "w"), indent=1)
     print(json.dumps(rec))
 
