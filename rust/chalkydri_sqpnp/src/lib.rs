@@ -5,8 +5,8 @@
 //! The reference's types are nalgebra's (`Isometry3<f64>`, `Rotation3<f64>`, `SVector<f64, 3>`; lib.rs:15-26).  nalgebra is not
 //! available offline, so the core API takes the same data as arrays: an isometry is a translation `[f64; 3]` plus a unit
 //! quaternion `[f64; 4]` in (w, x, y, z) order — exactly what `Isometry3` holds — and a rotation is a row-major 3x3.
-//! The conversions are one-liners at the call site (`iso.translation.vector.into()`, `iso.rotation.coords` reordered), kept
-//! behind the `nalgebra` feature for a maintainer who has the crate.
+//! With the `nalgebra` feature (a maintainer who has the crate: `nalgebra = "0.34.1"`, crates/chalkydri_sqpnp/Cargo.toml:7) the
+//! module `na` below offers the reference's own signatures (lib.rs:297-304, 430-437) as thin conversions onto this core.
 use chalkydri_hip_sys as sys;
 
 pub type Mat3 = [[f64; 3]; 3];
@@ -29,7 +29,7 @@ impl Iso3 {
 pub const XY_STD_DEV_SCALAR: f64 = 5.0;
 pub const THETA_STD_DEV_SCALAR: f64 = 2.0;
 pub const MAX_TRUSTABLE_RMS: f64 = 0.1;
-pub const MAX_GYRO_DELTA: f64 = 30.0 * std::f64::consts::PI / 180.0;
+pub const MAX_GYRO_DELTA: f64 = 30.0; // degrees, as in the reference (lib.rs:35)
 pub const TAG_SIZE: f64 = 0.1651;
 pub const CORNER_DISTANCE: f64 = TAG_SIZE / 2.0;
 
@@ -82,5 +82,67 @@ impl SqPnP {
         let mut out = unsafe { std::mem::zeroed::<sys::ck_iso3_t>() };
         unsafe { sys::ck_sqpnp_create_solver_camera_transform(fwd_m, left_m, up_m, roll_deg, pitch_deg, yaw_deg, &mut out) };
         Iso3 { translation: out.t, rotation_wxyz: out.q }
+    }
+}
+
+
+/// The reference's typed surface (lib.rs:15-26, 297-304, 430-437) for builds that have nalgebra: the same type aliases and the
+/// two entry points with the reference's exact signatures, converting to and from the array core above.
+#[cfg(feature = "nalgebra")]
+pub mod na {
+    use nalgebra::{Isometry3, Matrix3, Quaternion, Rotation3, SVector, Translation3, UnitQuaternion};
+
+    pub type Mat3 = Matrix3<f64>;
+    pub type Vec3 = SVector<f64, 3>;
+    pub type Iso3 = Isometry3<f64>;
+    pub type Rot3 = Rotation3<f64>;
+
+    fn to_core(iso: &Isometry3<f64>) -> super::Iso3 {
+        let q = iso.rotation.quaternion(); // coords are (i, j, k, w)
+        super::Iso3 { translation: [iso.translation.x, iso.translation.y, iso.translation.z], rotation_wxyz: [q.w, q.i, q.j, q.k] }
+    }
+    fn from_core(iso: &super::Iso3) -> Isometry3<f64> {
+        let [w, x, y, z] = iso.rotation_wxyz;
+        Isometry3::from_parts(Translation3::new(iso.translation[0], iso.translation[1], iso.translation[2]),
+                              UnitQuaternion::from_quaternion(Quaternion::new(w, x, y, z)))
+    }
+
+    /// `SqPnP` with the reference's method signatures; `Clone + Debug + Default` like the reference's
+    #[derive(Clone, Debug, Default)]
+    pub struct SqPnP(pub super::SqPnP);
+    impl SqPnP {
+        pub fn new() -> Self { Self(super::SqPnP::new()) }
+        pub const fn max_iter(self, max_iter: usize) -> Self { Self(self.0.max_iter(max_iter)) }
+        pub const fn tolerance(self, tol: f64) -> Self { Self(self.0.tolerance(tol)) }
+        pub fn on(self, handle: *mut chalkydri_hip_sys::ck_handle_t) -> Self { Self(self.0.on(handle)) }
+
+        /// lib.rs:297-304
+        pub fn solve_robot_pose(
+            &mut self,
+            points_isometry: &[Isometry3<f64>],
+            points_2d: &[Vec3],
+            robot_to_cam: &Isometry3<f64>,
+            gyro: f64,
+            sign_change_error: f64,
+        ) -> Option<(Rot3, Vec3, Vec3)> {
+            let tags: Vec<super::Iso3> = points_isometry.iter().map(to_core).collect();
+            let bearings: Vec<super::Vec3> = points_2d.iter().map(|v| [v[0], v[1], v[2]]).collect();
+            let (rot, pos, dev) = self.0.solve_robot_pose(&tags, &bearings, &to_core(robot_to_cam), gyro, sign_change_error)?;
+            let m = rot.0;
+            let r = Matrix3::new(m[0][0], m[0][1], m[0][2], m[1][0], m[1][1], m[1][2], m[2][0], m[2][1], m[2][2]);
+            Some((Rotation3::from_matrix_unchecked(r), Vec3::new(pos[0], pos[1], pos[2]), Vec3::new(dev[0], dev[1], dev[2])))
+        }
+
+        /// lib.rs:430-437
+        pub fn create_solver_camera_transform(
+            fwd_m: f64,
+            left_m: f64,
+            up_m: f64,
+            roll_deg: f64,
+            pitch_deg: f64,
+            yaw_deg: f64,
+        ) -> Iso3 {
+            from_core(&super::SqPnP::create_solver_camera_transform(fwd_m, left_m, up_m, roll_deg, pitch_deg, yaw_deg))
+        }
     }
 }

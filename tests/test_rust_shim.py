@@ -44,3 +44,35 @@ def test_safe_crates_keep_the_reference_surface():
     utils = open(os.path.join(ROOT, "rust", "chalkydri-apriltags", "src", "utils.rs")).read()
     for name in ("fn grayscale", "fn fast_angle", "fn orientation", "fn find_convex_hull", "enum Color"):
         assert name in utils, name
+
+
+def _consts(text):
+    """name -> value text of every `const NAME: f64 = ...;` (an expression over earlier names is evaluated)"""
+    out = {}
+    for name, expr in re.findall(r"^\s*(?:pub )?const (\w+): f64 = ([^;]+);", text, flags=re.M):
+        out[name] = float(eval(expr, {"__builtins__": {}}, dict(out)))
+    return out
+
+
+def test_shim_constants_equal_the_references():
+    """every constant the shim re-declares has the reference's value (crates/chalkydri_sqpnp/src/lib.rs:29-39); the reference
+    is read as text, and only here in the container — the GPU box has no /root/reference, the test is CPU-only"""
+    ref_path = "/root/reference/crates/chalkydri_sqpnp/src/lib.rs"
+    want = {"XY_STD_DEV_SCALAR": 5.0, "THETA_STD_DEV_SCALAR": 2.0, "MAX_TRUSTABLE_RMS": 0.1, "MAX_GYRO_DELTA": 30.0, "TAG_SIZE": 0.1651,
+            "CORNER_DISTANCE": 0.08255}
+    if os.path.exists(ref_path):
+        ref = _consts(open(ref_path).read())
+        assert {k: ref[k] for k in want} == want, "the reference's constants have changed: update this test and the shim"
+    mine = _consts(open(os.path.join(ROOT, "rust", "chalkydri_sqpnp", "src", "lib.rs")).read())
+    assert {k: mine.get(k) for k in want} == want
+
+
+def test_nalgebra_feature_gates_the_typed_signatures():
+    sq = open(os.path.join(ROOT, "rust", "chalkydri_sqpnp", "src", "lib.rs")).read()
+    toml = open(os.path.join(ROOT, "rust", "chalkydri_sqpnp", "Cargo.toml")).read()
+    assert 'nalgebra = ["dep:nalgebra"]' in toml and "optional = true" in toml
+    gated = sq[sq.index('#[cfg(feature = "nalgebra")]'):]
+    flat = re.sub(r"\s+", " ", gated)
+    assert ("pub fn solve_robot_pose( &mut self, points_isometry: &[Isometry3<f64>], points_2d: &[Vec3], robot_to_cam: &Isometry3<f64>, "
+            "gyro: f64, sign_change_error: f64, ) -> Option<(Rot3, Vec3, Vec3)>") in flat
+    assert "pub fn create_solver_camera_transform( fwd_m: f64, left_m: f64, up_m: f64, roll_deg: f64, pitch_deg: f64, yaw_deg: f64, ) -> Iso3" in flat
