@@ -58,7 +58,11 @@ bool ck_guarded_free(void *p) {
     (void)hipDeviceSynchronize();
     (void)hipMemUnmap(g.va, g.map_bytes);
     (void)hipMemRelease(g.mem);
-    (void)hipMemAddressFree(g.va, g.va_bytes);
+    // The address range stays reserved for the life of the process.  Freed, the runtime hands the same range to the next
+    // reservation, and kernels then still reach the OLD, released pages through it while the copy engine sees the new ones
+    // (tools/probes/vmm_reuse_probe.hip shows it with runtime calls alone: every reuse reads back zeros / the fill pattern):
+    // that was the fp64 probe's "zeros" under CK_POISON=3.  A test process reserves a few thousand ranges of 47-bit address
+    // space at most; and an access after free faults now, too.
     return true;
 }
 
@@ -237,8 +241,9 @@ extern "C" int ck_segment_batch(ck_handle_t *h, const ck_image_u8_t *imgs, int32
     if (rc != CK_OK) return rc;
     size_t total = h->npix * (size_t)n;
     uint32_t *d_canon = nullptr, *d_sizes = nullptr;
-    if (ck_malloc_dev(&d_canon, total * sizeof(uint32_t)) != hipSuccess) return CK_ENOMEM;
-    if (sizes_out && ck_malloc_dev(&d_sizes, total * sizeof(uint32_t)) != hipSuccess) { (void)ck_free_dev(d_canon); return CK_ENOMEM; }
+    // (a failed allocation leaves the runtime's per-thread error behind: cleared, so that the next call's launch check does not meet it)
+    if (ck_malloc_dev(&d_canon, total * sizeof(uint32_t)) != hipSuccess) { (void)hipGetLastError(); return CK_ENOMEM; }
+    if (sizes_out && ck_malloc_dev(&d_sizes, total * sizeof(uint32_t)) != hipSuccess) { (void)ck_free_dev(d_canon); (void)hipGetLastError(); return CK_ENOMEM; }
     rc = ck_launch_canonical_labels(h, n, d_canon, d_sizes);
     if (rc == CK_OK) {
         hipError_t e = hipMemcpyAsync(labels_out, d_canon, total * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream);

@@ -85,7 +85,8 @@ struct ck_stage_ws {
     ck_run *d_runs;            // [n][run_cap]
     int run_cap;
     unsigned long long *d_lscratch; // [CK_LSCRATCH_WGS][CK_LSCRATCH_PER_WG]: sort scratch / maxima list of the large fit class, per workgroup
-    unsigned long long *d_hscratch; // [2][CK_HUGE_WGS][2][CK_HUGE_CAP]: keys + sort scratch / maxima list of the largest class (null when no cluster can be that large)
+    unsigned long long *d_hscratch; // [2][CK_HUGE_WGS][2][hcap]: keys + sort scratch / maxima list of the largest class (null when no cluster can be that large)
+    int hcap;                       // points per cluster that buffer is laid out for: max_cluster_points rounded up to 1024 (<= CK_HUGE_CAP)
     ck_cluster_t *d_clusters;  // [n][cluster_cap]
     uint32_t *d_counters;      // [n][8]: 0 tmp points, 1 clusters, 2 kept points, 3 quads, 4 detections, 5 status
     ck_quad_t *d_quads;        // [n][quad_cap]

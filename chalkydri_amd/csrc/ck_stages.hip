@@ -7,6 +7,17 @@
 
 static int next_pow2(int v) { int p = 1; while (p < v) p <<= 1; return p; }
 
+// an allocation that fails for lack of memory is CK_ENOMEM, as in ck_create (not the CK_EDEVICE of a runtime failure)
+#define CK_ALLOC(call)                                                                                     \
+    do {                                                                                                    \
+        hipError_t e_ = (call);                                                                             \
+        if (e_ != hipSuccess) {                                                                             \
+            snprintf(ck_err_text, sizeof ck_err_text, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), \
+                     __FILE__, __LINE__);                                                                   \
+            (void)hipGetLastError();                                                                        \
+            return e_ == hipErrorOutOfMemory ? CK_ENOMEM : CK_EDEVICE;                                      \
+        }                                                                                                   \
+    } while (0)
 int ck_stage_alloc(ck_handle *h) {
     ck_stage_ws &ws = h->ws;
     const ck_config_t &cfg = h->cfg;
@@ -24,38 +35,39 @@ int ck_stage_alloc(ck_handle *h) {
     if (ws.ht_size < 1024) ws.ht_size = 1024;
     ws.max_cluster_points = 3 * (2 * h->qw + 2 * h->qh); // AprilTag-3's bound; <= 3 * 4 * 4095 < CK_HUGE_CAP (ck_create bounds the sides)
     if (cfg.max_nmaxima < 4 || cfg.max_nmaxima > 12) return CK_EINVAL;
-    CK_HIP(ck_malloc_dev(&ws.d_ht_keys, sizeof(unsigned long long) * (size_t)ws.ht_size * nb));
-    CK_HIP(ck_malloc_dev(&ws.d_ht_count, sizeof(uint32_t) * (size_t)ws.ht_size * nb));
-    CK_HIP(ck_malloc_dev(&ws.d_ht_off, sizeof(uint32_t) * (size_t)ws.ht_size * nb));
-    CK_HIP(ck_malloc_dev(&ws.d_tmp, sizeof(ck_packed_point) * (size_t)ws.point_cap * nb));
-    CK_HIP(ck_malloc_dev(&ws.d_points, sizeof(ck_packed_point) * (size_t)ws.point_cap * nb));
+    CK_ALLOC(ck_malloc_dev(&ws.d_ht_keys, sizeof(unsigned long long) * (size_t)ws.ht_size * nb));
+    CK_ALLOC(ck_malloc_dev(&ws.d_ht_count, sizeof(uint32_t) * (size_t)ws.ht_size * nb));
+    CK_ALLOC(ck_malloc_dev(&ws.d_ht_off, sizeof(uint32_t) * (size_t)ws.ht_size * nb));
+    CK_ALLOC(ck_malloc_dev(&ws.d_tmp, sizeof(ck_packed_point) * (size_t)ws.point_cap * nb));
+    CK_ALLOC(ck_malloc_dev(&ws.d_points, sizeof(ck_packed_point) * (size_t)ws.point_cap * nb));
     ws.run_cap = 4 * ws.cluster_cap;
-    CK_HIP(ck_malloc_dev(&ws.d_runs, sizeof(ck_run) * (size_t)ws.run_cap * nb));
-    CK_HIP(ck_malloc_dev(&ws.d_lscratch, 2 * sizeof(unsigned long long) * (size_t)CK_LSCRATCH_PER_WG * CK_LSCRATCH_WGS));
+    CK_ALLOC(ck_malloc_dev(&ws.d_runs, sizeof(ck_run) * (size_t)ws.run_cap * nb));
+    CK_ALLOC(ck_malloc_dev(&ws.d_lscratch, 2 * sizeof(unsigned long long) * (size_t)CK_LSCRATCH_PER_WG * CK_LSCRATCH_WGS));
     ws.d_hscratch = nullptr;
+    ws.hcap = (ws.max_cluster_points + 1023) & ~1023; // (1920 x 1080: 18 432 points, 144 MiB instead of the 512 MiB of the class's template capacity)
     if (ws.max_cluster_points > 16384) // (one copy per stream of a split batch)
-        CK_HIP(ck_malloc_dev(&ws.d_hscratch, 2 * sizeof(unsigned long long) * 2 * (size_t)CK_HUGE_CAP * CK_HUGE_WGS));
-    CK_HIP(ck_malloc_dev(&ws.d_clusters, sizeof(ck_cluster_t) * (size_t)ws.cluster_cap * nb));
-    CK_HIP(ck_malloc_dev(&ws.d_counters, sizeof(uint32_t) * CK_CNT_STRIDE * nb));
-    CK_HIP(ck_malloc_dev(&ws.d_quads, sizeof(ck_quad_t) * (size_t)ws.quad_cap * nb));
-    CK_HIP(ck_malloc_dev(&ws.d_dets, sizeof(ck_detection_t) * (size_t)ws.det_cap * nb));
+        CK_ALLOC(ck_malloc_dev(&ws.d_hscratch, 2 * sizeof(unsigned long long) * 2 * (size_t)ws.hcap * CK_HUGE_WGS));
+    CK_ALLOC(ck_malloc_dev(&ws.d_clusters, sizeof(ck_cluster_t) * (size_t)ws.cluster_cap * nb));
+    CK_ALLOC(ck_malloc_dev(&ws.d_counters, sizeof(uint32_t) * CK_CNT_STRIDE * nb));
+    CK_ALLOC(ck_malloc_dev(&ws.d_quads, sizeof(ck_quad_t) * (size_t)ws.quad_cap * nb));
+    CK_ALLOC(ck_malloc_dev(&ws.d_dets, sizeof(ck_detection_t) * (size_t)ws.det_cap * nb));
     // fit scratch: one work list per size class + counters, then the decode candidates
     size_t list_bytes = ((size_t)CK_FIT_CLASSES * ws.cluster_cap * nb + 16) * sizeof(uint32_t);
     size_t cand_bytes = 256 + ((nb * 4 + 255) / 256) * 256 + sizeof(ck_detection_t) * (size_t)ws.quad_cap * cfg.n_families * nb;
     ws.fit_scratch_bytes = ((list_bytes + 255) / 256) * 256 + cand_bytes;
-    CK_HIP(ck_malloc_dev(&ws.d_fit_scratch, 2 * ws.fit_scratch_bytes)); // second copy: the half-batch that runs on stream2
-    CK_HIP(ck_malloc_dev(&ws.d_wimg, sizeof(uint16_t) * h->npix * nb));
+    CK_ALLOC(ck_malloc_dev(&ws.d_fit_scratch, 2 * ws.fit_scratch_bytes)); // second copy: the half-batch that runs on stream2
+    CK_ALLOC(ck_malloc_dev(&ws.d_wimg, sizeof(uint16_t) * h->npix * nb));
     ws.field_cap = 1024;
-    CK_HIP(ck_malloc_dev(&ws.d_field, sizeof(ck_field_tag_t) * (size_t)ws.field_cap));
-    CK_HIP(ck_malloc_dev(&ws.d_gyro, sizeof(double) * nb));
-    CK_HIP(ck_malloc_dev(&ws.d_has_gyro, nb));
-    CK_HIP(ck_malloc_dev(&ws.d_problems, sizeof(ck_sqpnp_problem_t) * nb));
-    CK_HIP(ck_malloc_dev(&ws.d_pose_tags, sizeof(ck_iso3_t) * nb * ws.det_cap));
-    CK_HIP(ck_malloc_dev(&ws.d_bearings, sizeof(double) * 12 * nb * ws.det_cap));
-    CK_HIP(ck_malloc_dev(&ws.d_world, sizeof(double) * 12 * nb * ws.det_cap));
-    CK_HIP(ck_malloc_dev(&ws.d_results, sizeof(ck_sqpnp_result_t) * nb));
-    CK_HIP(ck_malloc_dev(&ws.d_meas, sizeof(ck_vision_measurement_t) * nb));
-    CK_HIP(ck_malloc_dev(&ws.d_valid, sizeof(int32_t) * nb));
+    CK_ALLOC(ck_malloc_dev(&ws.d_field, sizeof(ck_field_tag_t) * (size_t)ws.field_cap));
+    CK_ALLOC(ck_malloc_dev(&ws.d_gyro, sizeof(double) * nb));
+    CK_ALLOC(ck_malloc_dev(&ws.d_has_gyro, nb));
+    CK_ALLOC(ck_malloc_dev(&ws.d_problems, sizeof(ck_sqpnp_problem_t) * nb));
+    CK_ALLOC(ck_malloc_dev(&ws.d_pose_tags, sizeof(ck_iso3_t) * nb * ws.det_cap));
+    CK_ALLOC(ck_malloc_dev(&ws.d_bearings, sizeof(double) * 12 * nb * ws.det_cap));
+    CK_ALLOC(ck_malloc_dev(&ws.d_world, sizeof(double) * 12 * nb * ws.det_cap));
+    CK_ALLOC(ck_malloc_dev(&ws.d_results, sizeof(ck_sqpnp_result_t) * nb));
+    CK_ALLOC(ck_malloc_dev(&ws.d_meas, sizeof(ck_vision_measurement_t) * nb));
+    CK_ALLOC(ck_malloc_dev(&ws.d_valid, sizeof(int32_t) * nb));
     // family tables
     std::vector<ck_dev_family> fams((size_t)cfg.n_families);
     for (int f = 0; f < cfg.n_families; f++) {
@@ -66,14 +78,15 @@ int ck_stage_alloc(ck_handle *h) {
         d.total_width = src->total_width; d.reversed_border = src->reversed_border;
         for (uint32_t i = 0; i < src->nbits; i++) { d.bit_x[i] = src->bit_x[i]; d.bit_y[i] = src->bit_y[i]; }
         uint64_t *dc = nullptr;
-        CK_HIP(ck_malloc_dev(&dc, sizeof(uint64_t) * src->ncodes));
+        CK_ALLOC(ck_malloc_dev(&dc, sizeof(uint64_t) * src->ncodes));
         CK_HIP(hipMemcpy(dc, src->codes, sizeof(uint64_t) * src->ncodes, hipMemcpyHostToDevice));
         d.codes = dc;
     }
-    CK_HIP(ck_malloc_dev(&h->d_fams, sizeof(ck_dev_family) * fams.size()));
+    CK_ALLOC(ck_malloc_dev(&h->d_fams, sizeof(ck_dev_family) * fams.size()));
     CK_HIP(hipMemcpy(h->d_fams, fams.data(), sizeof(ck_dev_family) * fams.size(), hipMemcpyHostToDevice));
     return CK_OK;
 }
+#undef CK_ALLOC
 
 void ck_stage_free(ck_handle *h) {
     ck_stage_ws &ws = h->ws;
@@ -117,7 +130,7 @@ static ck_handle make_view(const ck_handle *h, int f0, bool second_stream = true
     w.d_ht_keys += f * w.ht_size; w.d_ht_count += f * w.ht_size; w.d_ht_off += f * w.ht_size;
     w.d_tmp += f * w.point_cap; w.d_points += f * w.point_cap; w.d_runs += f * w.run_cap;
     if (second_stream) w.d_lscratch += (size_t)CK_LSCRATCH_PER_WG * CK_LSCRATCH_WGS;
-    if (second_stream && w.d_hscratch) w.d_hscratch += 2 * (size_t)CK_HUGE_CAP * CK_HUGE_WGS;
+    if (second_stream && w.d_hscratch) w.d_hscratch += 2 * (size_t)w.hcap * CK_HUGE_WGS;
     w.d_clusters += f * w.cluster_cap; w.d_counters += f * CK_CNT_STRIDE; w.d_quads += f * w.quad_cap; w.d_dets += f * w.det_cap;
     w.d_wimg += f * npix;
     if (second_stream) w.d_fit_scratch = static_cast<uint8_t *>(w.d_fit_scratch) + w.fit_scratch_bytes;

@@ -1459,14 +1459,22 @@ int ck_launch_canonical_labels(ck_handle *h, int n, uint32_t *d_out, uint32_t *d
     unsigned blocks = (unsigned)((total + NT - 1) / NT);
     hipLaunchKernelGGL(k_canon, dim3(blocks), dim3(NT), 0, h->stream, h->d_labels, h->d_groot, (size_t)h->broot_cap, d_out, h->npix, total);
     if (d_sizes) {
-        // exact sizes by counting: test path only (the pipeline uses the SMALL flag / csize[] instead)
+        // exact sizes by counting: test path only (the pipeline uses the SMALL flag of the label words and the slot tables instead).
+        // One exit: the count array is released on every path, and through the handle's allocator (guard pages under CK_POISON=3).
         uint32_t *cnt = nullptr;
-        CK_HIP(hipMalloc(&cnt, total * sizeof(uint32_t)));
-        CK_HIP(hipMemsetAsync(cnt, 0, total * sizeof(uint32_t), h->stream));
-        hipLaunchKernelGGL(k_count, dim3(blocks), dim3(NT), 0, h->stream, d_out, cnt, h->npix, total);
-        hipLaunchKernelGGL(k_sizes, dim3(blocks), dim3(NT), 0, h->stream, d_out, cnt, d_sizes, h->npix, total);
-        CK_HIP(hipStreamSynchronize(h->stream));
-        CK_HIP(hipFree(cnt));
+        hipError_t e = ck_malloc_dev(&cnt, total * sizeof(uint32_t));
+        if (e == hipSuccess) e = hipMemsetAsync(cnt, 0, total * sizeof(uint32_t), h->stream);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(k_count, dim3(blocks), dim3(NT), 0, h->stream, d_out, cnt, h->npix, total);
+            hipLaunchKernelGGL(k_sizes, dim3(blocks), dim3(NT), 0, h->stream, d_out, cnt, d_sizes, h->npix, total);
+            e = hipStreamSynchronize(h->stream);
+        }
+        (void)ck_free_dev(cnt);
+        if (e != hipSuccess) {
+            snprintf(ck_err_text, sizeof ck_err_text, "canonical labels: %s", hipGetErrorString(e));
+            (void)hipGetLastError();
+            return e == hipErrorOutOfMemory ? CK_ENOMEM : CK_EDEVICE;
+        }
     }
     CK_HIP(hipGetLastError());
     return CK_OK;

@@ -548,7 +548,9 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(WPS, 8))) v
     // sKeys holds the 64-bit sort keys; after duplicate removal its first half is reused for the packed
     // coordinates (x<<13|y, u32) and the third quarter for the u16 weights.
     __shared__ unsigned long long sKeysL[GK ? 1 : CAP];
-    unsigned long long *const sKeys = GK ? a.ws.d_hscratch + (size_t)blockIdx.x * 2 * CAP : sKeysL;
+    // (the largest class's slice of global memory is laid out for the frame's own bound on a cluster's points, not for the template's)
+    const int capr = GK ? a.ws.hcap : CAP;
+    unsigned long long *const sKeys = GK ? a.ws.d_hscratch + (size_t)blockIdx.x * 2 * capr : sKeysL;
     // inclusive moment prefix sums over the current span of SL points: Mxx, Mxy, Myy as 64-bit and Mx, My, W as 32-bit
     // (a span's sums stay below 304 * 362 * 8192 < 2^32); the same bytes are the sort's histogram before and the pair-fit
     // table after the chunk loop
@@ -580,8 +582,8 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(WPS, 8))) v
     const int tid = threadIdx.x;
     const ck_stage_ws &ws = a.ws;
     uint32_t *sXY = reinterpret_cast<uint32_t *>(sKeys);
-    uint16_t *sW = reinterpret_cast<uint16_t *>(sKeys) + 2 * CAP; // bytes [4*CAP, 6*CAP)
-    uint16_t *sMaxIdx = reinterpret_cast<uint16_t *>(sKeys) + 3 * CAP; // bytes [6*CAP, 8*CAP): free once the keys are packed
+    uint16_t *sW = reinterpret_cast<uint16_t *>(sKeys) + 2 * capr; // bytes [4*CAP, 6*CAP)
+    uint16_t *sMaxIdx = reinterpret_cast<uint16_t *>(sKeys) + 3 * capr; // bytes [6*CAP, 8*CAP): free once the keys are packed
 
     // chunked dequeue from the class work list: DQ consecutive clusters per atomic.  One atomic per cluster is too much for
     // the small class (520 k clusters per batch through one counter cost more than any phase of the fit), static striding
@@ -619,7 +621,7 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(WPS, 8))) v
         const ck_packed_point *pts = ws.d_points + (size_t)frame * ws.point_cap + cl.start;
         // 8 bytes per point for the large class (sort scratch, then the maxima list): one fixed region per workgroup, so
         // the same few hundred KB are reused cluster after cluster and stay in L2
-        unsigned long long *scratch8 = GK ? ws.d_hscratch + (size_t)blockIdx.x * 2 * CAP + CAP : ws.d_lscratch + (size_t)blockIdx.x * CK_LSCRATCH_PER_WG;
+        unsigned long long *scratch8 = GK ? ws.d_hscratch + (size_t)blockIdx.x * 2 * capr + capr : ws.d_lscratch + (size_t)blockIdx.x * CK_LSCRATCH_PER_WG;
         const int sz0 = (int)cl.count;
         const uint16_t *wq = a.wimg + (size_t)frame * a.qw * a.qh;
         const uint8_t *im = a.im + (size_t)frame * a.pitch;
