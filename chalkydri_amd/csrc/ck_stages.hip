@@ -45,7 +45,8 @@ int ck_stage_alloc(ck_handle *h) {
     CK_ALLOC(ck_malloc_dev(&ws.d_lscratch, 2 * sizeof(unsigned long long) * (size_t)CK_LSCRATCH_PER_WG * CK_LSCRATCH_WGS));
     ws.d_hscratch = nullptr;
     ws.hcap = (ws.max_cluster_points + 1023) & ~1023; // (1920 x 1080: 18 432 points, 144 MiB instead of the 512 MiB of the class's template capacity)
-    if (ws.max_cluster_points > 16384) // (one copy per stream of a split batch)
+    if (ws.hcap < 16384 && getenv("CK_FIT_GK")) ws.hcap = 16384;
+    if (ws.max_cluster_points > 16384 || getenv("CK_FIT_GK")) // (one copy per stream of a split batch)
         CK_ALLOC(ck_malloc_dev(&ws.d_hscratch, 2 * sizeof(unsigned long long) * 2 * (size_t)ws.hcap * CK_HUGE_WGS));
     CK_ALLOC(ck_malloc_dev(&ws.d_clusters, sizeof(ck_cluster_t) * (size_t)ws.cluster_cap * nb));
     CK_ALLOC(ck_malloc_dev(&ws.d_counters, sizeof(uint32_t) * CK_CNT_STRIDE * nb));

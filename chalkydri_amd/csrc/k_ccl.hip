@@ -952,6 +952,7 @@ struct FmFrame {
     int nhs, nvs;
     int w, h, tiles_x, tiles_y;
     uint32_t mode;                     // what this workgroup joins: 0 the black roots, 1 the white ones, 2 both (a frame with few roots)
+    int diag;                          // diagnostics (CK_FMERGE_STOP_AFTER 20 / 21): 1 the sweep without its loads, 2 without its joins
     // k_tile hands out white ids from 0 up and black ones from RING_CAP - 1 down; among the roots this workgroup joins, a tile's
     // white ones come first (in id order), then its black ones (in reverse id order)
     __device__ __forceinline__ bool acc(uint32_t e) const { return e != 0xFFFFu && (mode == 2u || (e >> 15) == mode); }
@@ -969,7 +970,26 @@ struct FmFrame {
 // Calls emit(j0, j1, j2) once per boundary pixel slot and lane (uniformly: every lane of the workgroup makes the same number of
 // calls); a join is number | number << 16 when numbers fit 16 bits (LDS path) — the global path passes WIDE = true and gets
 // the two numbers in separate calls of emit2.
-constexpr int FM_BATCH = 4; // rounds whose ring entries are requested together
+constexpr int FM_BATCH = 2; // groups per lane whose ring entries are requested together
+constexpr int FM_GRP = 8;   // boundary pixels per lane and group: one 16-byte load per ring row
+// eight consecutive ring entries (u16) in one load instruction.  The vector-memory unit takes a wave's load about 16 cycles whatever
+// its width, and the sweep of a 2448 x 2048 frame is a million ring entries per workgroup: fetched two bytes at a time, those
+// load instructions alone were 1.1 of the kernel's 1.9 ms.  The rows are 2-byte aligned only (any frame width), which global
+// memory takes.
+struct __attribute__((packed, aligned(2))) FmEntries8 { uint32_t v[4]; };
+__device__ __forceinline__ void fm_load8(const uint16_t *row, int i, int n, uint32_t (&e)[4]) { // entries i .. i + 7 of a row of n (0xFFFF beyond it)
+    if (i + FM_GRP <= n) {
+        const FmEntries8 t = *reinterpret_cast<const FmEntries8 *>(row + i);
+        e[0] = t.v[0]; e[1] = t.v[1]; e[2] = t.v[2]; e[3] = t.v[3];
+    } else {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const uint32_t lo = i + 2 * q < n ? row[i + 2 * q] : 0xFFFFu, hi = i + 2 * q + 1 < n ? row[i + 2 * q + 1] : 0xFFFFu;
+            e[q] = lo | (hi << 16);
+        }
+    }
+}
+__device__ __forceinline__ uint32_t fm_entry(const uint32_t (&e)[4], int j) { return (e[j >> 1] >> ((j & 1) * 16)) & 0xFFFFu; } // (j a compile-time constant)
 // The sweep visits the tile edges of the two lists only: the top edge of a tile that has roots for this workgroup, the left edge of
 // a tile when it or its left neighbour has (fm_edges).  A frame whose background thresholds to "no colour" has few.
 __device__ __forceinline__ void fm_edges(const FmFrame &f, int tiles, uint16_t *hseg, uint16_t *vseg, uint32_t *segn, int tid) {
@@ -985,65 +1005,78 @@ __device__ __forceinline__ void fm_edges(const FmFrame &f, int tiles, uint16_t *
 template <typename Emit>
 __device__ __forceinline__ void fm_boundaries(const FmFrame &f, int tid, Emit &&emit) {
     const int w = f.w, h = f.h, tiles_x = f.tiles_x;
-    // A round = one boundary pixel per lane.  The ring entries come from global memory (written by another kernel: a trip to the
-    // Infinity Cache at best), so the entries of FM_BATCH rounds are requested together and the rounds then worked off.
+    // A lane takes FM_GRP consecutive boundary pixels: their ring entries come in one load per ring row (plus the entries beside
+    // the group).  The entries come from global memory (written by another kernel: a trip to the Infinity Cache at best), so
+    // the entries of FM_BATCH groups are requested together and the groups then worked off.
     // horizontal edges: the top row of tile row ty against the bottom row of tile row ty - 1 (up, and for white up-left / up-right)
-    const int nh = f.nhs * TW;
+    const int nh = f.nhs * (TW / FM_GRP);
     for (int item0 = 0; item0 < nh; item0 += FM_BATCH * FM_NT) {
-        uint32_t P[FM_BATCH], Q1[FM_BATCH], Q0[FM_BATCH], Q2[FM_BATCH], PL[FM_BATCH];
+        uint32_t P[FM_BATCH][4], Q[FM_BATCH][4], QL[FM_BATCH], QR[FM_BATCH], PL[FM_BATCH];
         int X[FM_BATCH], TY[FM_BATCH];
 #pragma unroll
         for (int k = 0; k < FM_BATCH; k++) {
             const int item = item0 + k * FM_NT + tid;
-            P[k] = 0xFFFFu; Q1[k] = Q0[k] = Q2[k] = PL[k] = 0xFFFFu; X[k] = 0; TY[k] = 1;
+#pragma unroll
+            for (int q = 0; q < 4; q++) P[k][q] = Q[k][q] = 0xFFFFFFFFu;
+            QL[k] = QR[k] = PL[k] = 0xFFFFu; X[k] = 0; TY[k] = 1;
             if (item < nh) {
-                const uint32_t sg = f.hseg[item >> 7];
-                const int tyi = (int)(sg >> 5), x = (int)(sg & 31u) * TW + (item & (TW - 1));
+                const uint32_t sg = f.hseg[item / (TW / FM_GRP)];
+                const int tyi = (int)(sg >> 5), x = (int)(sg & 31u) * TW + (item % (TW / FM_GRP)) * FM_GRP;
                 X[k] = x; TY[k] = tyi;
-                if (x >= 1 && x <= w - 2) { // an origin column
+                if (x < w && f.diag != 1) {
                     const uint16_t *up = f.HB + (size_t)(tyi - 1) * w, *lo = f.HT + (size_t)tyi * w;
-                    P[k] = lo[x]; Q1[k] = up[x]; Q0[k] = up[x - 1]; Q2[k] = up[x + 1]; PL[k] = lo[x - 1];
+                    fm_load8(lo, x, w, P[k]); fm_load8(up, x, w, Q[k]);
+                    if (x > 0) { QL[k] = up[x - 1]; PL[k] = lo[x - 1]; }
+                    if (x + FM_GRP < w) QR[k] = up[x + FM_GRP];
                 }
             }
         }
 #pragma unroll
         for (int k = 0; k < FM_BATCH; k++) {
             if (item0 + k * FM_NT >= nh) break; // (uniform)
-            uint32_t a0 = NOJ, b0 = NOJ, b1 = NOJ, b2 = NOJ;
-            const int x = X[k];
-            const uint32_t p = P[k], q1 = Q1[k], q0 = Q0[k], q2 = Q2[k];
-            // the pixel on the left made the same joins when it is the same component over the same component (and, for
-            // white, the new diagonal neighbour up-right is that component again): nothing to add
-            // (ring entries are tile-local ids: comparable inside one tile column only)
-            const bool same = x > 1 && (x & (TW - 1)) != 0 && (x & (TW - 1)) != TW - 1 && PL[k] == p && q0 == q1 && (q2 == q1 || !(p & 0x8000u));
-            if (f.acc(p) && !same) {
-                const int trow = (TY[k] - 1) * tiles_x;
-                a0 = f.num(trow + tiles_x + (x >> 7), p);
-                if (q1 != 0xFFFFu && ((q1 ^ p) & 0x8000u) == 0) b0 = f.num(trow + (x >> 7), q1);
-                if (p & 0x8000u) { // white
-                    if ((q0 & 0x8000u) && q0 != 0xFFFFu && q0 != q1) b1 = f.num(trow + ((x - 1) >> 7), q0);
-                    if ((q2 & 0x8000u) && q2 != 0xFFFFu && q2 != q1) b2 = f.num(trow + ((x + 1) >> 7), q2);
+#pragma unroll
+            for (int j = 0; j < FM_GRP; j++) {
+                uint32_t a0 = NOJ, b0 = NOJ, b1 = NOJ, b2 = NOJ;
+                const int x = X[k] + j;
+                const bool origin = x >= 1 && x <= w - 2; // only origin columns join
+                const uint32_t p = origin ? fm_entry(P[k], j) : 0xFFFFu, q1 = fm_entry(Q[k], j);
+                const uint32_t q0 = j ? fm_entry(Q[k], j ? j - 1 : 0) : QL[k], q2 = j < FM_GRP - 1 ? fm_entry(Q[k], j < FM_GRP - 1 ? j + 1 : 0) : QR[k];
+                const uint32_t pl = j ? fm_entry(P[k], j ? j - 1 : 0) : PL[k];
+                // the pixel on the left made the same joins when it is the same component over the same component (and, for
+                // white, the new diagonal neighbour up-right is that component again): nothing to add
+                // (ring entries are tile-local ids: comparable inside one tile column only)
+                const bool same = x > 1 && (x & (TW - 1)) != 0 && (x & (TW - 1)) != TW - 1 && pl == p && q0 == q1 && (q2 == q1 || !(p & 0x8000u));
+                if (f.acc(p) && !same) {
+                    const int trow = (TY[k] - 1) * tiles_x;
+                    a0 = f.num(trow + tiles_x + (x >> 7), p);
+                    if (q1 != 0xFFFFu && ((q1 ^ p) & 0x8000u) == 0) b0 = f.num(trow + (x >> 7), q1);
+                    if (p & 0x8000u) { // white
+                        if ((q0 & 0x8000u) && q0 != 0xFFFFu && q0 != q1) b1 = f.num(trow + ((x - 1) >> 7), q0);
+                        if ((q2 & 0x8000u) && q2 != 0xFFFFu && q2 != q1) b2 = f.num(trow + ((x + 1) >> 7), q2);
+                    }
                 }
+                emit(a0, b0, a0, b1, a0, b2);
             }
-            emit(a0, b0, a0, b1, a0, b2);
         }
     }
     // vertical edges: the left column of tile column tx against the right column of tile column tx - 1
-    const int nv = f.nvs * TH;
+    const int nv = f.nvs * (TH / FM_GRP);
     for (int item0 = 0; item0 < nv; item0 += FM_BATCH * FM_NT) {
-        uint32_t P[FM_BATCH], Q[FM_BATCH], QL[FM_BATCH], PU[FM_BATCH];
+        uint32_t P[FM_BATCH][4], Q[FM_BATCH][4], QL[FM_BATCH], PU[FM_BATCH];
         int Y[FM_BATCH], TX[FM_BATCH];
 #pragma unroll
         for (int k = 0; k < FM_BATCH; k++) {
             const int item = item0 + k * FM_NT + tid;
-            P[k] = Q[k] = QL[k] = PU[k] = 0xFFFFu; Y[k] = 0; TX[k] = 1;
+#pragma unroll
+            for (int q = 0; q < 4; q++) P[k][q] = Q[k][q] = 0xFFFFFFFFu;
+            QL[k] = PU[k] = 0xFFFFu; Y[k] = 0; TX[k] = 1;
             if (item < nv) {
-                const uint32_t sg = f.vseg[item >> 5];
-                const int txi = (int)(sg & 31u), y = (int)(sg >> 5) * TH + (item & (TH - 1));
+                const uint32_t sg = f.vseg[item / (TH / FM_GRP)];
+                const int txi = (int)(sg & 31u), y = (int)(sg >> 5) * TH + (item % (TH / FM_GRP)) * FM_GRP;
                 Y[k] = y; TX[k] = txi;
-                if (y < h) {
+                if (y < h && f.diag != 1) {
                     const uint16_t *lf = f.VR + (size_t)(txi - 1) * h, *rt = f.VL + (size_t)txi * h;
-                    P[k] = rt[y]; Q[k] = lf[y];                // pixels (x, y) and (x - 1, y)
+                    fm_load8(rt, y, h, P[k]); fm_load8(lf, y, h, Q[k]);   // pixels (x, y ..) and (x - 1, y ..)
                     if (y > 0) { QL[k] = lf[y - 1]; PU[k] = rt[y - 1]; }
                 }
             }
@@ -1051,27 +1084,30 @@ __device__ __forceinline__ void fm_boundaries(const FmFrame &f, int tid, Emit &&
 #pragma unroll
         for (int k = 0; k < FM_BATCH; k++) {
             if (item0 + k * FM_NT >= nv) break; // (uniform)
-            uint32_t ap = NOJ, aq = NOJ, b0 = NOJ, b1 = NOJ, b2 = NOJ;
-            const int txi = TX[k], y = Y[k];
-            const int x = txi * TW;                        // >= 1; an origin unless it is the frame's last column
-            const int tp = (y / TH) * tiles_x + txi;       // tile of (x, y); (x - 1, y) lies in tp - 1
-            uint32_t p = P[k], q = Q[k];                    // (x - 1, y) is always an origin column (1 <= x - 1 <= w - 2)
-            if (!f.acc(p)) p = 0xFFFFu;                     // the other colour's pixels: another workgroup's
-            if (!f.acc(q)) q = 0xFFFFu;
-            if (p != 0xFFFFu) ap = f.num(tp, p);
-            if (q != 0xFFFFu) aq = f.num(tp - 1, q);
-            if (p != 0xFFFFu && x <= w - 2) {
-                if (q != 0xFFFFu && ((q ^ p) & 0x8000u) == 0) b0 = aq;
-                if ((p & 0x8000u) && y > 0) {              // white: up-left
-                    const uint32_t ql = QL[k];
-                    if ((ql & 0x8000u) && ql != 0xFFFFu) b1 = f.num(((y - 1) / TH) * tiles_x + txi - 1, ql);
+#pragma unroll
+            for (int j = 0; j < FM_GRP; j++) {
+                uint32_t ap = NOJ, aq = NOJ, b0 = NOJ, b1 = NOJ, b2 = NOJ;
+                const int txi = TX[k], y = Y[k] + j;
+                const int x = txi * TW;                        // >= 1; an origin unless it is the frame's last column
+                const int tp = (y / TH) * tiles_x + txi;       // tile of (x, y); (x - 1, y) lies in tp - 1
+                uint32_t p = fm_entry(P[k], j), q = fm_entry(Q[k], j); // (x - 1, y) is always an origin column (1 <= x - 1 <= w - 2); beyond the frame's last row both are 0xFFFF
+                if (!f.acc(p)) p = 0xFFFFu;                     // the other colour's pixels: another workgroup's
+                if (!f.acc(q)) q = 0xFFFFu;
+                if (p != 0xFFFFu) ap = f.num(tp, p);
+                if (q != 0xFFFFu) aq = f.num(tp - 1, q);
+                if (p != 0xFFFFu && x <= w - 2) {
+                    if (q != 0xFFFFu && ((q ^ p) & 0x8000u) == 0) b0 = aq;
+                    if ((p & 0x8000u) && y > 0) {              // white: up-left
+                        const uint32_t ql = j ? fm_entry(Q[k], j ? j - 1 : 0) : QL[k];
+                        if ((ql & 0x8000u) && ql != 0xFFFFu) b1 = f.num(((y - 1) / TH) * tiles_x + txi - 1, ql);
+                    }
                 }
+                if (q != 0xFFFFu && (q & 0x8000u) && y > 0) { // white pixel (x - 1, y): up-right is (x, y - 1)
+                    const uint32_t pu = j ? fm_entry(P[k], j ? j - 1 : 0) : PU[k];
+                    if ((pu & 0x8000u) && pu != 0xFFFFu) b2 = f.num(((y - 1) / TH) * tiles_x + txi, pu);
+                }
+                emit(ap, b0, ap, b1, aq, b2);
             }
-            if (q != 0xFFFFu && (q & 0x8000u) && y > 0) { // white pixel (x - 1, y): up-right is (x, y - 1)
-                const uint32_t pu = PU[k];
-                if ((pu & 0x8000u) && pu != 0xFFFFu) b2 = f.num(((y - 1) / TH) * tiles_x + txi, pu);
-            }
-            emit(ap, b0, ap, b1, aq, b2);
         }
     }
 }
@@ -1110,8 +1146,12 @@ __device__ __forceinline__ void fm_union(uint16_t *p, const uint16_t *key, const
     for (;;) {
         fm_find2(p, a, b);
         if (a == b) break;
-        uint32_t pa = key ? key[a] : 0u, pb = key ? key[b] : 0u; // both are roots right now; a root's pixel never changes
-        if (pa == pb) { pa = br[a].root; pb = br[b].root; }    // (no key array: every comparison reads the packed list, which this workgroup wrote: L2)
+        // both are roots right now; a root's pixel never changes.  Without a key array (more roots than parents + keys fit) the hook
+        // goes by the roots' NUMBERS — any fixed order keeps the forest acyclic — and the component's smallest pixel is found
+        // afterwards with one atomic minimum per root (reading the pixels from the packed list here, in L2, was what the
+        // 2448 x 2048 frames waited for)
+        uint32_t pa = key ? key[a] : a, pb = key ? key[b] : b;
+        if (key && pa == pb) { pa = br[a].root; pb = br[b].root; }
         const uint32_t hi = pa > pb ? a : b, lo = pa > pb ? b : a;
         if (fm_cas16(p, hi, hi, lo)) { a = lo; break; } // hooked while still a root: parent pixel < child pixel, so no cycle can form
     }
@@ -1222,6 +1262,7 @@ __global__ __launch_bounds__(FM_NT, 8) __attribute__((amdgpu_num_sgpr(80))) void
     FmFrame f;
     f.HT = fr; f.HB = fr + (size_t)tiles_y * w; f.VL = fr + 2 * (size_t)tiles_y * w; f.VR = f.VL + (size_t)tiles_x * h;
     f.base = base; f.boff = boff; f.numtab = numtab; f.w = w; f.h = h; f.tiles_x = tiles_x; f.tiles_y = tiles_y;
+    f.diag = stop_after == 20 ? 1 : (stop_after == 21 ? 2 : 0);
     // numbers: the tiles' counts, scanned (up to four tiles per thread).  Both colours are counted first: when all of a frame's
     // roots fit the LDS path together, the white workgroup joins both colours in one sweep and the black one has nothing to do.
     uint32_t n;
@@ -1273,7 +1314,7 @@ __global__ __launch_bounds__(FM_NT, 8) __attribute__((amdgpu_num_sgpr(80))) void
     if (stop_after == 0) return; // diagnostics (CK_FMERGE_STOP_AFTER)
     uint32_t *sc = gscratch + (size_t)frame * 2 * slots + (f.mode == 0u ? slots - n : 0); // global-memory path: parents; the sizes `slots` further on
     // More roots than parents + keys fit: up to twice as many (and at most 65 535) still run their unions in LDS, on the parents
-    // alone — root pixels are then compared through the packed list and the sizes added up in global memory.
+    // alone — hooked by root number, with the components' smallest pixels and sizes settled afterwards by atomics in global memory.
     const bool keyless = n > (uint32_t)lds_cap;
     if (n > 2u * (uint32_t)lds_cap || n > 0xFFFFu || min_comp > 0x7FFF) {
         fm_global_path(f, br, n, sc, sc + slots, groot, gsize, tiles);
@@ -1285,7 +1326,7 @@ __global__ __launch_bounds__(FM_NT, 8) __attribute__((amdgpu_num_sgpr(80))) void
     while ((npix - 1) >> key_shift > 0xFFFFu) key_shift++;
     for (uint32_t i = tid; i < n; i += FM_NT) {
         parent[i] = (uint16_t)i; // (without keys the parents run on into the key array's bytes)
-        if (keyless) gsz[i] = 0; else size16[i] = (uint16_t)(br[i].root >> key_shift);
+        if (keyless) { gsz[i] = 0; sc[i] = br[i].root; } else size16[i] = (uint16_t)(br[i].root >> key_shift); // (sc[]: the smallest pixel of the component a root ends up heading)
     }
     if (keyless) __threadfence();
     __syncthreads();
@@ -1300,6 +1341,7 @@ __global__ __launch_bounds__(FM_NT, 8) __attribute__((amdgpu_num_sgpr(80))) void
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (stop_after != 10) // (10: diagnostics, the sweep without its unions)
         for (uint32_t j = (uint32_t)lane; j < qn; j += 64) {
             const uint32_t e = wq[j];
             fm_union(parent, key, br, e & 0xFFFFu, e >> 16);
@@ -1308,7 +1350,8 @@ __global__ __launch_bounds__(FM_NT, 8) __attribute__((amdgpu_num_sgpr(80))) void
         qn = 0;
     };
     fm_boundaries(f, tid, [&](uint32_t a0, uint32_t b0, uint32_t a1, uint32_t b1, uint32_t a2, uint32_t b2) {
-        const bool v0 = a0 != NOJ && b0 != NOJ, v1 = a1 != NOJ && b1 != NOJ, v2 = a2 != NOJ && b2 != NOJ;
+        const bool live = f.diag != 2;
+        const bool v0 = live && a0 != NOJ && b0 != NOJ, v1 = live && a1 != NOJ && b1 != NOJ, v2 = live && a2 != NOJ && b2 != NOJ;
         const uint32_t cnt = (uint32_t)v0 + (uint32_t)v1 + (uint32_t)v2;
         const uint32_t incl = wave_scan_u32(cnt);
         uint32_t pos = qn + incl - cnt;
@@ -1332,7 +1375,7 @@ __global__ __launch_bounds__(FM_NT, 8) __attribute__((amdgpu_num_sgpr(80))) void
     const uint32_t enough = (uint32_t)min_comp;
     for (uint32_t i = tid; i < n; i += FM_NT) {
         const uint32_t sz = br[i].size;
-        if (keyless) atomicAdd(&gsz[parent[i]], sz);
+        if (keyless) { atomicAdd(&gsz[parent[i]], sz); if (parent[i] != i) atomicMin(&sc[parent[i]], br[i].root); }
         else fm_size_add(size16, parent[i], sz > 0x7FFFu ? 0x7FFFu : sz, enough);
     }
     if (keyless) __threadfence();
@@ -1344,7 +1387,7 @@ __global__ __launch_bounds__(FM_NT, 8) __attribute__((amdgpu_num_sgpr(80))) void
         for (uint32_t l = (uint32_t)(tid & 63); l < cnt; l += 64) {
             const uint32_t r = parent[b0 + l];
             const size_t slot = (size_t)t * RING_CAP + f.id_of(t, l, cnt);
-            groot[slot] = br[r].root;
+            groot[slot] = keyless ? gm_load(sc, r) : br[r].root;
             gsize[slot] = keyless ? gm_load(gsz, r) : size16[r];
         }
     }

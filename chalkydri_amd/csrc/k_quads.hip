@@ -1394,6 +1394,8 @@ int ck_launch_fit_quads(ck_handle *h, const uint8_t *qframes, int qstride, size_
         CK_HIP(hipEventRecord(h->ev_fit_fork, h->stream));
         for (int k = 0; k < CK_FIT_SIDE_STREAMS; k++) CK_HIP(hipStreamWaitEvent(h->fit_stream[k], h->ev_fit_fork, 0));
     }
+    static const int gk_env = getenv("CK_FIT_GK") ? atoi(getenv("CK_FIT_GK")) : 0; // (experiment: bit c set = class c keeps its keys in global memory: small LDS, more workgroups per CU)
+    const int gk_mask = ws.d_hscratch ? gk_env : 0;
     static const int skip_mask = getenv("CK_FIT_SKIP") ? atoi(getenv("CK_FIT_SKIP")) : 0; // (diagnostics: bit c set = class c is not launched)
     auto launch = [&](int c) {
         if ((skip_mask >> c) & 1) return;
@@ -1405,8 +1407,14 @@ int ck_launch_fit_quads(ck_handle *h, const uint8_t *qframes, int qstride, size_
         case 6: hipLaunchKernelGGL((k_fit<128, 1024, 128, true, 4>), dim3((unsigned)(cus * 7)), dim3(128), 0, cs[c], a); break;
         case 1: hipLaunchKernelGGL((k_fit<256, 2048, 224, true, 4>), dim3((unsigned)(cus * 4)), dim3(256), 0, cs[c], a); break;
         case 2: hipLaunchKernelGGL((k_fit<256, 4096, 512, true, 2>), dim3((unsigned)(cus * 2)), dim3(256), 0, cs[c], a); break;
-        case 3: hipLaunchKernelGGL((k_fit<512, 8192, 896, true, 2>), dim3((unsigned)cus), dim3(512), 0, cs[c], a); break;
-        case 4: hipLaunchKernelGGL((k_fit<512, 16384, 512, false, 2>), dim3((unsigned)cus), dim3(512), 0, cs[c], a); break;
+        case 3:
+            if (gk_mask & 8) hipLaunchKernelGGL((k_fit<512, 16384, 512, false, 4, true>), dim3((unsigned)CK_HUGE_WGS), dim3(512), 0, cs[c], a);
+            else hipLaunchKernelGGL((k_fit<512, 8192, 896, true, 2>), dim3((unsigned)cus), dim3(512), 0, cs[c], a);
+            break;
+        case 4:
+            if (gk_mask & 16) hipLaunchKernelGGL((k_fit<512, 16384, 512, false, 4, true>), dim3((unsigned)CK_HUGE_WGS), dim3(512), 0, cs[c], a);
+            else hipLaunchKernelGGL((k_fit<512, 16384, 512, false, 2>), dim3((unsigned)cus), dim3(512), 0, cs[c], a);
+            break;
         default: // more than 16384 points: only frames with more than 2730 pixels of half-perimeter have the buffer (and can have such clusters)
             if (ws.d_hscratch) hipLaunchKernelGGL((k_fit<512, CK_HUGE_CAP, 896, false, 2, true>), dim3((unsigned)CK_HUGE_WGS), dim3(512), 0, cs[c], a);
             break;
