@@ -936,7 +936,7 @@ namespace {
 // No label, threshold or per-pixel size word is read or written here.
 //
 // The unions run in LDS (u16 parents: up to FM_CAP roots per frame; dense noise at 1280x800 has about 22 000); a frame with
-// more takes the same steps in global memory (fm_global_path).  The frame-level root must be the component's smallest
+// more takes the same steps in global memory (fm_global_begin / fm_global_end).  The frame-level root must be the component's smallest
 // pixel, so a union hooks the root with the larger PIXEL under the other one (compare-and-swap on the root's own entry).
 constexpr int FM_NT = 1024;
 constexpr int FM_CAP = 30000;                 // roots a workgroup's LDS path holds with 16-bit pixel keys beside the parents (twice as many without)
@@ -970,26 +970,31 @@ struct FmFrame {
 // Calls emit(j0, j1, j2) once per boundary pixel slot and lane (uniformly: every lane of the workgroup makes the same number of
 // calls); a join is number | number << 16 when numbers fit 16 bits (LDS path) — the global path passes WIDE = true and gets
 // the two numbers in separate calls of emit2.
-constexpr int FM_BATCH = 2; // groups per lane whose ring entries are requested together
-constexpr int FM_GRP = 8;   // boundary pixels per lane and group: one 16-byte load per ring row
-// eight consecutive ring entries (u16) in one load instruction.  The vector-memory unit takes a wave's load about 16 cycles whatever
-// its width, and the sweep of a 2448 x 2048 frame is a million ring entries per workgroup: fetched two bytes at a time, those
-// load instructions alone were 1.1 of the kernel's 1.9 ms.  The rows are 2-byte aligned only (any frame width), which global
-// memory takes.
-struct __attribute__((packed, aligned(2))) FmEntries8 { uint32_t v[4]; };
-__device__ __forceinline__ void fm_load8(const uint16_t *row, int i, int n, uint32_t (&e)[4]) { // entries i .. i + 7 of a row of n (0xFFFF beyond it)
+constexpr int FM_GRP = 8;   // boundary pixels per lane and round: one 16-byte load per ring row
+// eight consecutive ring entries (u16) in one load instruction: a sweep that fetched them two bytes at a time issued a million
+// load instructions per workgroup at 2448 x 2048.  The rows are 2-byte aligned only (any frame width), which global memory takes.
+struct __attribute__((packed, aligned(2))) FmEntries8 { unsigned long long lo, hi; };
+struct FmRow8 { unsigned long long lo, hi; };
+__device__ __forceinline__ FmRow8 fm_load8(const uint16_t *row, int i, int n) { // entries i .. i + 7 of a row of n (0xFFFF beyond it)
+    FmRow8 r;
     if (i + FM_GRP <= n) {
         const FmEntries8 t = *reinterpret_cast<const FmEntries8 *>(row + i);
-        e[0] = t.v[0]; e[1] = t.v[1]; e[2] = t.v[2]; e[3] = t.v[3];
+        r.lo = t.lo; r.hi = t.hi;
     } else {
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const uint32_t lo = i + 2 * q < n ? row[i + 2 * q] : 0xFFFFu, hi = i + 2 * q + 1 < n ? row[i + 2 * q + 1] : 0xFFFFu;
-            e[q] = lo | (hi << 16);
+        r.lo = r.hi = ~0ull;
+        for (int q = 0; q < FM_GRP && i + q < n; q++) {
+            const unsigned long long v = row[i + q];
+            if (q < 4) r.lo = (r.lo & ~(0xFFFFull << (16 * q))) | (v << (16 * q));
+            else r.hi = (r.hi & ~(0xFFFFull << (16 * (q - 4)))) | (v << (16 * (q - 4)));
         }
     }
+    return r;
 }
-__device__ __forceinline__ uint32_t fm_entry(const uint32_t (&e)[4], int j) { return (e[j >> 1] >> ((j & 1) * 16)) & 0xFFFFu; } // (j a compile-time constant)
+// the loop over a group's pixels looks at entry 0 (and 1) of the row and shifts the row down by one entry per round (a row
+// indexed by the loop counter would live in scratch memory)
+__device__ __forceinline__ uint32_t fm_first(const FmRow8 &e) { return (uint32_t)e.lo & 0xFFFFu; }
+__device__ __forceinline__ uint32_t fm_second(const FmRow8 &e) { return (uint32_t)(e.lo >> 16) & 0xFFFFu; }
+__device__ __forceinline__ void fm_shift(FmRow8 &e) { e.lo = (e.lo >> 16) | (e.hi << 48); e.hi = (e.hi >> 16) | (0xFFFFull << 48); }
 // The sweep visits the tile edges of the two lists only: the top edge of a tile that has roots for this workgroup, the left edge of
 // a tile when it or its left neighbour has (fm_edges).  A frame whose background thresholds to "no colour" has few.
 __device__ __forceinline__ void fm_edges(const FmFrame &f, int tiles, uint16_t *hseg, uint16_t *vseg, uint32_t *segn, int tid) {
@@ -1002,112 +1007,97 @@ __device__ __forceinline__ void fm_edges(const FmFrame &f, int tiles, uint16_t *
     }
     __syncthreads();
 }
+// The loops are kept rolled (one group of eight pixels per lane and round, the eight worked off by a loop): unrolled, the sweep was
+// 140 KB of code, and sixteen waves at sixteen places of it waited for instruction fetches most of the time.
 template <typename Emit>
 __device__ __forceinline__ void fm_boundaries(const FmFrame &f, int tid, Emit &&emit) {
     const int w = f.w, h = f.h, tiles_x = f.tiles_x;
-    // A lane takes FM_GRP consecutive boundary pixels: their ring entries come in one load per ring row (plus the entries beside
-    // the group).  The entries come from global memory (written by another kernel: a trip to the Infinity Cache at best), so
-    // the entries of FM_BATCH groups are requested together and the groups then worked off.
+    const FmRow8 none = {~0ull, ~0ull};
     // horizontal edges: the top row of tile row ty against the bottom row of tile row ty - 1 (up, and for white up-left / up-right)
     const int nh = f.nhs * (TW / FM_GRP);
-    for (int item0 = 0; item0 < nh; item0 += FM_BATCH * FM_NT) {
-        uint32_t P[FM_BATCH][4], Q[FM_BATCH][4], QL[FM_BATCH], QR[FM_BATCH], PL[FM_BATCH];
-        int X[FM_BATCH], TY[FM_BATCH];
-#pragma unroll
-        for (int k = 0; k < FM_BATCH; k++) {
-            const int item = item0 + k * FM_NT + tid;
-#pragma unroll
-            for (int q = 0; q < 4; q++) P[k][q] = Q[k][q] = 0xFFFFFFFFu;
-            QL[k] = QR[k] = PL[k] = 0xFFFFu; X[k] = 0; TY[k] = 1;
-            if (item < nh) {
-                const uint32_t sg = f.hseg[item / (TW / FM_GRP)];
-                const int tyi = (int)(sg >> 5), x = (int)(sg & 31u) * TW + (item % (TW / FM_GRP)) * FM_GRP;
-                X[k] = x; TY[k] = tyi;
-                if (x < w && f.diag != 1) {
-                    const uint16_t *up = f.HB + (size_t)(tyi - 1) * w, *lo = f.HT + (size_t)tyi * w;
-                    fm_load8(lo, x, w, P[k]); fm_load8(up, x, w, Q[k]);
-                    if (x > 0) { QL[k] = up[x - 1]; PL[k] = lo[x - 1]; }
-                    if (x + FM_GRP < w) QR[k] = up[x + FM_GRP];
-                }
+#pragma unroll 1
+    for (int item0 = 0; item0 < nh; item0 += FM_NT) {
+        const int item = item0 + tid;
+        FmRow8 P = none, Q = none;
+        uint32_t QL = 0xFFFFu, QR = 0xFFFFu, PL = 0xFFFFu;
+        int X = 0, TY = 1;
+        if (item < nh) {
+            const uint32_t sg = f.hseg[item / (TW / FM_GRP)];
+            const int tyi = (int)(sg >> 5), x = (int)(sg & 31u) * TW + (item % (TW / FM_GRP)) * FM_GRP;
+            X = x; TY = tyi;
+            if (x < w && f.diag != 1) {
+                const uint16_t *up = f.HB + (size_t)(tyi - 1) * w, *lo = f.HT + (size_t)tyi * w;
+                P = fm_load8(lo, x, w); Q = fm_load8(up, x, w);
+                if (x > 0) { QL = up[x - 1]; PL = lo[x - 1]; }
+                if (x + FM_GRP < w) QR = up[x + FM_GRP];
             }
         }
-#pragma unroll
-        for (int k = 0; k < FM_BATCH; k++) {
-            if (item0 + k * FM_NT >= nh) break; // (uniform)
-#pragma unroll
-            for (int j = 0; j < FM_GRP; j++) {
-                uint32_t a0 = NOJ, b0 = NOJ, b1 = NOJ, b2 = NOJ;
-                const int x = X[k] + j;
-                const bool origin = x >= 1 && x <= w - 2; // only origin columns join
-                const uint32_t p = origin ? fm_entry(P[k], j) : 0xFFFFu, q1 = fm_entry(Q[k], j);
-                const uint32_t q0 = j ? fm_entry(Q[k], j ? j - 1 : 0) : QL[k], q2 = j < FM_GRP - 1 ? fm_entry(Q[k], j < FM_GRP - 1 ? j + 1 : 0) : QR[k];
-                const uint32_t pl = j ? fm_entry(P[k], j ? j - 1 : 0) : PL[k];
-                // the pixel on the left made the same joins when it is the same component over the same component (and, for
-                // white, the new diagonal neighbour up-right is that component again): nothing to add
-                // (ring entries are tile-local ids: comparable inside one tile column only)
-                const bool same = x > 1 && (x & (TW - 1)) != 0 && (x & (TW - 1)) != TW - 1 && pl == p && q0 == q1 && (q2 == q1 || !(p & 0x8000u));
-                if (f.acc(p) && !same) {
-                    const int trow = (TY[k] - 1) * tiles_x;
-                    a0 = f.num(trow + tiles_x + (x >> 7), p);
-                    if (q1 != 0xFFFFu && ((q1 ^ p) & 0x8000u) == 0) b0 = f.num(trow + (x >> 7), q1);
-                    if (p & 0x8000u) { // white
-                        if ((q0 & 0x8000u) && q0 != 0xFFFFu && q0 != q1) b1 = f.num(trow + ((x - 1) >> 7), q0);
-                        if ((q2 & 0x8000u) && q2 != 0xFFFFu && q2 != q1) b2 = f.num(trow + ((x + 1) >> 7), q2);
-                    }
+        uint32_t q0 = QL, pl = PL;                     // the entries on the left of the pixel at hand
+        uint32_t q1 = fm_first(Q);
+#pragma unroll 1
+        for (int j = 0; j < FM_GRP; j++) {
+            uint32_t a0 = NOJ, b0 = NOJ, b1 = NOJ, b2 = NOJ;
+            const int x = X + j;
+            const bool origin = x >= 1 && x <= w - 2; // only origin columns join
+            const uint32_t praw = fm_first(P), p = origin ? praw : 0xFFFFu;
+            const uint32_t q2 = j < FM_GRP - 1 ? fm_second(Q) : QR;
+            // the pixel on the left made the same joins when it is the same component over the same component (and, for
+            // white, the new diagonal neighbour up-right is that component again): nothing to add
+            // (ring entries are tile-local ids: comparable inside one tile column only)
+            const bool same = x > 1 && (x & (TW - 1)) != 0 && (x & (TW - 1)) != TW - 1 && pl == p && q0 == q1 && (q2 == q1 || !(p & 0x8000u));
+            if (f.acc(p) && !same) {
+                const int trow = (TY - 1) * tiles_x;
+                a0 = f.num(trow + tiles_x + (x >> 7), p);
+                if (q1 != 0xFFFFu && ((q1 ^ p) & 0x8000u) == 0) b0 = f.num(trow + (x >> 7), q1);
+                if (p & 0x8000u) { // white
+                    if ((q0 & 0x8000u) && q0 != 0xFFFFu && q0 != q1) b1 = f.num(trow + ((x - 1) >> 7), q0);
+                    if ((q2 & 0x8000u) && q2 != 0xFFFFu && q2 != q1) b2 = f.num(trow + ((x + 1) >> 7), q2);
                 }
-                emit(a0, b0, a0, b1, a0, b2);
             }
+            emit(a0, b0, a0, b1, a0, b2);
+            q0 = q1; q1 = q2; pl = praw;
+            fm_shift(P); fm_shift(Q);
         }
     }
     // vertical edges: the left column of tile column tx against the right column of tile column tx - 1
     const int nv = f.nvs * (TH / FM_GRP);
-    for (int item0 = 0; item0 < nv; item0 += FM_BATCH * FM_NT) {
-        uint32_t P[FM_BATCH][4], Q[FM_BATCH][4], QL[FM_BATCH], PU[FM_BATCH];
-        int Y[FM_BATCH], TX[FM_BATCH];
-#pragma unroll
-        for (int k = 0; k < FM_BATCH; k++) {
-            const int item = item0 + k * FM_NT + tid;
-#pragma unroll
-            for (int q = 0; q < 4; q++) P[k][q] = Q[k][q] = 0xFFFFFFFFu;
-            QL[k] = PU[k] = 0xFFFFu; Y[k] = 0; TX[k] = 1;
-            if (item < nv) {
-                const uint32_t sg = f.vseg[item / (TH / FM_GRP)];
-                const int txi = (int)(sg & 31u), y = (int)(sg >> 5) * TH + (item % (TH / FM_GRP)) * FM_GRP;
-                Y[k] = y; TX[k] = txi;
-                if (y < h && f.diag != 1) {
-                    const uint16_t *lf = f.VR + (size_t)(txi - 1) * h, *rt = f.VL + (size_t)txi * h;
-                    fm_load8(rt, y, h, P[k]); fm_load8(lf, y, h, Q[k]);   // pixels (x, y ..) and (x - 1, y ..)
-                    if (y > 0) { QL[k] = lf[y - 1]; PU[k] = rt[y - 1]; }
-                }
+#pragma unroll 1
+    for (int item0 = 0; item0 < nv; item0 += FM_NT) {
+        const int item = item0 + tid;
+        FmRow8 P = none, Q = none;
+        uint32_t ql = 0xFFFFu, pu = 0xFFFFu;           // the entries above the pixels at hand
+        int Y = 0, txi = 1;
+        if (item < nv) {
+            const uint32_t sg = f.vseg[item / (TH / FM_GRP)];
+            txi = (int)(sg & 31u);
+            Y = (int)(sg >> 5) * TH + (item % (TH / FM_GRP)) * FM_GRP;
+            if (Y < h && f.diag != 1) {
+                const uint16_t *lf = f.VR + (size_t)(txi - 1) * h, *rt = f.VL + (size_t)txi * h;
+                P = fm_load8(rt, Y, h); Q = fm_load8(lf, Y, h);   // pixels (x, y ..) and (x - 1, y ..)
+                if (Y > 0) { ql = lf[Y - 1]; pu = rt[Y - 1]; }
             }
         }
-#pragma unroll
-        for (int k = 0; k < FM_BATCH; k++) {
-            if (item0 + k * FM_NT >= nv) break; // (uniform)
-#pragma unroll
-            for (int j = 0; j < FM_GRP; j++) {
-                uint32_t ap = NOJ, aq = NOJ, b0 = NOJ, b1 = NOJ, b2 = NOJ;
-                const int txi = TX[k], y = Y[k] + j;
-                const int x = txi * TW;                        // >= 1; an origin unless it is the frame's last column
-                const int tp = (y / TH) * tiles_x + txi;       // tile of (x, y); (x - 1, y) lies in tp - 1
-                uint32_t p = fm_entry(P[k], j), q = fm_entry(Q[k], j); // (x - 1, y) is always an origin column (1 <= x - 1 <= w - 2); beyond the frame's last row both are 0xFFFF
-                if (!f.acc(p)) p = 0xFFFFu;                     // the other colour's pixels: another workgroup's
-                if (!f.acc(q)) q = 0xFFFFu;
-                if (p != 0xFFFFu) ap = f.num(tp, p);
-                if (q != 0xFFFFu) aq = f.num(tp - 1, q);
-                if (p != 0xFFFFu && x <= w - 2) {
-                    if (q != 0xFFFFu && ((q ^ p) & 0x8000u) == 0) b0 = aq;
-                    if ((p & 0x8000u) && y > 0) {              // white: up-left
-                        const uint32_t ql = j ? fm_entry(Q[k], j ? j - 1 : 0) : QL[k];
-                        if ((ql & 0x8000u) && ql != 0xFFFFu) b1 = f.num(((y - 1) / TH) * tiles_x + txi - 1, ql);
-                    }
-                }
-                if (q != 0xFFFFu && (q & 0x8000u) && y > 0) { // white pixel (x - 1, y): up-right is (x, y - 1)
-                    const uint32_t pu = j ? fm_entry(P[k], j ? j - 1 : 0) : PU[k];
-                    if ((pu & 0x8000u) && pu != 0xFFFFu) b2 = f.num(((y - 1) / TH) * tiles_x + txi, pu);
-                }
-                emit(ap, b0, ap, b1, aq, b2);
+        const int x = txi * TW;                        // >= 1; an origin unless it is the frame's last column
+#pragma unroll 1
+        for (int j = 0; j < FM_GRP; j++) {
+            uint32_t ap = NOJ, aq = NOJ, b0 = NOJ, b1 = NOJ, b2 = NOJ;
+            const int y = Y + j;
+            const int tp = (y / TH) * tiles_x + txi;       // tile of (x, y); (x - 1, y) lies in tp - 1
+            const uint32_t praw = fm_first(P), qraw = fm_first(Q); // (x - 1, y) is always an origin column (1 <= x - 1 <= w - 2); beyond the frame's last row both are 0xFFFF
+            uint32_t p = praw, q = qraw;
+            if (!f.acc(p)) p = 0xFFFFu;                     // the other colour's pixels: another workgroup's
+            if (!f.acc(q)) q = 0xFFFFu;
+            if (p != 0xFFFFu) ap = f.num(tp, p);
+            if (q != 0xFFFFu) aq = f.num(tp - 1, q);
+            if (p != 0xFFFFu && x <= w - 2) {
+                if (q != 0xFFFFu && ((q ^ p) & 0x8000u) == 0) b0 = aq;
+                if ((p & 0x8000u) && y > 0 && (ql & 0x8000u) && ql != 0xFFFFu) b1 = f.num(((y - 1) / TH) * tiles_x + txi - 1, ql); // white: up-left
             }
+            if (q != 0xFFFFu && (q & 0x8000u) && y > 0 && (pu & 0x8000u) && pu != 0xFFFFu)  // white pixel (x - 1, y): up-right is (x, y - 1)
+                b2 = f.num(((y - 1) / TH) * tiles_x + txi, pu);
+            emit(ap, b0, ap, b1, aq, b2);
+            ql = qraw; pu = praw;
+            fm_shift(P); fm_shift(Q);
         }
     }
 }
@@ -1199,15 +1189,16 @@ __device__ __forceinline__ void gm_union(uint32_t *p, const ck_border_root *__re
         if (atomicCAS(&p[hi], hi, lo) == hi) return;
     }
 }
-__device__ __forceinline__ void fm_global_path(const FmFrame &f, const ck_border_root *__restrict__ br, uint32_t n, uint32_t *gparent, uint32_t *gsz,
-                               uint32_t *groot, uint32_t *gsize, int tiles) {
+// The global-memory path's steps either side of the (shared) boundary sweep
+__device__ __forceinline__ void fm_global_begin(uint32_t n, uint32_t *gparent, uint32_t *gsz) {
     const int tid = threadIdx.x;
     for (uint32_t i = tid; i < n; i += FM_NT) { gparent[i] = i; gsz[i] = 0; }
     __threadfence();
     __syncthreads();
-    fm_boundaries(f, tid, [&](uint32_t a0, uint32_t b0, uint32_t a1, uint32_t b1, uint32_t a2, uint32_t b2) {
-        gm_union(gparent, br, a0, b0); gm_union(gparent, br, a1, b1); gm_union(gparent, br, a2, b2);
-    });
+}
+__device__ __forceinline__ void fm_global_end(const FmFrame &f, const ck_border_root *__restrict__ br, uint32_t n, uint32_t *gparent, uint32_t *gsz,
+                                              uint32_t *groot, uint32_t *gsize, int tiles) {
+    const int tid = threadIdx.x;
     __threadfence();
     __syncthreads();
     for (uint32_t i = tid; i < n; i += FM_NT) {
@@ -1262,7 +1253,7 @@ __global__ __launch_bounds__(FM_NT, 8) __attribute__((amdgpu_num_sgpr(80))) void
     FmFrame f;
     f.HT = fr; f.HB = fr + (size_t)tiles_y * w; f.VL = fr + 2 * (size_t)tiles_y * w; f.VR = f.VL + (size_t)tiles_x * h;
     f.base = base; f.boff = boff; f.numtab = numtab; f.w = w; f.h = h; f.tiles_x = tiles_x; f.tiles_y = tiles_y;
-    f.diag = stop_after == 20 ? 1 : (stop_after == 21 ? 2 : 0);
+    f.diag = stop_after == 20 ? 1 : (stop_after == 21 ? 2 : (stop_after == 22 ? 1 : 0));
     // numbers: the tiles' counts, scanned (up to four tiles per thread).  Both colours are counted first: when all of a frame's
     // roots fit the LDS path together, the white workgroup joins both colours in one sweep and the black one has nothing to do.
     uint32_t n;
@@ -1316,20 +1307,22 @@ __global__ __launch_bounds__(FM_NT, 8) __attribute__((amdgpu_num_sgpr(80))) void
     // More roots than parents + keys fit: up to twice as many (and at most 65 535) still run their unions in LDS, on the parents
     // alone — hooked by root number, with the components' smallest pixels and sizes settled afterwards by atomics in global memory.
     const bool keyless = n > (uint32_t)lds_cap;
-    if (n > 2u * (uint32_t)lds_cap || n > 0xFFFFu || min_comp > 0x7FFF) {
-        fm_global_path(f, br, n, sc, sc + slots, groot, gsize, tiles);
-        return;
-    }
+    // ... and beyond that (or with a min_component_px the 16-bit sizes cannot express) the same steps run in global memory; the
+    // boundary sweep below is the same code for both (one instantiation: its joins go to the wave's queue or straight to gm_union)
+    const bool gmode = n > 2u * (uint32_t)lds_cap || n > 0xFFFFu || min_comp > 0x7FFF;
     uint32_t *gsz = sc + slots;
+    if (gmode) fm_global_begin(n, sc, gsz);
     // while the unions run, the size array holds the roots' pixel keys: pixel index >> key_shift, 16 bits
     int key_shift = 0;
     while ((npix - 1) >> key_shift > 0xFFFFu) key_shift++;
-    for (uint32_t i = tid; i < n; i += FM_NT) {
-        parent[i] = (uint16_t)i; // (without keys the parents run on into the key array's bytes)
-        if (keyless) { gsz[i] = 0; sc[i] = br[i].root; } else size16[i] = (uint16_t)(br[i].root >> key_shift); // (sc[]: the smallest pixel of the component a root ends up heading)
+    if (!gmode) {
+        for (uint32_t i = tid; i < n; i += FM_NT) {
+            parent[i] = (uint16_t)i; // (without keys the parents run on into the key array's bytes)
+            if (keyless) { gsz[i] = 0; sc[i] = br[i].root; } else size16[i] = (uint16_t)(br[i].root >> key_shift); // (sc[]: the smallest pixel of the component a root ends up heading)
+        }
+        if (keyless) __threadfence();
+        __syncthreads();
     }
-    if (keyless) __threadfence();
-    __syncthreads();
     const uint16_t *key = keyless ? nullptr : size16;
     // Every boundary pixel yields up to three joins; most lanes have fewer, and a join is a chain of dependent LDS reads.  So the
     // joins of a wave are queued in LDS (wave prefix sums) and then worked off one per lane, all lanes busy, instead of every
@@ -1350,6 +1343,8 @@ __global__ __launch_bounds__(FM_NT, 8) __attribute__((amdgpu_num_sgpr(80))) void
         qn = 0;
     };
     fm_boundaries(f, tid, [&](uint32_t a0, uint32_t b0, uint32_t a1, uint32_t b1, uint32_t a2, uint32_t b2) {
+        if (gmode) { gm_union(sc, br, a0, b0); gm_union(sc, br, a1, b1); gm_union(sc, br, a2, b2); return; } // (uniform)
+        if (stop_after == 22) return; // (diagnostics: the sweep without its queueing)
         const bool live = f.diag != 2;
         const bool v0 = live && a0 != NOJ && b0 != NOJ, v1 = live && a1 != NOJ && b1 != NOJ, v2 = live && a2 != NOJ && b2 != NOJ;
         const uint32_t cnt = (uint32_t)v0 + (uint32_t)v1 + (uint32_t)v2;
@@ -1361,6 +1356,7 @@ __global__ __launch_bounds__(FM_NT, 8) __attribute__((amdgpu_num_sgpr(80))) void
         qn += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
         if (qn > FM_WQ - 192) drain();
     });
+    if (gmode) { fm_global_end(f, br, n, sc, gsz, groot, gsize, tiles); return; }
     drain();
     __syncthreads();
     if (stop_after == 1) return;

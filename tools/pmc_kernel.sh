@@ -6,7 +6,7 @@ root=$GRAFT_REPO_ROOT
 sub=$1; kind=$2; shift 2
 out=$root/gpurun_out/pmc_k
 rm -rf $out
-timeout -k 10 200 rocprofv3 --pmc "$@" --output-format csv -d $out -- python3 $root/tools/bench_thrseg.py 1280 800 256 $kind > /dev/null 2>&1
+timeout -k 10 200 rocprofv3 --pmc "$@" --output-format csv -d $out -- python3 $root/tools/bench_thrseg.py ${GEOM:-1280 800 256} $kind > /dev/null 2>&1
 python3 - <<PY
 import csv, glob
 acc, n = {}, {}
