@@ -1,0 +1,5 @@
+#!/bin/bash
+# clusters stage time with k_emit cut short (CK_EMIT_STOP_AFTER: 0 staging, 1 + count pass, 2 + reservation, 99 all)
+for s in 0 1 2 99; do
+  CK_EMIT_STOP_AFTER=$s CK_FIT_SKIP=255 python tools/bench_detect.py 1280 800 256 3 1 2>/dev/null | tail -n 1 | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('emit stop=$s', 'clusters', d['clusters'])"
+done
