@@ -1220,10 +1220,20 @@ __device__ __forceinline__ void fm_global_end(const FmFrame &f, const ck_border_
     }
 }
 
+// Diagnostic build only (-DCK_FM_PROFILE): per-phase shader-clock totals of k_fmerge's first wave, in a buffer of their own.
+#ifdef CK_FM_PROFILE
+__device__ unsigned long long g_fm_prof[16];
+#define FPROF_DECL unsigned long long fp0 = __builtin_readcyclecounter()
+#define FPROF(k) do { unsigned long long t_ = __builtin_readcyclecounter(); if (threadIdx.x == 0) atomicAdd(&g_fm_prof[k], t_ - fp0); fp0 = t_; } while (0)
+#else
+#define FPROF_DECL
+#define FPROF(k)
+#endif
+
 // One workgroup per (frame, colour): white and black components never join, so the two colours of a frame are two independent
 // union-finds over half the roots each — two workgroups per CU instead of one, each with half the chain of dependent steps.
 // Dynamic LDS: parent u16[cap] | size / key u16[cap] | base u32[tiles + 1] | queue u32[16][FM_WQ].
-__global__ __launch_bounds__(FM_NT, 8) __attribute__((amdgpu_num_sgpr(80))) void k_fmerge(ck_border_root *__restrict__ broots, const uint32_t *__restrict__ tile_count,
+__global__ __launch_bounds__(FM_NT, 4) __attribute__((amdgpu_num_sgpr(80))) void k_fmerge(ck_border_root *__restrict__ broots, const uint32_t *__restrict__ tile_count,
                                                   const uint16_t *__restrict__ ring, size_t ring_len, uint32_t *__restrict__ groot_all,
                                                   uint32_t *__restrict__ gsize_all, uint32_t *__restrict__ gscratch, size_t npix, int w, int h,
                                                   int tiles_x, int tiles_y, int frame0, int n_frames, int min_comp, int lds_cap, int stop_after) {
@@ -1292,17 +1302,13 @@ __global__ __launch_bounds__(FM_NT, 8) __attribute__((amdgpu_num_sgpr(80))) void
         __syncthreads();
     }
     if (n == 0) return;
+    FPROF_DECL;
     fm_edges(f, tiles, hseg, vseg, segn, tid);
+    FPROF(0);
     f.hseg = hseg; f.vseg = vseg; f.nhs = (int)segn[0]; f.nvs = (int)segn[1];
     // the same entries packed, a root's index = its number: from the front of the frame's second half — the black workgroup of a
     // frame whose colours are joined separately packs at its end (the two colours' roots together are at most `slots`)
     ck_border_root *br = broots + (size_t)frame * 2 * slots + slots + (f.mode == 0u ? slots - n : 0);
-    for (int t = tid >> 6; t < tiles; t += FM_NT / 64) { // pack: a wave per tile copies the slice's entries it joins
-        const uint32_t b0 = base[t], cnt = base[t + 1] - b0;
-        for (uint32_t l = (uint32_t)(tid & 63); l < cnt; l += 64) br[b0 + l] = slice[(size_t)t * RING_CAP + f.id_of(t, l, cnt)];
-    }
-    __syncthreads(); // the packed list was written by this workgroup: visible to it after the barrier
-    if (stop_after == 0) return; // diagnostics (CK_FMERGE_STOP_AFTER)
     uint32_t *sc = gscratch + (size_t)frame * 2 * slots + (f.mode == 0u ? slots - n : 0); // global-memory path: parents; the sizes `slots` further on
     // More roots than parents + keys fit: up to twice as many (and at most 65 535) still run their unions in LDS, on the parents
     // alone — hooked by root number, with the components' smallest pixels and sizes settled afterwards by atomics in global memory.
@@ -1311,18 +1317,65 @@ __global__ __launch_bounds__(FM_NT, 8) __attribute__((amdgpu_num_sgpr(80))) void
     // boundary sweep below is the same code for both (one instantiation: its joins go to the wave's queue or straight to gm_union)
     const bool gmode = n > 2u * (uint32_t)lds_cap || n > 0xFFFFu || min_comp > 0x7FFF;
     uint32_t *gsz = sc + slots;
-    if (gmode) fm_global_begin(n, sc, gsz);
     // while the unions run, the size array holds the roots' pixel keys: pixel index >> key_shift, 16 bits
     int key_shift = 0;
     while ((npix - 1) >> key_shift > 0xFFFFu) key_shift++;
-    if (!gmode) {
-        for (uint32_t i = tid; i < n; i += FM_NT) {
-            parent[i] = (uint16_t)i; // (without keys the parents run on into the key array's bytes)
-            if (keyless) { gsz[i] = 0; sc[i] = br[i].root; } else size16[i] = (uint16_t)(br[i].root >> key_shift); // (sc[]: the smallest pixel of the component a root ends up heading)
+    // Pack: a wave takes FM_PT tiles per round and copies their slices' entries; the loads of a round (two per lane and tile) are
+    // all issued before the first store — one memory round trip per round instead of one per tile (the old loop's chain of load,
+    // store, load ... was a sixth of the kernel at 1280 x 800).  The entry's number is also where its parent, key and, on the
+    // keyless path, its size and smallest-pixel cells start out: written here, from the registers that hold the entry.
+    constexpr int FM_PT = 4;
+    for (int t0 = tid >> 6; t0 < tiles; t0 += FM_PT * (FM_NT / 64)) {
+        ck_border_root e[FM_PT][2];
+        uint32_t at[FM_PT][2];
+#pragma unroll
+        for (int u = 0; u < FM_PT; u++) {
+            const int t = t0 + u * (FM_NT / 64);
+            const uint32_t b0 = t < tiles ? base[t] : 0u, cnt = t < tiles ? base[t + 1] - b0 : 0u;
+#pragma unroll
+            for (int v = 0; v < 2; v++) {
+                const uint32_t l = (uint32_t)(tid & 63) + 64u * v;
+                at[u][v] = l < cnt ? b0 + l : 0xFFFFFFFFu;
+                if (l < cnt) e[u][v] = slice[(size_t)t * RING_CAP + f.id_of(t, l, cnt)];
+            }
         }
-        if (keyless) __threadfence();
-        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < FM_PT; u++)
+#pragma unroll
+            for (int v = 0; v < 2; v++) {
+                const uint32_t i = at[u][v];
+                if (i == 0xFFFFFFFFu) continue;
+                br[i] = e[u][v];
+                if (!gmode) {
+                    parent[i] = (uint16_t)i; // (without keys the parents run on into the key array's bytes)
+                    if (keyless) { gsz[i] = 0; sc[i] = e[u][v].root; } // (sc[]: the smallest pixel of the component a root ends up heading)
+                    else size16[i] = (uint16_t)(e[u][v].root >> key_shift);
+                }
+            }
+        for (int u = 0; u < FM_PT; u++) { // a tile with more than 128 ring-touching roots of this workgroup's colours: the rest, one by one
+            const int t = t0 + u * (FM_NT / 64);
+            if (t >= tiles) break;
+            const uint32_t b0 = base[t], cnt = base[t + 1] - b0;
+            for (uint32_t l = (uint32_t)(tid & 63) + 128u; l < cnt; l += 64) {
+                const ck_border_root x = slice[(size_t)t * RING_CAP + f.id_of(t, l, cnt)];
+                const uint32_t i = b0 + l;
+                br[i] = x;
+                if (!gmode) {
+                    parent[i] = (uint16_t)i;
+                    if (keyless) { gsz[i] = 0; sc[i] = x.root; } else size16[i] = (uint16_t)(x.root >> key_shift);
+                }
+            }
+        }
     }
+    // the packed list and the cells in global memory were written by this workgroup and are read (and updated by atomics, which
+    // execute at L2, where this CU's stores are once they are counted done) by this workgroup only: a workgroup-scope release
+    // and the barrier order them — no agent-scope fence, which is a cache write-back and invalidate per thread
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    FPROF(1);
+    if (stop_after == 0) return; // diagnostics (CK_FMERGE_STOP_AFTER)
+    if (gmode) fm_global_begin(n, sc, gsz);
+    FPROF(2);
     const uint16_t *key = keyless ? nullptr : size16;
     // Every boundary pixel yields up to three joins; most lanes have fewer, and a join is a chain of dependent LDS reads.  So the
     // joins of a wave are queued in LDS (wave prefix sums) and then worked off one per lane, all lanes busy, instead of every
@@ -1356,9 +1409,11 @@ __global__ __launch_bounds__(FM_NT, 8) __attribute__((amdgpu_num_sgpr(80))) void
         qn += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
         if (qn > FM_WQ - 192) drain();
     });
+    FPROF(3);
     if (gmode) { fm_global_end(f, br, n, sc, gsz, groot, gsize, tiles); return; }
     drain();
     __syncthreads();
+    FPROF(4);
     if (stop_after == 1) return;
     for (uint32_t i = tid; i < n; i += FM_NT) { // flatten (walks only read: other lanes' entries may still be mid-chain)
         uint32_t r = i;
@@ -1367,27 +1422,86 @@ __global__ __launch_bounds__(FM_NT, 8) __attribute__((amdgpu_num_sgpr(80))) void
         if (!keyless) size16[i] = 0;         // the keys are dead: the array becomes the sizes
     }
     __syncthreads();
+    FPROF(5);
     if (stop_after == 2) return;
     const uint32_t enough = (uint32_t)min_comp;
-    for (uint32_t i = tid; i < n; i += FM_NT) {
-        const uint32_t sz = br[i].size;
-        if (keyless) { atomicAdd(&gsz[parent[i]], sz); if (parent[i] != i) atomicMin(&sc[parent[i]], br[i].root); }
-        else fm_size_add(size16, parent[i], sz > 0x7FFFu ? 0x7FFFu : sz, enough);
-    }
-    if (keyless) __threadfence();
-    __syncthreads();
-    if (stop_after == 3) return;
-    // the tables, tile by tile
-    for (int t = tid >> 6; t < tiles; t += FM_NT / 64) {
-        const uint32_t b0 = base[t], cnt = base[t + 1] - b0;
-        for (uint32_t l = (uint32_t)(tid & 63); l < cnt; l += 64) {
-            const uint32_t r = parent[b0 + l];
-            const size_t slot = (size_t)t * RING_CAP + f.id_of(t, l, cnt);
-            groot[slot] = keyless ? gm_load(sc, r) : br[r].root;
-            gsize[slot] = keyless ? gm_load(gsz, r) : size16[r];
+    // sizes (and, without keys, the components' smallest pixels): four roots per lane and round, their list entries requested
+    // together.  On the keyless path the cells are in global memory and a frame's giant component is most of its roots: every add
+    // and every minimum to ONE address, served one by one at L2 — so a cell is read first, and an add to a size already at
+    // min_component_px (sizes are exact below it only) or a minimum that would not lower the cell is not issued.
+    for (uint32_t i0 = 0; i0 < n; i0 += 4 * FM_NT) {
+        ck_border_root e[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const uint32_t i = i0 + u * FM_NT + tid; if (i < n) e[u] = br[i]; }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t i = i0 + u * FM_NT + tid;
+            if (i >= n) continue;
+            const uint32_t r = parent[i], sz = e[u].size;
+            if (keyless) {
+                if (gm_load(gsz, r) < enough) atomicAdd(&gsz[r], sz);
+                if (r != i && gm_load(sc, r) > e[u].root) atomicMin(&sc[r], e[u].root);
+            } else fm_size_add(size16, r, sz > 0x7FFFu ? 0x7FFFu : sz, enough);
         }
     }
+    if (keyless) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); // (the cells are read back by this workgroup only, with L2 loads)
+    __syncthreads();
+    FPROF(6);
+    if (stop_after == 3) return;
+    // the tables, tile by tile: FM_PT tiles per wave and round, the round's lookups in flight together
+    for (int t0 = tid >> 6; t0 < tiles; t0 += FM_PT * (FM_NT / 64)) {
+        uint32_t rr[FM_PT][2], rootv[FM_PT][2], sizev[FM_PT][2];
+        size_t slot[FM_PT][2];
+#pragma unroll
+        for (int u = 0; u < FM_PT; u++) {
+            const int t = t0 + u * (FM_NT / 64);
+            const uint32_t b0 = t < tiles ? base[t] : 0u, cnt = t < tiles ? base[t + 1] - b0 : 0u;
+#pragma unroll
+            for (int v = 0; v < 2; v++) {
+                const uint32_t l = (uint32_t)(tid & 63) + 64u * v;
+                rr[u][v] = 0xFFFFFFFFu;
+                if (l < cnt) { rr[u][v] = parent[b0 + l]; slot[u][v] = (size_t)t * RING_CAP + f.id_of(t, l, cnt); }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < FM_PT; u++)
+#pragma unroll
+            for (int v = 0; v < 2; v++) {
+                const uint32_t r = rr[u][v];
+                if (r == 0xFFFFFFFFu) continue;
+                rootv[u][v] = keyless ? gm_load(sc, r) : br[r].root;
+                sizev[u][v] = keyless ? gm_load(gsz, r) : size16[r];
+            }
+#pragma unroll
+        for (int u = 0; u < FM_PT; u++)
+#pragma unroll
+            for (int v = 0; v < 2; v++)
+                if (rr[u][v] != 0xFFFFFFFFu) { groot[slot[u][v]] = rootv[u][v]; gsize[slot[u][v]] = sizev[u][v]; }
+        for (int u = 0; u < FM_PT; u++) { // (more than 128 roots in a tile: the rest)
+            const int t = t0 + u * (FM_NT / 64);
+            if (t >= tiles) break;
+            const uint32_t b0 = base[t], cnt = base[t + 1] - b0;
+            for (uint32_t l = (uint32_t)(tid & 63) + 128u; l < cnt; l += 64) {
+                const uint32_t r = parent[b0 + l];
+                const size_t sl = (size_t)t * RING_CAP + f.id_of(t, l, cnt);
+                groot[sl] = keyless ? gm_load(sc, r) : br[r].root;
+                gsize[sl] = keyless ? gm_load(gsz, r) : size16[r];
+            }
+        }
+    }
+    FPROF(7);
 }
+
+#ifdef CK_FM_PROFILE
+} // namespace
+extern "C" int ck_fm_profile_read(unsigned long long *out, int reset) {
+    unsigned long long z[16] = {};
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fm_prof), sizeof z) != hipSuccess) return -1;
+    if (reset && hipMemcpyToSymbol(HIP_SYMBOL(g_fm_prof), z, sizeof z) != hipSuccess) return -1;
+    return 0;
+}
+namespace {
+#endif
 
 // ---- parity / test path: canonical labels and exact sizes ---------------------------------------------------------------------
 __global__ __launch_bounds__(NT) void k_canon(const uint32_t *__restrict__ labels, const uint32_t *__restrict__ groot, size_t slots,
