@@ -1034,6 +1034,11 @@ __device__ __forceinline__ void fm_boundaries(const FmFrame &f, int tid, Emit &&
         }
         uint32_t q0 = QL, pl = PL;                     // the entries on the left of the pixel at hand
         uint32_t q1 = fm_first(Q);
+        // the group lies inside one tile column: the numbers of its two tiles' roots start at the same four table entries for all
+        // eight pixels (only a diagonal neighbour at the group's very ends can lie in the next tile column)
+        const int trow = (TY - 1) * tiles_x, tcol = X >> 7;
+        const uint2 nlo = *reinterpret_cast<const uint2 *>(&f.numtab[2 * (trow + tiles_x + tcol)]), nup = *reinterpret_cast<const uint2 *>(&f.numtab[2 * (trow + tcol)]);
+        auto num_of = [](const uint2 &nb, uint32_t e) -> uint32_t { const uint32_t id = e & 0x7FFFu; return (e & 0x8000u) ? nb.x + id : nb.y - id; };
 #pragma unroll 1
         for (int j = 0; j < FM_GRP; j++) {
             uint32_t a0 = NOJ, b0 = NOJ, b1 = NOJ, b2 = NOJ;
@@ -1046,12 +1051,11 @@ __device__ __forceinline__ void fm_boundaries(const FmFrame &f, int tid, Emit &&
             // (ring entries are tile-local ids: comparable inside one tile column only)
             const bool same = x > 1 && (x & (TW - 1)) != 0 && (x & (TW - 1)) != TW - 1 && pl == p && q0 == q1 && (q2 == q1 || !(p & 0x8000u));
             if (f.acc(p) && !same) {
-                const int trow = (TY - 1) * tiles_x;
-                a0 = f.num(trow + tiles_x + (x >> 7), p);
-                if (q1 != 0xFFFFu && ((q1 ^ p) & 0x8000u) == 0) b0 = f.num(trow + (x >> 7), q1);
+                a0 = num_of(nlo, p);
+                if (q1 != 0xFFFFu && ((q1 ^ p) & 0x8000u) == 0) b0 = num_of(nup, q1);
                 if (p & 0x8000u) { // white
-                    if ((q0 & 0x8000u) && q0 != 0xFFFFu && q0 != q1) b1 = f.num(trow + ((x - 1) >> 7), q0);
-                    if ((q2 & 0x8000u) && q2 != 0xFFFFu && q2 != q1) b2 = f.num(trow + ((x + 1) >> 7), q2);
+                    if ((q0 & 0x8000u) && q0 != 0xFFFFu && q0 != q1) b1 = ((x - 1) >> 7) == tcol ? num_of(nup, q0) : f.num(trow + ((x - 1) >> 7), q0);
+                    if ((q2 & 0x8000u) && q2 != 0xFFFFu && q2 != q1) b2 = ((x + 1) >> 7) == tcol ? num_of(nup, q2) : f.num(trow + ((x + 1) >> 7), q2);
                 }
             }
             emit(a0, b0, a0, b1, a0, b2);
@@ -1078,23 +1082,26 @@ __device__ __forceinline__ void fm_boundaries(const FmFrame &f, int tid, Emit &&
             }
         }
         const int x = txi * TW;                        // >= 1; an origin unless it is the frame's last column
+        const int tp = (Y / TH) * tiles_x + txi;       // tile of (x, y) for the group's eight rows; (x - 1, y) lies in tp - 1
+        const uint2 nrt = *reinterpret_cast<const uint2 *>(&f.numtab[2 * tp]), nlf = *reinterpret_cast<const uint2 *>(&f.numtab[2 * (tp - 1)]);
+        auto num_of = [](const uint2 &nb, uint32_t e) -> uint32_t { const uint32_t id = e & 0x7FFFu; return (e & 0x8000u) ? nb.x + id : nb.y - id; };
 #pragma unroll 1
         for (int j = 0; j < FM_GRP; j++) {
             uint32_t ap = NOJ, aq = NOJ, b0 = NOJ, b1 = NOJ, b2 = NOJ;
             const int y = Y + j;
-            const int tp = (y / TH) * tiles_x + txi;       // tile of (x, y); (x - 1, y) lies in tp - 1
+            const bool up_same = ((y - 1) / TH) == (Y / TH) && y > 0; // the row above lies in the same tile row (all but the group's first row at a tile's top)
             const uint32_t praw = fm_first(P), qraw = fm_first(Q); // (x - 1, y) is always an origin column (1 <= x - 1 <= w - 2); beyond the frame's last row both are 0xFFFF
             uint32_t p = praw, q = qraw;
             if (!f.acc(p)) p = 0xFFFFu;                     // the other colour's pixels: another workgroup's
             if (!f.acc(q)) q = 0xFFFFu;
-            if (p != 0xFFFFu) ap = f.num(tp, p);
-            if (q != 0xFFFFu) aq = f.num(tp - 1, q);
+            if (p != 0xFFFFu) ap = num_of(nrt, p);
+            if (q != 0xFFFFu) aq = num_of(nlf, q);
             if (p != 0xFFFFu && x <= w - 2) {
                 if (q != 0xFFFFu && ((q ^ p) & 0x8000u) == 0) b0 = aq;
-                if ((p & 0x8000u) && y > 0 && (ql & 0x8000u) && ql != 0xFFFFu) b1 = f.num(((y - 1) / TH) * tiles_x + txi - 1, ql); // white: up-left
+                if ((p & 0x8000u) && y > 0 && (ql & 0x8000u) && ql != 0xFFFFu) b1 = up_same ? num_of(nlf, ql) : f.num(((y - 1) / TH) * tiles_x + txi - 1, ql); // white: up-left
             }
             if (q != 0xFFFFu && (q & 0x8000u) && y > 0 && (pu & 0x8000u) && pu != 0xFFFFu)  // white pixel (x - 1, y): up-right is (x, y - 1)
-                b2 = f.num(((y - 1) / TH) * tiles_x + txi, pu);
+                b2 = up_same ? num_of(nrt, pu) : f.num(((y - 1) / TH) * tiles_x + txi, pu);
             emit(ap, b0, ap, b1, aq, b2);
             ql = qraw; pu = praw;
             fm_shift(P); fm_shift(Q);
