@@ -512,13 +512,11 @@ __global__ __launch_bounds__(KNT) __attribute__((amdgpu_num_sgpr(80))) void k_ti
             if (li < (uint32_t)LIST_CAP) list[li] = lk | lcol | (((uint32_t)__popc(Mt & span) + (uint32_t)__popc(Mb & span)) << 16);
             li += lstep;
         }
-        // (c)
-        PairCtx v;
-        v.Mt = Mt; v.S2 = S2; v.Ut = Ut; v.S2u = S2u; v.base = base;
-        v.left = info_l & 0xFFFu; v.up_l = info_ul & 0xFFFu; v.up_r = upbase + 32u + (((info_ur >> 14) & 1u) ? 0u : (uint32_t)TW);
-        v.Ev = Ev & ~F; v.DL = DL & ~F; v.DR = DR & ~(F & ~DL);
-        v.flags = ((link & 1u) ? CK_LINK_HLEFT : 0u) | ((K.DL & 1u) ? CK_LINK_CROSS_L : 0u) | ((K.DR >> 31) ? CK_LINK_CROSS_R : 0u);
-        uint32_t extra = links_left(v);
+        // (c) what is left: the vertical links one loop, the two diagonal kinds one loop each, then the three links that cross a
+        // word boundary (a generic "take the next link" loop cost twice the instructions per link)
+        const uint32_t lEv = Ev & ~F, lDL = DL & ~F, lDR = DR & ~(F & ~DL);
+        const uint32_t fl = ((link & 1u) ? CK_LINK_HLEFT : 0u) | ((K.DL & 1u) ? CK_LINK_CROSS_L : 0u) | ((K.DR >> 31) ? CK_LINK_CROSS_R : 0u);
+        const uint32_t extra = (uint32_t)__popc(lEv) + (uint32_t)__popc(lDL) + (uint32_t)__popc(lDR) + (uint32_t)__popc(fl);
         const uint32_t xincl = wave_scan_u32(extra);
         const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)xincl, 63);
         if (total) {
@@ -526,11 +524,16 @@ __global__ __launch_bounds__(KNT) __attribute__((amdgpu_num_sgpr(80))) void k_ti
             if ((tid & 63) == 63) wb = atomicAdd(&misc[5], total);
             wb = (uint32_t)__builtin_amdgcn_readlane((int)wb, 63);
             uint32_t pos = wb + xincl - extra;
-            for (; extra; extra--, pos++) {
-                uint32_t a_, b_;
-                take_link(v, a_, b_);
-                if (pos < (uint32_t)POOL_CAP) pool[pos] = a_ | (b_ << 16);
-            }
+            // an entry of the node that holds column x of this pair word / of the pair word above
+            auto lower = [&](uint32_t x) -> uint32_t { const uint32_t st = 31u - (uint32_t)__builtin_clz((S2 & ((2u << x) - 1u)) | 1u); return base + st + (((nMt >> st) & 1u) << 7); };
+            auto upper = [&](uint32_t x) -> uint32_t { const uint32_t st = 31u - (uint32_t)__builtin_clz((S2u & ((2u << x) - 1u)) | 1u); return upbase + st + (((nUt >> st) & 1u) << 7); };
+            auto push = [&](uint32_t a_, uint32_t b_) { if (pos < (uint32_t)POOL_CAP) pool[pos] = a_ | (b_ << 16); pos++; };
+            for (uint32_t m = lEv; m; m &= m - 1u) { const uint32_t x = (uint32_t)__builtin_ctz(m); push(lower(x), upper(x)); }
+            for (uint32_t m = lDL; m; m &= m - 1u) { const uint32_t x = (uint32_t)__builtin_ctz(m); push(lower(x), upper(x - 1u)); }
+            for (uint32_t m = lDR; m; m &= m - 1u) { const uint32_t x = (uint32_t)__builtin_ctz(m); push(lower(x), upper(x + 1u)); }
+            if (fl & CK_LINK_HLEFT) push(base + (((nMt >> 0) & 1u) << 7), info_l & 0xFFFu);          // (column 0 of a word always starts a node)
+            if (fl & CK_LINK_CROSS_L) push(base + (((nMt >> 0) & 1u) << 7), info_ul & 0xFFFu);
+            if (fl & CK_LINK_CROSS_R) push(lower(31u), upbase + 32u + (((info_ur >> 14) & 1u) ? 0u : (uint32_t)TW));
         }
     } else if (tid < 3 * 64) {
         int r, xl; uint32_t ec;
