@@ -747,12 +747,15 @@ __global__ __launch_bounds__(KNT) __attribute__((amdgpu_num_sgpr(80))) void k_ti
         };
         uint32_t lw[NPL], elw;
 #pragma unroll
-        for (int k = 0; k < NPL; k++) lw[k] = label_word(keep[k]);
+        for (int k = 0; k < NPL; k++) { // (keep[k] holds list entries k * KNT ..: the rounds past the tile's node count are skipped as a whole)
+            lw[k] = 0;
+            if ((uint32_t)(k * KNT) < nruns) lw[k] = label_word(keep[k]);
+        }
         elw = label_word(ekeep);
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < NPL; k++)
-            if (keep[k] != KEEP_NONE) tab32[keep[k] & 0xFFFu] = lw[k];
+            if ((uint32_t)(k * KNT) < nruns && keep[k] != KEEP_NONE) tab32[keep[k] & 0xFFFu] = lw[k];
         if (ekeep != KEEP_NONE) tab32[ekeep & 0xFFFu] = elw;
         __syncthreads();
     }
