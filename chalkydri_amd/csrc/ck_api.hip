@@ -129,7 +129,7 @@ extern "C" int ck_create(const ck_config_t *cfg, ck_handle_t **out) {
     CK_TRY(ck_malloc_dev(&h->d_frames, h->frame_pitch * nb));
     if (cfg->quad_decimate > 1) CK_TRY(ck_malloc_dev(&h->d_qframes, (size_t)round_up(qw, 16) * qh * nb));
     CK_TRY(ck_malloc_dev(&h->d_thresh, h->npix * nb));
-    CK_TRY(ck_malloc_dev(&h->d_labels, h->npix * nb * sizeof(uint32_t)));
+    CK_TRY(ck_malloc_dev(&h->d_labels, h->npix * nb * sizeof(ck_label_t)));
     CK_TRY(ck_malloc_dev(&h->d_groot, (size_t)h->broot_cap * nb * sizeof(uint32_t)));
     CK_TRY(ck_malloc_dev(&h->d_gsize, (size_t)h->broot_cap * nb * sizeof(uint32_t)));
     CK_TRY(ck_malloc_dev(&h->d_gscratch, 2 * (size_t)h->broot_cap * nb * sizeof(uint32_t)));

@@ -10,22 +10,37 @@
 #include "chalkydri_hip.h"
 
 // ---- label word format (segment stage output; DESIGN.md §Data layout) --------------------------------
-// bits 0..25  pixel index (y*width+x) of the component root the pixel points at, or, with CK_LBL_BORDER, a slot
-// bit  30     CK_LBL_BORDER: the tile-local component touches its tile's outer ring, so it may continue in a
-//             neighbouring tile; bits 0..25 are its SLOT (tile index * CK_RING_CAP + tile-local id) in the frame's
-//             tables: groot[slot] = pixel index of the frame-level root, gsize[slot] = the component's pixel count
-//             (exact while below min_component_px) — two independent reads
-// bit  31     CK_LBL_SMALL : tile-interior component with fewer than min_component_px pixels (final)
-// 0xFFFFFFFF  pixel thresholded to 127 (no component)
-#define CK_LBL_IDX_MASK 0x03FFFFFFu
-#define CK_LBL_BORDER 0x40000000u
-#define CK_LBL_SMALL 0x80000000u
-#define CK_LBL_INVALID 0xFFFFFFFFu
+// 16 bits per pixel, TILE-LOCAL (the consumer knows the pixel's 32 x 128 tile from its coordinates):
+// bit  15     CK_LBL_BORDER: the tile-local component touches its tile's outer ring, so it may continue in a neighbouring tile;
+//             bits 0..8 are its tile-local id, SLOT = tile index * CK_RING_CAP + id in the frame's tables:
+//             groot[slot] = pixel index of the frame-level root, gsize[slot] = the component's pixel count (exact while below
+//             min_component_px) — two independent reads
+// bit  14     CK_LBL_SMALL : tile-interior component with fewer than min_component_px pixels (final)
+// bits 0..11  (neither BORDER nor all ones) tile pixel (row << 7 | column) of the component's root inside the pixel's own tile:
+//             its pixel index in the frame is (tile_y0 + row) * width + tile_x0 + column
+// 0xFFFF      pixel thresholded to 127 (no component)
+// (Round 3: the words were 32 bits with frame-level indices — 4 of the stage's 6 bytes per pixel of HBM traffic.)
+typedef uint16_t ck_label_t;
+#define CK_LBL_BORDER 0x8000u
+#define CK_LBL_SMALL 0x4000u
+#define CK_LBL_LOCAL_MASK 0x0FFFu
+#define CK_LBL_ID_MASK 0x01FFu
+#define CK_LBL_NONE 0xFFFFu
+#define CK_LBL_INVALID 0xFFFFFFFFu /* "no component" in CANONICAL label arrays (32-bit pixel indices: the C ABI's label output) */
 
 // CCL tile geometry (one workgroup per tile)
 #define CK_TW 128
 #define CK_TH 32
 #define CK_RING_CAP (2 * (CK_TW + CK_TH)) /* ring-touching roots a tile can have: one per ring pixel at most */
+
+// frame-level resolution of a label word at pixel (x, y): the root's pixel index for an interior component, CK_LBL_INVALID for none;
+// a ring-touching component (CK_LBL_BORDER) is resolved by the caller through the slot tables (ck_label_slot)
+__host__ __device__ inline uint32_t ck_label_slot(uint32_t l, int x, int y, int ccl_tiles_x) {
+    return (uint32_t)((y / CK_TH) * ccl_tiles_x + x / CK_TW) * (uint32_t)CK_RING_CAP + (l & CK_LBL_ID_MASK);
+}
+__host__ __device__ inline uint32_t ck_label_interior_root(uint32_t l, int x, int y, int w) {
+    return (uint32_t)((y & ~(CK_TH - 1)) + (int)((l >> 7) & (CK_TH - 1))) * (uint32_t)w + (uint32_t)((x & ~(CK_TW - 1)) + (int)(l & (CK_TW - 1)));
+}
 
 struct ck_border_root {
     uint32_t root; // pixel index of a tile-local root whose component touches the tile ring
@@ -139,7 +154,7 @@ struct ck_handle {
     size_t frame_pitch;
     uint8_t *d_qframes;  // decimated copy (== d_frames when quad_decimate == 1)
     uint8_t *d_thresh;   // [n][qh][qw]
-    uint32_t *d_labels;  // [n][qh][qw] label words
+    ck_label_t *d_labels; // [n][qh][qw] label words
     uint32_t *d_groot;   // [n][broot_cap] slot table: frame-level root (pixel index) of every ring-touching tile-local component
     uint32_t *d_gsize;   // [n][broot_cap] slot table: its pixel count (exact while below min_component_px)
     uint32_t *d_gscratch; // [n][2][broot_cap] parents and sizes of k_fmerge's global-memory path

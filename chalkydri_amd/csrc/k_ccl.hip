@@ -253,7 +253,7 @@ __device__ unsigned long long g_tile_prof[16];
 template <bool PRE>
 __global__ __launch_bounds__(KNT) __attribute__((amdgpu_num_sgpr(80))) void k_tile(const uint8_t *__restrict__ frames, size_t frame_pitch, int stride,
                                              int w, int h, int tiles_x, int tiles_y, int frame0, int n_frames, int xcd_map, int min_diff, int min_comp,
-                                             uint8_t *__restrict__ thresh, uint32_t *__restrict__ labels,
+                                             uint8_t *__restrict__ thresh, ck_label_t *__restrict__ labels,
                                              ck_border_root *__restrict__ broots, uint32_t *__restrict__ tile_count,
                                              uint16_t *__restrict__ ring, size_t ring_len, int stop_after, int sweeps) {
     __shared__ __attribute__((aligned(16))) uint8_t lds[LDS_BYTES];
@@ -730,20 +730,17 @@ __global__ __launch_bounds__(KNT) __attribute__((amdgpu_num_sgpr(80))) void k_ti
         if (tile_has_runs && ring_root[rnd] != 0xFFFFFFFFu) val = ((uint32_t)parent[ring_root[rnd]] & 0x1FFu) | (ring_white[rnd] << 15);
         ring_f[dst] = (uint16_t)val;
     }
-    const uint32_t gbase = (uint32_t)ty0 * (uint32_t)w + (uint32_t)tx0;
-    const uint32_t slot0 = CK_LBL_BORDER | ((uint32_t)tile * RING_CAP);
-    const uint32_t w24 = (uint32_t)w & 0xFFFFFFu; // (the compiler then sees two 24-bit factors: a full-rate multiply instead of a 64-bit one)
     if (!tile_has_runs || tabled) {
-    // ---- P6c: the label word of every node, formed once per node from its root's entry (interior component: the root's pixel index,
-    // final; ring-touching: the component's slot in the frame's tables) and, behind a barrier — every read of the union-find is done —
+    // ---- P6c: the label word of every node (16 bits: ck_internal.h), formed once per node from its root's entry (interior component:
+    // the root's tile pixel, final; ring-touching: the component's tile-local id) and, behind a barrier — every read of the union-find is done —
     // written to a table of 32-bit words over the parent and list arrays, indexed by the node's lookup pixel.
     uint32_t *tab32 = reinterpret_cast<uint32_t *>(lds);
     if (tile_has_runs) {
         auto label_word = [&](uint32_t kp) -> uint32_t {
             const uint32_t root = kp >> 16;
             const uint32_t ce = parent[root & (uint32_t)(TH * TW - 1)]; // (KEEP_NONE: a harmless in-range read, the word is not used)
-            return (ce & CK_RING) ? slot0 + (ce & 0x1FFu)
-                                  : ((gbase + (root >> 7) * w24 + (root & (TW - 1))) | ((int)(ce & CK_COUNT) < min_comp ? CK_LBL_SMALL : 0u));
+            return (ce & CK_RING) ? CK_LBL_BORDER | (ce & CK_LBL_ID_MASK)
+                                  : ((root & CK_LBL_LOCAL_MASK) | ((int)(ce & CK_COUNT) < min_comp ? CK_LBL_SMALL : 0u));
         };
         uint32_t lw[NPL], elw;
 #pragma unroll
@@ -759,36 +756,30 @@ __global__ __launch_bounds__(KNT) __attribute__((amdgpu_num_sgpr(80))) void k_ti
         if (ekeep != KEEP_NONE) tab32[ekeep & 0xFFFu] = elw;
         __syncthreads();
     }
-    // ---- P7: write label words.  Two passes; in pass q lane L owns the 4-column group L & 31 of pair q * 8 + (L >> 5): both rows, so
-    // that the search for a column's node (per colour: the nearest node start at or below it, then the row of that node's lookup
-    // pixel) is shared by the column's two pixels; a wave's store instruction covers two stretches of 512 contiguous bytes.  One
-    // table lookup per pixel.
+    // ---- P7: write label words.  Lane L owns the 8-column group L & 15 of pair L >> 4, both rows: the search for a column's node
+    // (per colour: the nearest node start at or below it, then the row of that node's lookup pixel) is shared by the column's two
+    // pixels, ONE table lookup per pixel, and a lane's eight 16-bit words of a row leave in one 16-byte store.
     {
-        const int g = tid & 31, wd = g >> 3, sh = 4 * (g & 7);       // the same for the lane's two passes
-        const int gx = tx0 + 4 * g;
+        const int g = tid & 15, pr = tid >> 4, wd = g >> 2, sh = 8 * (g & 3);
+        const int gx = tx0 + 8 * g, gy = ty0 + 2 * pr;
         const uint32_t Oo = ck_origin32(tx0 + 32 * wd, w);
-        const uint32_t edge4 = (~Oo >> sh) & 15u;     // columns of the group that are non-origin columns of the frame: their pixels are nodes of their own
-        if (gx < w)
-#pragma unroll
-        for (int q = 0; q < 2; q++) {
-            const int pr = q * (KNT / 32) + (tid >> 5);
-            const int gy = ty0 + 2 * pr;
-            if (gy >= h) continue;
+        const uint32_t edge8 = (~Oo >> sh) & 255u;    // columns of the group that are non-origin columns of the frame: their pixels are nodes of their own
+        if (gx < w && gy < h) {
             const uint32_t pbase = (uint32_t)((2 * pr) * TW + 32 * wd), cbase = pbase + (uint32_t)sh;
-            uint32_t outw[2][4];
+            uint32_t outw[2][4]; // two 16-bit words each
 #pragma unroll
-            for (int k = 0; k < 4; k++) outw[0][k] = outw[1][k] = CK_LBL_INVALID;
+            for (int k = 0; k < 4; k++) outw[0][k] = outw[1][k] = 0xFFFFFFFFu;
             if (tile_has_runs) {
                 const uint2 m4 = *reinterpret_cast<const uint2 *>(&mk[((2 * pr) * NWD + wd) * 2]);          // top row: white, black word ...
                 const uint2 b4 = *reinterpret_cast<const uint2 *>(&mk[((2 * pr + 1) * NWD + wd) * 2]);      // ... and the bottom row's
-                const uint32_t any_t = ((m4.x | m4.y) >> sh) & 15u, any_b = ((b4.x | b4.y) >> sh) & 15u;
+                const uint32_t any_t = ((m4.x | m4.y) >> sh) & 255u, any_b = ((b4.x | b4.y) >> sh) & 255u;
                 if (any_t | any_b) {
                     const uint2 s2 = *reinterpret_cast<const uint2 *>(&s2w[(pr * NWD + wd) * 2]);
                     // node starts whose lookup pixel is in the bottom row: the first column has no top pixel
                     const uint32_t lowW = s2.x & ~(m4.x & Oo), lowB = s2.y & ~(m4.y & Oo);
-                    uint32_t at[2][4];
+                    uint32_t at[2][8];
 #pragma unroll
-                    for (int k = 0; k < 4; k++) {
+                    for (int k = 0; k < 8; k++) {
                         const uint32_t upto = (2u << (sh + k)) - 1u;
                         const uint32_t cw = 31u - (uint32_t)__builtin_clz((s2.x & upto) | 1u), cb = 31u - (uint32_t)__builtin_clz((s2.y & upto) | 1u);
                         const uint32_t atw = pbase + cw + (((lowW >> cw) & 1u) << 7), atb = pbase + cb + (((lowB >> cb) & 1u) << 7);
@@ -797,36 +788,38 @@ __global__ __launch_bounds__(KNT) __attribute__((amdgpu_num_sgpr(80))) void k_ti
                         at[0][k] = (atw & wt) | (atb & ~wt);
                         at[1][k] = (atw & wbm) | (atb & ~wbm);
                     }
-                    if (edge4) // (only the lanes at the frame's first and last column)
+                    if (edge8) // (only the lanes at the frame's first and last column)
 #pragma unroll
-                        for (int k = 0; k < 4; k++)
-                            if ((edge4 >> k) & 1u) { at[0][k] = cbase + (uint32_t)k; at[1][k] = cbase + (uint32_t)(TW + k); }
-                    uint32_t lwv[2][4];
+                        for (int k = 0; k < 8; k++)
+                            if ((edge8 >> k) & 1u) { at[0][k] = cbase + (uint32_t)k; at[1][k] = cbase + (uint32_t)(TW + k); }
+                    uint32_t lwv[2][8];
 #pragma unroll
                     for (int r = 0; r < 2; r++)
 #pragma unroll
-                        for (int k = 0; k < 4; k++) lwv[r][k] = tab32[at[r][k]];
+                        for (int k = 0; k < 8; k++) lwv[r][k] = tab32[at[r][k]];
 #pragma unroll
-                    for (int k = 0; k < 4; k++) {
-                        outw[0][k] = ((any_t >> k) & 1u) ? lwv[0][k] : CK_LBL_INVALID;
-                        outw[1][k] = ((any_b >> k) & 1u) ? lwv[1][k] : CK_LBL_INVALID;
+                    for (int k = 0; k < 8; k++) { // (no colour: all ones)
+                        lwv[0][k] = (lwv[0][k] | (0u - (((any_t >> k) & 1u) ^ 1u))) & 0xFFFFu;
+                        lwv[1][k] = (lwv[1][k] | (0u - (((any_b >> k) & 1u) ^ 1u))) & 0xFFFFu;
                     }
+#pragma unroll
+                    for (int r = 0; r < 2; r++)
+#pragma unroll
+                        for (int k = 0; k < 4; k++) outw[r][k] = lwv[r][2 * k] | (lwv[r][2 * k + 1] << 16);
                 }
             }
 #pragma unroll
             for (int r = 0; r < 2; r++) {
                 if (gy + r >= h || stop_after == 98) continue; // (98: diagnostics, everything but the label stores)
-                uint32_t *dst = labels + fbase + (size_t)(gy + r) * w + gx;
-                if (packed_rows) {
-                    // (the empty asm keeps the compiler from merging this store with the per-pixel ones of the other branch: merged, it
-                    // became a 12-byte store plus a 4-byte one)
-                    __asm__ volatile("" ::: "memory");
+                ck_label_t *dst = labels + fbase + (size_t)(gy + r) * w + gx;
+                if ((w & 7) == 0) { // rows of labels[] start 8-pixel aligned: one 16-byte store
+                    __asm__ volatile("" ::: "memory"); // (keeps the compiler from merging this store with the per-pixel ones of the other branch)
                     *reinterpret_cast<uint4 *>(dst) = make_uint4(outw[r][0], outw[r][1], outw[r][2], outw[r][3]);
                     __asm__ volatile("" ::: "memory");
                 } else {
 #pragma unroll
-                    for (int k = 0; k < 4; k++)
-                        if (gx + k < w) dst[k] = outw[r][k];
+                    for (int k = 0; k < 8; k++)
+                        if (gx + k < w) dst[k] = (ck_label_t)(outw[r][k >> 1] >> (16 * (k & 1)));
                 }
             }
         }
@@ -852,7 +845,7 @@ __global__ __launch_bounds__(KNT) __attribute__((amdgpu_num_sgpr(80))) void k_ti
             const uint32_t pbase = (uint32_t)((2 * pr) * TW + 32 * wd), cbase = pbase + (uint32_t)sh;
             uint32_t outw[2][4];
 #pragma unroll
-            for (int k = 0; k < 4; k++) outw[0][k] = outw[1][k] = CK_LBL_INVALID;
+            for (int k = 0; k < 4; k++) outw[0][k] = outw[1][k] = CK_LBL_NONE;
             if (tile_has_runs) {
                 const uint2 m4 = *reinterpret_cast<const uint2 *>(&mk[((2 * pr) * NWD + wd) * 2]);          // top row: white, black word ...
                 const uint2 b4 = *reinterpret_cast<const uint2 *>(&mk[((2 * pr + 1) * NWD + wd) * 2]);      // ... and the bottom row's
@@ -892,26 +885,24 @@ __global__ __launch_bounds__(KNT) __attribute__((amdgpu_num_sgpr(80))) void k_ti
                             const uint32_t ce = is_root ? ev[r][k] : rv[r][k];      // its entry
                             // interior component: the root's pixel index, final; ring-touching: the component's slot in the frame's tables
                             // (as a branch: formed both ways and bit-selected it measured 1.2 % slower)
-                            const uint32_t word = (ce & CK_RING) ? slot0 + (ce & 0x1FFu)
-                                                                 : ((gbase + ((node >> 7) & (uint32_t)(TH - 1)) * w24 + (node & (TW - 1))) | ((int)(ce & CK_COUNT) < min_comp ? CK_LBL_SMALL : 0u));
-                            outw[r][k] = (((col4[r][0] | col4[r][1]) >> k) & 1u) ? word : CK_LBL_INVALID;
+                            const uint32_t word = (ce & CK_RING) ? CK_LBL_BORDER | (ce & CK_LBL_ID_MASK)
+                                                                 : ((node & CK_LBL_LOCAL_MASK) | ((int)(ce & CK_COUNT) < min_comp ? CK_LBL_SMALL : 0u));
+                            outw[r][k] = (((col4[r][0] | col4[r][1]) >> k) & 1u) ? word : CK_LBL_NONE;
                         }
                 }
             }
 #pragma unroll
             for (int r = 0; r < 2; r++) {
                 if (gy + r >= h) continue;
-                uint32_t *dst = labels + fbase + (size_t)(gy + r) * w + gx;
+                ck_label_t *dst = labels + fbase + (size_t)(gy + r) * w + gx;
                 if (packed_rows) {
-                    // (the empty asm keeps the compiler from merging this store with the per-pixel ones of the other branch: merged, it
-                    // became a 12-byte store plus a 4-byte one)
                     __asm__ volatile("" ::: "memory");
-                    *reinterpret_cast<uint4 *>(dst) = make_uint4(outw[r][0], outw[r][1], outw[r][2], outw[r][3]);
+                    *reinterpret_cast<uint2 *>(dst) = make_uint2(outw[r][0] | (outw[r][1] << 16), outw[r][2] | (outw[r][3] << 16));
                     __asm__ volatile("" ::: "memory");
                 } else {
 #pragma unroll
                     for (int k = 0; k < 4; k++)
-                        if (gx + k < w) dst[k] = outw[r][k];
+                        if (gx + k < w) dst[k] = (ck_label_t)outw[r][k];
                 }
             }
         }
@@ -1517,15 +1508,17 @@ namespace {
 #endif
 
 // ---- parity / test path: canonical labels and exact sizes ---------------------------------------------------------------------
-__global__ __launch_bounds__(NT) void k_canon(const uint32_t *__restrict__ labels, const uint32_t *__restrict__ groot, size_t slots,
-                                              uint32_t *__restrict__ out, size_t npix, size_t total) {
+__global__ __launch_bounds__(NT) void k_canon(const ck_label_t *__restrict__ labels, const uint32_t *__restrict__ groot, size_t slots,
+                                              uint32_t *__restrict__ out, size_t npix, size_t total, int w, int tiles_x) {
     size_t i = (size_t)blockIdx.x * NT + threadIdx.x;
     if (i >= total) return;
-    uint32_t l = labels[i];
+    const uint32_t l = labels[i];
     uint32_t g = CK_LBL_INVALID;
-    if (l != CK_LBL_INVALID) {
-        g = l & CK_LBL_IDX_MASK;
-        if (l & CK_LBL_BORDER) g = groot[(i / npix) * slots + g]; // a ring-touching component: the word carries its slot
+    if (l != CK_LBL_NONE) {
+        const size_t fr = i / npix, pi = i - fr * npix;
+        const int y = (int)(pi / (size_t)w), x = (int)(pi - (size_t)y * w);
+        g = (l & CK_LBL_BORDER) ? groot[fr * slots + ck_label_slot(l, x, y, tiles_x)] // a ring-touching component: the word carries its tile-local id
+                                : ck_label_interior_root(l, x, y, w);
     }
     out[i] = g;
 }
@@ -1623,7 +1616,7 @@ int ck_launch_threshold_segment(ck_handle *h, const uint8_t *frames, int stride,
 int ck_launch_canonical_labels(ck_handle *h, int n, uint32_t *d_out, uint32_t *d_sizes) {
     size_t total = h->npix * (size_t)n;
     unsigned blocks = (unsigned)((total + NT - 1) / NT);
-    hipLaunchKernelGGL(k_canon, dim3(blocks), dim3(NT), 0, h->stream, h->d_labels, h->d_groot, (size_t)h->broot_cap, d_out, h->npix, total);
+    hipLaunchKernelGGL(k_canon, dim3(blocks), dim3(NT), 0, h->stream, h->d_labels, h->d_groot, (size_t)h->broot_cap, d_out, h->npix, total, h->qw, h->tiles_x);
     if (d_sizes) {
         // exact sizes by counting: test path only (the pipeline uses the SMALL flag of the label words and the slot tables instead).
         // One exit: the count array is released on every path, and through the handle's allocator (guard pages under CK_POISON=3).

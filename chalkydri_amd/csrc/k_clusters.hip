@@ -30,10 +30,11 @@ __device__ __forceinline__ uint32_t key_hash(unsigned long long k) {
 
 struct EmitArgs {
     const uint8_t *thresh;
-    const uint32_t *labels;
+    const ck_label_t *labels;
     const uint32_t *groot, *gsize; // slot tables of the ring-touching components (k_ccl.hip: k_fmerge)
     size_t slots;
     int w, h, tiles_x, tiles_y, min_comp;
+    int ccl_tiles_x; // tiles per row of the segmentation stage (the label words are local to its 32 x 128 tiles)
     int stop_after; // diagnostics (CK_EMIT_STOP_AFTER): 0 staging only, 1 +count, 2 +reserve; 99 = everything
     ck_stage_ws ws;
 };
@@ -52,7 +53,7 @@ __global__ __launch_bounds__(NT) void k_emit(EmitArgs a) {
     const int w = a.w, h = a.h;
     const size_t npix = (size_t)w * h;
     const uint8_t *T = a.thresh + (size_t)frame * npix;
-    const uint32_t *L = a.labels + (size_t)frame * npix;
+    const ck_label_t *L = a.labels + (size_t)frame * npix;
     const uint32_t *GR = a.groot + (size_t)frame * a.slots, *GS = a.gsize + (size_t)frame * a.slots;
     const ck_stage_ws &ws = a.ws;
     unsigned long long *gkeys = ws.d_ht_keys + (size_t)frame * ws.ht_size;
@@ -65,24 +66,26 @@ __global__ __launch_bounds__(NT) void k_emit(EmitArgs a) {
     {   // staging: every thread's pixels go through the (up to three) dependent loads side by side, so a thread waits for
         // three memory round trips, not three per pixel
         constexpr int SPT = (LH * LW + NT - 1) / NT;
-        uint32_t lab[SPT], hop[SPT], csz[SPT];
+        uint32_t lab[SPT], hop[SPT], csz[SPT], slot[SPT];
         uint8_t tv[SPT];
 #pragma unroll
         for (int q = 0; q < SPT; q++) {
             const int i = tid + q * NT;
             const int ly = i / LW, lx = i - ly * LW;
             const int gy = y0 + ly, gx = x0 - 1 + lx;
-            tv[q] = 127; lab[q] = CK_LBL_INVALID;
+            tv[q] = 127; lab[q] = CK_LBL_NONE; slot[q] = 0;
             if (i < LH * LW && gy < h && gx >= 0 && gx < w) {
                 const uint32_t p = (uint32_t)gy * (uint32_t)w + (uint32_t)gx;
                 tv[q] = T[p]; lab[q] = L[p];
+                slot[q] = ck_label_slot(lab[q], gx, gy, a.ccl_tiles_x);
             }
         }
+        // (a word with CK_LBL_SMALL: an interior component below min_component_px — or no component: CK_LBL_NONE has every bit set)
 #pragma unroll
-        for (int q = 0; q < SPT; q++) { // ring-touching components: the word holds a slot; root and size come from the frame's tables
+        for (int q = 0; q < SPT; q++) { // ring-touching components: the word holds a tile-local id; root and size come from the frame's tables
             const bool two = tv[q] != 127 && !(lab[q] & CK_LBL_SMALL) && (lab[q] & CK_LBL_BORDER);
-            hop[q] = two ? GR[lab[q] & CK_LBL_IDX_MASK] : CK_LBL_INVALID;
-            csz[q] = two ? GS[lab[q] & CK_LBL_IDX_MASK] : 0u;
+            hop[q] = two ? GR[slot[q]] : CK_LBL_INVALID;
+            csz[q] = two ? GS[slot[q]] : 0u;
         }
 #pragma unroll
         for (int q = 0; q < SPT; q++) {
@@ -90,9 +93,9 @@ __global__ __launch_bounds__(NT) void k_emit(EmitArgs a) {
             if (i >= LH * LW) continue;
             const int ly = i / LW, lx = i - ly * LW;
             uint32_t r = SKIP;
-            if (tv[q] != 127 && !(lab[q] & CK_LBL_SMALL)) { // SMALL covers CK_LBL_INVALID too
-                r = lab[q] & CK_LBL_IDX_MASK;
-                if (lab[q] & CK_LBL_BORDER) r = ((int)csz[q] < a.min_comp) ? SKIP : (hop[q] & CK_LBL_IDX_MASK);
+            if (tv[q] != 127 && !(lab[q] & CK_LBL_SMALL)) { // SMALL covers CK_LBL_NONE too
+                if (lab[q] & CK_LBL_BORDER) r = ((int)csz[q] < a.min_comp) ? SKIP : hop[q];
+                else r = ck_label_interior_root(lab[q], x0 - 1 + lx, y0 + ly, w);
             }
             sT[ly][lx] = tv[q];
             sR[ly][lx] = r;
@@ -434,7 +437,7 @@ int ck_launch_clusters(ck_handle *h, int n) {
     EmitArgs a;
     a.thresh = h->d_thresh; a.labels = h->d_labels; a.groot = h->d_groot; a.gsize = h->d_gsize; a.slots = (size_t)h->broot_cap;
     a.w = h->qw; a.h = h->qh; a.tiles_x = (h->qw + ETW - 1) / ETW; a.tiles_y = (h->qh + ETH - 1) / ETH;
-    a.min_comp = h->cfg.min_component_px; a.ws = ws;
+    a.min_comp = h->cfg.min_component_px; a.ws = ws; a.ccl_tiles_x = h->tiles_x;
     { static const int stop_after = getenv("CK_EMIT_STOP_AFTER") ? atoi(getenv("CK_EMIT_STOP_AFTER")) : 99; a.stop_after = stop_after; }
     hipLaunchKernelGGL(k_emit, dim3((unsigned)(a.tiles_x * a.tiles_y * n)), dim3(NT), 0, h->stream, a);
     int min_cluster = h->cfg.min_cluster_pixels < 24 ? 24 : h->cfg.min_cluster_pixels;
