@@ -938,6 +938,7 @@ namespace {
 constexpr int FM_NT = 1024;
 constexpr int FM_CAP = 30000;                 // roots a workgroup's LDS path holds with 16-bit pixel keys beside the parents (twice as many without)
 constexpr int FM_WQ = 384;                    // joins a wave's queue holds (one round of boundary pixels adds at most 192)
+constexpr int FM_WQS = FM_WQ + 8;             // a queue's stride in LDS: entry FM_WQ takes the joins that are none (stores without a branch)
 constexpr uint32_t NOJ = 0xFFFFFFFFu;         // "no join"
 
 struct FmFrame {
@@ -1005,11 +1006,20 @@ __device__ __forceinline__ void fm_edges(const FmFrame &f, int tiles, uint16_t *
     __syncthreads();
 }
 // The loops are kept rolled (one group of eight pixels per lane and round, the eight worked off by a loop): unrolled, the sweep was
-// 140 KB of code, and sixteen waves at sixteen places of it waited for instruction fetches most of the time.
-template <typename Emit>
-__device__ __forceinline__ void fm_boundaries(const FmFrame &f, int tid, Emit &&emit) {
-    const int w = f.w, h = f.h, tiles_x = f.tiles_x;
+// 140 KB of code.  The work on a pixel is written WITHOUT branches — every candidate join is formed and carries a flag: as nested
+// ifs it compiled to a dozen exec-mask save / branch / restore sequences per pixel, and the sweep, sixteen waves walking a serial
+// program, was bound by those scalar round trips (80 of the loop's 190 instructions).
+// emit_q(v0, j0, v1, j1, v2, j2): up to three joins (number | number << 16) with their flags; emit_wide: the global-memory path's
+// form (numbers beyond 16 bits), used when `wide`.
+template <typename EmitQ, typename EmitWide>
+__device__ __forceinline__ void fm_boundaries(const FmFrame &f, int tid, bool wide, EmitQ &&emit_q, EmitWide &&emit_wide) {
+    const int w = f.w, h = f.h, tiles_x = f.tiles_x, tiles_y = f.tiles_y;
     const FmRow8 none = {~0ull, ~0ull};
+    const uint32_t mode = f.mode;
+    auto acc = [mode](uint32_t e) -> bool { return (e != 0xFFFFu) & ((mode == 2u) | ((e >> 15) == mode)); };
+    auto num_of = [](const uint2 &nb, uint32_t e) -> uint32_t { const uint32_t id = e & 0x7FFFu; return (e & 0x8000u) ? nb.x + id : nb.y - id; };
+    auto pick = [](bool c, const uint2 &a_, const uint2 &b_) -> uint2 { return make_uint2(c ? a_.x : b_.x, c ? a_.y : b_.y); };
+    auto tabs = [&f](int t) -> uint2 { return *reinterpret_cast<const uint2 *>(&f.numtab[2 * t]); };
     // horizontal edges: the top row of tile row ty against the bottom row of tile row ty - 1 (up, and for white up-left / up-right)
     const int nh = f.nhs * (TW / FM_GRP);
 #pragma unroll 1
@@ -1031,31 +1041,30 @@ __device__ __forceinline__ void fm_boundaries(const FmFrame &f, int tid, Emit &&
         }
         uint32_t q0 = QL, pl = PL;                     // the entries on the left of the pixel at hand
         uint32_t q1 = fm_first(Q);
-        // the group lies inside one tile column: the numbers of its two tiles' roots start at the same four table entries for all
-        // eight pixels (only a diagonal neighbour at the group's very ends can lie in the next tile column)
+        // the group lies inside one tile column: the numbers of its two tiles' roots start at the same table entries for all eight
+        // pixels; only a diagonal neighbour at the group's very ends can lie in the next tile column (whose entries are loaded, too)
         const int trow = (TY - 1) * tiles_x, tcol = X >> 7;
-        const uint2 nlo = *reinterpret_cast<const uint2 *>(&f.numtab[2 * (trow + tiles_x + tcol)]), nup = *reinterpret_cast<const uint2 *>(&f.numtab[2 * (trow + tcol)]);
-        auto num_of = [](const uint2 &nb, uint32_t e) -> uint32_t { const uint32_t id = e & 0x7FFFu; return (e & 0x8000u) ? nb.x + id : nb.y - id; };
+        const uint2 nlo = tabs(trow + tiles_x + tcol), nup = tabs(trow + tcol);
+        const uint2 nupL = tabs(trow + max(tcol - 1, 0)), nupR = tabs(trow + min(tcol + 1, tiles_x - 1));
 #pragma unroll 1
         for (int j = 0; j < FM_GRP; j++) {
-            uint32_t a0 = NOJ, b0 = NOJ, b1 = NOJ, b2 = NOJ;
             const int x = X + j;
-            const bool origin = x >= 1 && x <= w - 2; // only origin columns join
+            const bool origin = (x >= 1) & (x <= w - 2); // only origin columns join
             const uint32_t praw = fm_first(P), p = origin ? praw : 0xFFFFu;
             const uint32_t q2 = j < FM_GRP - 1 ? fm_second(Q) : QR;
             // the pixel on the left made the same joins when it is the same component over the same component (and, for
             // white, the new diagonal neighbour up-right is that component again): nothing to add
             // (ring entries are tile-local ids: comparable inside one tile column only)
-            const bool same = x > 1 && (x & (TW - 1)) != 0 && (x & (TW - 1)) != TW - 1 && pl == p && q0 == q1 && (q2 == q1 || !(p & 0x8000u));
-            if (f.acc(p) && !same) {
-                a0 = num_of(nlo, p);
-                if (q1 != 0xFFFFu && ((q1 ^ p) & 0x8000u) == 0) b0 = num_of(nup, q1);
-                if (p & 0x8000u) { // white
-                    if ((q0 & 0x8000u) && q0 != 0xFFFFu && q0 != q1) b1 = ((x - 1) >> 7) == tcol ? num_of(nup, q0) : f.num(trow + ((x - 1) >> 7), q0);
-                    if ((q2 & 0x8000u) && q2 != 0xFFFFu && q2 != q1) b2 = ((x + 1) >> 7) == tcol ? num_of(nup, q2) : f.num(trow + ((x + 1) >> 7), q2);
-                }
-            }
-            emit(a0, b0, a0, b1, a0, b2);
+            const bool pw = (p & 0x8000u) != 0;
+            const bool same = (x > 1) & ((x & (TW - 1)) != 0) & ((x & (TW - 1)) != TW - 1) & (pl == p) & (q0 == q1) & ((q2 == q1) | !pw);
+            const bool valid = acc(p) & !same;
+            const bool v0 = valid & (q1 != 0xFFFFu) & (((q1 ^ p) & 0x8000u) == 0);
+            const bool v1 = valid & pw & ((q0 & 0x8000u) != 0) & (q0 != 0xFFFFu) & (q0 != q1);
+            const bool v2 = valid & pw & ((q2 & 0x8000u) != 0) & (q2 != 0xFFFFu) & (q2 != q1);
+            const uint32_t a0 = num_of(nlo, p), b0 = num_of(nup, q1);
+            const uint32_t b1 = num_of(pick(((x - 1) >> 7) == tcol, nup, nupL), q0), b2 = num_of(pick(((x + 1) >> 7) == tcol, nup, nupR), q2);
+            if (wide) emit_wide(v0 ? a0 : NOJ, b0, v1 ? a0 : NOJ, b1, v2 ? a0 : NOJ, b2); // (uniform)
+            else emit_q(v0, a0 | (b0 << 16), v1, a0 | (b1 << 16), v2, a0 | (b2 << 16));
             q0 = q1; q1 = q2; pl = praw;
             fm_shift(P); fm_shift(Q);
         }
@@ -1079,27 +1088,27 @@ __device__ __forceinline__ void fm_boundaries(const FmFrame &f, int tid, Emit &&
             }
         }
         const int x = txi * TW;                        // >= 1; an origin unless it is the frame's last column
-        const int tp = (Y / TH) * tiles_x + txi;       // tile of (x, y) for the group's eight rows; (x - 1, y) lies in tp - 1
-        const uint2 nrt = *reinterpret_cast<const uint2 *>(&f.numtab[2 * tp]), nlf = *reinterpret_cast<const uint2 *>(&f.numtab[2 * (tp - 1)]);
-        auto num_of = [](const uint2 &nb, uint32_t e) -> uint32_t { const uint32_t id = e & 0x7FFFu; return (e & 0x8000u) ? nb.x + id : nb.y - id; };
+        const int trow_i = Y / TH;
+        const int tp = trow_i * tiles_x + txi;         // tile of (x, y) for the group's eight rows; (x - 1, y) lies in tp - 1
+        const int tpu = max(trow_i - 1, 0) * tiles_x + txi; // the tiles above them (the group's first row can be a tile's top row)
+        const uint2 nrt = tabs(tp), nlf = tabs(tp - 1), nrtU = tabs(tpu), nlfU = tabs(tpu - 1);
+        const bool xin = x <= w - 2;
+        (void)tiles_y;
 #pragma unroll 1
         for (int j = 0; j < FM_GRP; j++) {
-            uint32_t ap = NOJ, aq = NOJ, b0 = NOJ, b1 = NOJ, b2 = NOJ;
             const int y = Y + j;
-            const bool up_same = ((y - 1) / TH) == (Y / TH) && y > 0; // the row above lies in the same tile row (all but the group's first row at a tile's top)
+            const bool ypos = y > 0;
+            const bool up_same = ((y - 1) / TH) == trow_i; // the row above lies in the same tile row (all but the group's first row at a tile's top)
             const uint32_t praw = fm_first(P), qraw = fm_first(Q); // (x - 1, y) is always an origin column (1 <= x - 1 <= w - 2); beyond the frame's last row both are 0xFFFF
-            uint32_t p = praw, q = qraw;
-            if (!f.acc(p)) p = 0xFFFFu;                     // the other colour's pixels: another workgroup's
-            if (!f.acc(q)) q = 0xFFFFu;
-            if (p != 0xFFFFu) ap = num_of(nrt, p);
-            if (q != 0xFFFFu) aq = num_of(nlf, q);
-            if (p != 0xFFFFu && x <= w - 2) {
-                if (q != 0xFFFFu && ((q ^ p) & 0x8000u) == 0) b0 = aq;
-                if ((p & 0x8000u) && y > 0 && (ql & 0x8000u) && ql != 0xFFFFu) b1 = up_same ? num_of(nlf, ql) : f.num(((y - 1) / TH) * tiles_x + txi - 1, ql); // white: up-left
-            }
-            if (q != 0xFFFFu && (q & 0x8000u) && y > 0 && (pu & 0x8000u) && pu != 0xFFFFu)  // white pixel (x - 1, y): up-right is (x, y - 1)
-                b2 = up_same ? num_of(nrt, pu) : f.num(((y - 1) / TH) * tiles_x + txi, pu);
-            emit(ap, b0, ap, b1, aq, b2);
+            const bool p_ok = acc(praw), q_ok = acc(qraw);      // (the other colour's pixels: another workgroup's)
+            const uint32_t ap = num_of(nrt, praw), aq = num_of(nlf, qraw);
+            const bool pin = p_ok & xin;
+            const bool v0 = pin & q_ok & (((qraw ^ praw) & 0x8000u) == 0);
+            const bool v1 = pin & ((praw & 0x8000u) != 0) & ypos & ((ql & 0x8000u) != 0) & (ql != 0xFFFFu);          // white: up-left
+            const bool v2 = q_ok & ((qraw & 0x8000u) != 0) & ypos & ((pu & 0x8000u) != 0) & (pu != 0xFFFFu);        // white pixel (x - 1, y): up-right is (x, y - 1)
+            const uint32_t b1 = num_of(pick(up_same, nlf, nlfU), ql), b2 = num_of(pick(up_same, nrt, nrtU), pu);
+            if (wide) emit_wide(v0 ? ap : NOJ, aq, v1 ? ap : NOJ, b1, v2 ? aq : NOJ, b2); // (uniform)
+            else emit_q(v0, ap | (aq << 16), v1, ap | (b1 << 16), v2, aq | (b2 << 16));
             ql = qraw; pu = praw;
             fm_shift(P); fm_shift(Q);
         }
@@ -1257,7 +1266,7 @@ __global__ __launch_bounds__(FM_NT, 4) __attribute__((amdgpu_num_sgpr(80))) void
     uint16_t *size16 = parent + lds_cap;                                   // (lds_cap is even)
     uint32_t *base = reinterpret_cast<uint32_t *>(size16 + lds_cap);
     uint32_t *queue = base + ((tiles + 1 + 3) & ~3);                       // per wave: joins waiting to be worked off
-    uint16_t *boff = reinterpret_cast<uint16_t *>(queue + (FM_NT / 64) * FM_WQ);
+    uint16_t *boff = reinterpret_cast<uint16_t *>(queue + (FM_NT / 64) * FM_WQS);
     uint16_t *hseg = boff + ((tiles + 7) & ~7), *vseg = hseg + ((tiles + 7) & ~7);
     uint32_t *numtab = reinterpret_cast<uint32_t *>(vseg + ((tiles + 7) & ~7));
     const size_t slots = (size_t)tiles * RING_CAP;
@@ -1384,7 +1393,7 @@ __global__ __launch_bounds__(FM_NT, 4) __attribute__((amdgpu_num_sgpr(80))) void
     // Every boundary pixel yields up to three joins; most lanes have fewer, and a join is a chain of dependent LDS reads.  So the
     // joins of a wave are queued in LDS (wave prefix sums) and then worked off one per lane, all lanes busy, instead of every
     // lane running its own zero to three joins while the others wait.
-    uint32_t *wq = queue + (tid >> 6) * FM_WQ;
+    uint32_t *wq = queue + (tid >> 6) * FM_WQS;
     const int lane = tid & 63;
     uint32_t qn = 0; // joins waiting in the wave's queue (wave-uniform)
     auto drain = [&]() {
@@ -1399,20 +1408,21 @@ __global__ __launch_bounds__(FM_NT, 4) __attribute__((amdgpu_num_sgpr(80))) void
         __builtin_amdgcn_wave_barrier();
         qn = 0;
     };
-    fm_boundaries(f, tid, [&](uint32_t a0, uint32_t b0, uint32_t a1, uint32_t b1, uint32_t a2, uint32_t b2) {
-        if (gmode) { gm_union(sc, br, a0, b0); gm_union(sc, br, a1, b1); gm_union(sc, br, a2, b2); return; } // (uniform)
-        if (stop_after == 22) return; // (diagnostics: the sweep without its queueing)
-        const bool live = f.diag != 2;
-        const bool v0 = live && a0 != NOJ && b0 != NOJ, v1 = live && a1 != NOJ && b1 != NOJ, v2 = live && a2 != NOJ && b2 != NOJ;
-        const uint32_t cnt = (uint32_t)v0 + (uint32_t)v1 + (uint32_t)v2;
-        const uint32_t incl = wave_scan_u32(cnt);
-        uint32_t pos = qn + incl - cnt;
-        if (v0) wq[pos++] = a0 | (b0 << 16);
-        if (v1) wq[pos++] = a1 | (b1 << 16);
-        if (v2) wq[pos++] = a2 | (b2 << 16);
-        qn += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-        if (qn > FM_WQ - 192) drain();
-    });
+    fm_boundaries(f, tid, gmode,
+        [&](bool v0, uint32_t j0, bool v1, uint32_t j1, bool v2, uint32_t j2) {
+            // into the wave's queue without a branch: a join that is not one goes to the queue's spare slot
+            const bool live = (f.diag != 2) & (stop_after != 22);
+            v0 &= live; v1 &= live; v2 &= live;
+            const uint32_t cnt = (uint32_t)v0 + (uint32_t)v1 + (uint32_t)v2;
+            const uint32_t incl = wave_scan_u32(cnt);
+            const uint32_t pos = qn + incl - cnt;
+            wq[v0 ? pos : (uint32_t)FM_WQ] = j0;
+            wq[v1 ? pos + (uint32_t)v0 : (uint32_t)FM_WQ] = j1;
+            wq[v2 ? pos + (uint32_t)v0 + (uint32_t)v1 : (uint32_t)FM_WQ] = j2;
+            qn += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+            if (qn > FM_WQ - 192) drain();
+        },
+        [&](uint32_t a0, uint32_t b0, uint32_t a1, uint32_t b1, uint32_t a2, uint32_t b2) { gm_union(sc, br, a0, b0); gm_union(sc, br, a1, b1); gm_union(sc, br, a2, b2); });
     FPROF(3);
     if (gmode) { fm_global_end(f, br, n, sc, gsz, groot, gsize, tiles); return; }
     drain();
@@ -1571,7 +1581,7 @@ int ck_launch_threshold_segment(ck_handle *h, const uint8_t *frames, int stride,
     cap = cap < 4096 ? 4096 : (cap > FM_CAP ? FM_CAP : cap);
     if (cap_env && atoi(cap_env) < cap) cap = atoi(cap_env);
     // (the per-tile arrays and the join queues come first: very large frames leave less room for roots)
-    const size_t fixed = (size_t)((tiles + 1 + 3) & ~3) * 4 + (size_t)(FM_NT / 64) * FM_WQ * 4 + (size_t)((tiles + 7) & ~7) * 2 * 3 + (size_t)tiles * 8;
+    const size_t fixed = (size_t)((tiles + 1 + 3) & ~3) * 4 + (size_t)(FM_NT / 64) * FM_WQS * 4 + (size_t)((tiles + 7) & ~7) * 2 * 3 + (size_t)tiles * 8;
     const size_t lds_max = 160 * 1024 - 512;
     if ((size_t)cap * 4 + fixed > lds_max) cap = (int)((lds_max - fixed) / 4);
     cap &= ~1;
