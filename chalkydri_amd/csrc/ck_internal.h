@@ -60,6 +60,14 @@ struct ck_dev_family {
 // 6: 513..1024, 7: <= 256 (the two youngest classes took the free indices: a cluster's cost is mostly per cluster, not per
 // point, so the small ones run on small workgroups, many per CU)
 constexpr int CK_FIT_CLASSES = 8;
+constexpr int CK_FIT_LISTS = 9;    // work lists: one per size class + (index 8) every cluster of the batch, which the tail kernel of the split fit walks
+// The split quad fit (k_quads.hip: k_fit<..., SPLIT> -> k_chunk -> k_tail) passes a cluster's sorted, de-duplicated points on as an
+// EXTENDED sequence: its last CK_EXT_PRE points, the points, its first CK_EXT_POST points again — so that the windowed line-fit
+// error, its smoothing and the maxima test of every point read neighbours at plain offsets and a kernel can stream over all
+// clusters of a frame without knowing where one ends.  Cluster ci of a frame owns the positions
+// [start + CK_EXT_HALO * ci, + count + CK_EXT_HALO) of the frame's sequence (start/count: its record; counts shrink with the duplicates).
+constexpr int CK_EXT_PRE = 25, CK_EXT_POST = 24, CK_EXT_HALO = CK_EXT_PRE + CK_EXT_POST;
+constexpr int CK_SPAN = 960;       // positions one k_chunk workgroup decides (15 words of 64), CK_SPAN / 2 = most maxima it can find
 constexpr int CK_HUGE_CAP = 65536, CK_HUGE_WGS = 256; // largest class: points per cluster (3 * 4 * 4095 < 65536), workgroups in its grid
 constexpr int CK_FIT_PARALLEL_MAX_FRAMES = 16; // calls with at most this many frames (twice as many at quad_decimate >= 2) run the classes side by side
 constexpr int CK_SEG_CHUNKS_MAX = 8;           // pieces a batch's threshold + segmentation is cut into at most
@@ -95,8 +103,19 @@ struct ck_stage_ws {
     unsigned long long *d_ht_keys; // [n][ht_size]  (rep0<<32 | rep1), 0 = empty
     uint32_t *d_ht_count;      // [n][ht_size]
     uint32_t *d_ht_off;        // [n][ht_size] start of the cluster in d_points (k_scatter advances it as it fills), or 0xFFFFFFFF
-    ck_packed_point *d_tmp;    // [n][point_cap] points in emission order (runs)
-    ck_packed_point *d_points; // [n][point_cap] points grouped by cluster
+    ck_packed_point *d_tmp;    // [n][ext_cap] (point_cap used) points in emission order (runs)
+    ck_packed_point *d_points; // [n][ext_cap] (point_cap used) points grouped by cluster
+    // split quad fit: extended point sequences and what k_chunk leaves for k_tail.  d_tmp and d_points are dead by then and carry
+    // the two largest arrays (same frame pitch, so a frame's bytes never overlap another frame's)
+    int ext_cap;               // positions per frame: point_cap + CK_EXT_HALO * cluster_cap, rounded up to a multiple of CK_SPAN; the frame pitch of d_tmp / d_points
+    uint32_t *d_ext_xy;        // = d_tmp: [n][ext_cap] x << 13 | y (half-pixel) | window half-width << 26
+    uint16_t *d_ext_w;         // [n][ext_cap] gradient weight
+    double *d_maxval;          // = d_points: [n][ext_cap / CK_SPAN][CK_SPAN / 2] smoothed errors at the maxima of a span, in position order
+    uint16_t *d_maxpos;        // same shape: the maximum's position inside its span
+    unsigned long long *d_maxmask; // [n][ext_cap / 64] bit = position is a maximum
+    uint16_t *d_maxpre;        // [n][ext_cap / 64] maxima of the span before this word
+    long long *d_blk;          // [n][ext_cap / 32][6] moment sums of every aligned block of 32 positions (Mx, My, Mxx, Mxy, Myy, W)
+    uint32_t *d_cstate;        // [n][cluster_cap] points left after duplicate removal | reversed border << 31; 0: rejected before the fit
     ck_run *d_runs;            // [n][run_cap]
     int run_cap;
     unsigned long long *d_lscratch; // [CK_LSCRATCH_WGS][CK_LSCRATCH_PER_WG]: sort scratch / maxima list of the large fit class, per workgroup
@@ -242,8 +261,8 @@ int ck_process_frames(ck_handle *h, const uint8_t *frames, int stride, size_t pi
 int ck_run_pose(ck_handle *h, int n, const ck_process_params_t *pp, const double *gyro, const uint8_t *has_gyro,
                 ck_vision_measurement_t *out, int32_t *valid, bool upload_field = true, bool sync = true);
 
-// Layout of the fit scratch (ck_stage_ws::d_fit_scratch): [CK_FIT_CLASSES][list_cap] work-list entries, 8 list counts,
-// 8 dequeue heads, then (256-byte aligned) the decode candidates' per-frame counts and the candidates themselves.
+// Layout of the fit scratch (ck_stage_ws::d_fit_scratch): [CK_FIT_LISTS][list_cap] work-list entries, 16 list counts,
+// 16 dequeue heads, then (256-byte aligned) the decode candidates' per-frame counts and the candidates themselves.
 struct ck_fit_layout {
     int list_cap;
     uint32_t *lists, *list_counts, *heads, *cand_count;
@@ -253,9 +272,9 @@ static inline ck_fit_layout ck_fit_scratch_layout(const ck_stage_ws &ws, int max
     ck_fit_layout L;
     L.list_cap = ws.cluster_cap * max_batch;
     L.lists = reinterpret_cast<uint32_t *>(ws.d_fit_scratch);
-    L.list_counts = L.lists + (size_t)CK_FIT_CLASSES * L.list_cap;
-    L.heads = L.list_counts + 8;
-    const size_t list_bytes = ((size_t)CK_FIT_CLASSES * L.list_cap + 16) * sizeof(uint32_t);
+    L.list_counts = L.lists + (size_t)CK_FIT_LISTS * L.list_cap;
+    L.heads = L.list_counts + 16;
+    const size_t list_bytes = ((size_t)CK_FIT_LISTS * L.list_cap + 32) * sizeof(uint32_t);
     uint8_t *base = reinterpret_cast<uint8_t *>(ws.d_fit_scratch) + ((list_bytes + 255) / 256) * 256;
     L.cand_count = reinterpret_cast<uint32_t *>(base);
     L.cands = reinterpret_cast<ck_detection_t *>(base + (((size_t)max_batch * 4 + 255) / 256) * 256);

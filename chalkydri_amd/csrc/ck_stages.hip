@@ -38,8 +38,21 @@ int ck_stage_alloc(ck_handle *h) {
     CK_ALLOC(ck_malloc_dev(&ws.d_ht_keys, sizeof(unsigned long long) * (size_t)ws.ht_size * nb));
     CK_ALLOC(ck_malloc_dev(&ws.d_ht_count, sizeof(uint32_t) * (size_t)ws.ht_size * nb));
     CK_ALLOC(ck_malloc_dev(&ws.d_ht_off, sizeof(uint32_t) * (size_t)ws.ht_size * nb));
-    CK_ALLOC(ck_malloc_dev(&ws.d_tmp, sizeof(ck_packed_point) * (size_t)ws.point_cap * nb));
-    CK_ALLOC(ck_malloc_dev(&ws.d_points, sizeof(ck_packed_point) * (size_t)ws.point_cap * nb));
+    {   // frame pitch of the point arrays = positions of the split fit's extended sequences (ck_internal.h)
+        const size_t e = (size_t)ws.point_cap + (size_t)CK_EXT_HALO * ws.cluster_cap;
+        const size_t r = (e + CK_SPAN - 1) / CK_SPAN * CK_SPAN;
+        if (r > 0x7FFFFFFFu - 4096) return CK_EINVAL;
+        ws.ext_cap = (int)r;
+    }
+    CK_ALLOC(ck_malloc_dev(&ws.d_tmp, sizeof(ck_packed_point) * (size_t)ws.ext_cap * nb));
+    CK_ALLOC(ck_malloc_dev(&ws.d_points, sizeof(ck_packed_point) * (size_t)ws.ext_cap * nb));
+    ws.d_ext_xy = ws.d_tmp; ws.d_maxval = reinterpret_cast<double *>(ws.d_points);
+    CK_ALLOC(ck_malloc_dev(&ws.d_ext_w, sizeof(uint16_t) * (size_t)ws.ext_cap * nb));
+    CK_ALLOC(ck_malloc_dev(&ws.d_maxpos, sizeof(uint16_t) * (size_t)(ws.ext_cap / 2) * nb));
+    CK_ALLOC(ck_malloc_dev(&ws.d_maxmask, sizeof(unsigned long long) * (size_t)(ws.ext_cap / 64) * nb));
+    CK_ALLOC(ck_malloc_dev(&ws.d_maxpre, sizeof(uint16_t) * (size_t)(ws.ext_cap / 64) * nb));
+    CK_ALLOC(ck_malloc_dev(&ws.d_blk, sizeof(long long) * 6 * (size_t)(ws.ext_cap / 32) * nb));
+    CK_ALLOC(ck_malloc_dev(&ws.d_cstate, sizeof(uint32_t) * (size_t)ws.cluster_cap * nb));
     ws.run_cap = 4 * ws.cluster_cap;
     CK_ALLOC(ck_malloc_dev(&ws.d_runs, sizeof(ck_run) * (size_t)ws.run_cap * nb));
     CK_ALLOC(ck_malloc_dev(&ws.d_lscratch, 2 * sizeof(unsigned long long) * (size_t)CK_LSCRATCH_PER_WG * CK_LSCRATCH_WGS));
@@ -53,7 +66,7 @@ int ck_stage_alloc(ck_handle *h) {
     CK_ALLOC(ck_malloc_dev(&ws.d_quads, sizeof(ck_quad_t) * (size_t)ws.quad_cap * nb));
     CK_ALLOC(ck_malloc_dev(&ws.d_dets, sizeof(ck_detection_t) * (size_t)ws.det_cap * nb));
     // fit scratch: one work list per size class + counters, then the decode candidates
-    size_t list_bytes = ((size_t)CK_FIT_CLASSES * ws.cluster_cap * nb + 16) * sizeof(uint32_t);
+    size_t list_bytes = ((size_t)CK_FIT_LISTS * ws.cluster_cap * nb + 32) * sizeof(uint32_t);
     size_t cand_bytes = 256 + ((nb * 4 + 255) / 256) * 256 + sizeof(ck_detection_t) * (size_t)ws.quad_cap * cfg.n_families * nb;
     ws.fit_scratch_bytes = ((list_bytes + 255) / 256) * 256 + cand_bytes;
     CK_ALLOC(ck_malloc_dev(&ws.d_fit_scratch, 2 * ws.fit_scratch_bytes)); // second copy: the half-batch that runs on stream2
@@ -98,6 +111,8 @@ void ck_stage_free(ck_handle *h) {
         (void)ck_free_dev(h->d_fams);
     }
     (void)ck_free_dev(ws.d_ht_keys); (void)ck_free_dev(ws.d_ht_count); (void)ck_free_dev(ws.d_ht_off); (void)ck_free_dev(ws.d_tmp);
+    (void)ck_free_dev(ws.d_ext_w); (void)ck_free_dev(ws.d_maxpos); (void)ck_free_dev(ws.d_maxmask); (void)ck_free_dev(ws.d_maxpre); (void)ck_free_dev(ws.d_blk);
+    (void)ck_free_dev(ws.d_cstate);
     (void)ck_free_dev(ws.d_points); (void)ck_free_dev(ws.d_runs); (void)ck_free_dev(ws.d_lscratch); (void)ck_free_dev(ws.d_hscratch); (void)ck_free_dev(ws.d_clusters); (void)ck_free_dev(ws.d_counters); (void)ck_free_dev(ws.d_quads);
     (void)ck_free_dev(ws.d_dets); (void)ck_free_dev(ws.d_fit_scratch); (void)ck_free_dev(ws.d_wimg);
     (void)ck_free_dev(ws.d_field); (void)ck_free_dev(ws.d_gyro); (void)ck_free_dev(ws.d_has_gyro); (void)ck_free_dev(ws.d_problems);
@@ -129,7 +144,10 @@ static ck_handle make_view(const ck_handle *h, int f0, bool second_stream = true
     v.d_groot += f * h->broot_cap; v.d_gsize += f * h->broot_cap; v.d_gscratch += f * 2 * h->broot_cap;
     v.d_broots += f * 2 * h->broot_cap; v.d_tile_count += f * (size_t)(h->tiles_x * h->tiles_y); v.d_ring += f * h->ring_len;
     w.d_ht_keys += f * w.ht_size; w.d_ht_count += f * w.ht_size; w.d_ht_off += f * w.ht_size;
-    w.d_tmp += f * w.point_cap; w.d_points += f * w.point_cap; w.d_runs += f * w.run_cap;
+    w.d_tmp += f * w.ext_cap; w.d_points += f * w.ext_cap; w.d_runs += f * w.run_cap;
+    w.d_ext_xy += f * w.ext_cap; w.d_ext_w += f * w.ext_cap; w.d_maxval += f * (size_t)(w.ext_cap / 2); w.d_maxpos += f * (size_t)(w.ext_cap / 2);
+    w.d_maxmask += f * (size_t)(w.ext_cap / 64); w.d_maxpre += f * (size_t)(w.ext_cap / 64); w.d_blk += f * 6 * (size_t)(w.ext_cap / 32);
+    w.d_cstate += f * w.cluster_cap;
     if (second_stream) w.d_lscratch += (size_t)CK_LSCRATCH_PER_WG * CK_LSCRATCH_WGS;
     if (second_stream && w.d_hscratch) w.d_hscratch += 2 * (size_t)w.hcap * CK_HUGE_WGS;
     w.d_clusters += f * w.cluster_cap; w.d_counters += f * CK_CNT_STRIDE; w.d_quads += f * w.quad_cap; w.d_dets += f * w.det_cap;
@@ -304,7 +322,7 @@ extern "C" int ck_clusters_batch(ck_handle_t *h, const ck_image_u8_t *imgs, int3
         if ((int)nc > cluster_cap || (int)np > point_cap) return CK_ECAPACITY;
         CK_HIP(hipMemcpy(clusters + (size_t)i * cluster_cap, ws.d_clusters + (size_t)i * ws.cluster_cap, sizeof(ck_cluster_t) * nc, hipMemcpyDeviceToHost));
         std::vector<ck_packed_point> packed(np);
-        CK_HIP(hipMemcpy(packed.data(), ws.d_points + (size_t)i * ws.point_cap, sizeof(ck_packed_point) * np, hipMemcpyDeviceToHost));
+        CK_HIP(hipMemcpy(packed.data(), ws.d_points + (size_t)i * ws.ext_cap, sizeof(ck_packed_point) * np, hipMemcpyDeviceToHost));
         for (uint32_t k = 0; k < np; k++) points[(size_t)i * point_cap + k] = ck_unpack_point(packed[k]);
         n_clusters[i] = (int32_t)nc; n_points[i] = (int32_t)np;
     }

@@ -59,7 +59,7 @@ __global__ __launch_bounds__(NT) void k_emit(EmitArgs a) {
     unsigned long long *gkeys = ws.d_ht_keys + (size_t)frame * ws.ht_size;
     uint32_t *gcount = ws.d_ht_count + (size_t)frame * ws.ht_size;
     uint32_t *counters = ws.d_counters + (size_t)frame * CK_CNT_STRIDE;
-    ck_packed_point *tmp = ws.d_tmp + (size_t)frame * ws.point_cap;
+    ck_packed_point *tmp = ws.d_tmp + (size_t)frame * ws.ext_cap;
     ck_run *runs = ws.d_runs + (size_t)frame * ws.run_cap;
 
     for (int i = tid; i < LHT; i += NT) { sKey[i] = 0ull; sCnt[i] = 0; }
@@ -352,10 +352,10 @@ __global__ __launch_bounds__(NT) void k_scatter(ck_stage_ws ws) {
     const uint32_t *counters = ws.d_counters + (size_t)frame * CK_CNT_STRIDE;
     const uint32_t nruns = min(counters[CK_CNT_RUNS], (uint32_t)ws.run_cap);
     const uint32_t ntmp = min(counters[CK_CNT_TMP], (uint32_t)ws.point_cap);
-    const ck_packed_point *tmp = ws.d_tmp + (size_t)frame * ws.point_cap;
+    const ck_packed_point *tmp = ws.d_tmp + (size_t)frame * ws.ext_cap;
     const ck_run *runs = ws.d_runs + (size_t)frame * ws.run_cap;
     uint32_t *goff = ws.d_ht_off + (size_t)frame * ws.ht_size;
-    ck_packed_point *pts = ws.d_points + (size_t)frame * ws.point_cap;
+    ck_packed_point *pts = ws.d_points + (size_t)frame * ws.ext_cap;
     const int lane = threadIdx.x & 63;
     const uint32_t wave = blockIdx.x * (NT / 64) + (threadIdx.x >> 6), nwaves = gridDim.x * (NT / 64);
     // 64 runs per wave and round: every lane fetches one run record and its cluster offset (two dependent loads paid once
@@ -432,7 +432,7 @@ int ck_launch_clusters(ck_handle *h, int n) {
         const size_t total4 = nkeys4 + ncnt4;
         hipLaunchKernelGGL(k_clear, dim3((unsigned)((total4 + NT - 1) / NT)), dim3(NT), 0, h->stream,
                            reinterpret_cast<uint4 *>(ws.d_ht_keys), nkeys4, reinterpret_cast<uint4 *>(ws.d_ht_count), ncnt4, ws.d_counters,
-                           (uint32_t)(CK_CNT_STRIDE * n), fl.list_counts, 16u, fl.cand_count, (uint32_t)n);
+                           (uint32_t)(CK_CNT_STRIDE * n), fl.list_counts, 32u, fl.cand_count, (uint32_t)n);
     }
     EmitArgs a;
     a.thresh = h->d_thresh; a.labels = h->d_labels; a.groot = h->d_groot; a.gsize = h->d_gsize; a.slots = (size_t)h->broot_cap;

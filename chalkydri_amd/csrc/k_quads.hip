@@ -534,7 +534,9 @@ __device__ __forceinline__ long long keys_bucket_sort_global(unsigned long long 
 
 // NTH threads per cluster, up to CAP points, chunks of CH points; MLDS: the maxima list fits in LDS; GK: the per-point arrays
 // (keys, then coordinates and weights) live in a per-workgroup slice of global memory instead of LDS (the largest class)
-template <int NTH, int CAP, int CH, bool MLDS, int WPS, bool GK = false>
+// SPLIT: the kernel ends after the weights and leaves the cluster's EXTENDED point sequence (ck_internal.h) and its state word for
+// k_chunk and k_tail; the per-point arrays of the later phases are then never used (the compiler drops them)
+template <int NTH, int CAP, int CH, bool MLDS, int WPS, bool GK = false, bool SPLIT = false>
 __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(WPS, 8))) void k_fit(FitArgs a) {
     using B = Block<NTH>;
     constexpr int SL = CH + 2 * HALO;
@@ -618,7 +620,7 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(WPS, 8))) v
         const uint32_t item = a.list[work];
         const int frame = (int)(item >> 20), ci = (int)(item & 0xFFFFFu);
         const ck_cluster_t cl = ws.d_clusters[(size_t)frame * ws.cluster_cap + ci];
-        const ck_packed_point *pts = ws.d_points + (size_t)frame * ws.point_cap + cl.start;
+        const ck_packed_point *pts = ws.d_points + (size_t)frame * ws.ext_cap + cl.start;
         // 8 bytes per point for the large class (sort scratch, then the maxima list): one fixed region per workgroup, so
         // the same few hundred KB are reused cluster after cluster and stay in L2
         unsigned long long *scratch8 = GK ? ws.d_hscratch + (size_t)blockIdx.x * 2 * capr + capr : ws.d_lscratch + (size_t)blockIdx.x * CK_LSCRATCH_PER_WG;
@@ -628,6 +630,8 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(WPS, 8))) v
         if (sz0 > CAP) continue; // cannot happen: the class lists are built from the counts
         PROF_DECL;
         PROF(15);
+        uint32_t *cstate = ws.d_cstate + (size_t)frame * ws.cluster_cap + ci;
+        if (SPLIT && tid == 0) *cstate = 0u; // rejected unless the end of the kernel says otherwise (same thread: ordered)
 
         if (a.stop_after == 0) continue;
         // ---- 1. bounding box + border direction ----------------------------------------------------------
@@ -756,6 +760,22 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(WPS, 8))) v
                     sW[i] = (ix >= 0 && ix < a.qw && iy >= 0 && iy < a.qh) ? wq[(size_t)iy * a.qw + ix] : (uint16_t)1;
                 }
             }
+        }
+        if constexpr (SPLIT) {
+            __syncthreads(); // weights written by other threads
+            const size_t es = (size_t)frame * ws.ext_cap + cl.start + (size_t)CK_EXT_HALO * ci;
+            uint32_t *exy = ws.d_ext_xy + es;
+            uint16_t *ew = ws.d_ext_w + es;
+            for (int k = tid; k < sz + CK_EXT_HALO; k += NTH) {
+                int src = k - CK_EXT_PRE;              // sz >= 24: at most two steps bring it into [0, sz)
+                if (src < 0) src += sz;
+                if (src < 0) src += sz;
+                if (src >= sz) src -= sz;
+                exy[k] = sXY[src] | ((uint32_t)ksz << 26);
+                ew[k] = sW[src];
+            }
+            if (tid == 0) *cstate = (uint32_t)sz | (reversed ? 0x80000000u : 0u);
+            continue;
         }
         // the cluster's slice of the 8-byte scratch is free again (the sort is done); the large class keeps its maxima there
         double *gval = reinterpret_cast<double *>(scratch8);
@@ -1258,6 +1278,668 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(WPS, 8))) v
     }
 }
 
+// ---- split fit, middle kernel: windowed line-fit error, smoothing and maxima of EVERY position of a frame's extended sequences --------
+// One workgroup decides CK_SPAN = 960 consecutive positions (15 words of 64) from 1024 loaded ones; it knows nothing about clusters:
+// a cluster's extended sequence carries its own neighbours (ck_internal.h), the window half-width travels in the point word, and
+// what it finds is filed by POSITION — a bit per position, the smoothed errors of a span's maxima side by side in position
+// order, moment sums of every aligned block of 32 positions — so k_tail picks its cluster's share with a few popcounts.  Positions
+// nobody wrote (rejected clusters, the room duplicates left) compute garbage that nobody reads.  All sums are exact integers,
+// the doubles are formed by the operations of k_fit's chunk loop in the same order: the same bits.
+constexpr int KL = 1024, KOFF = 32;
+static_assert(CK_SPAN == 960 && KOFF >= CK_EXT_PRE + 3 && KL - KOFF - CK_SPAN >= CK_EXT_POST + 4, "span geometry");
+__global__ __launch_bounds__(256) void k_chunk(ck_stage_ws ws) {
+    __shared__ __attribute__((aligned(16))) unsigned long long sP64[3][KL]; // inclusive sums from the first loaded position: Mxx, Mxy, Myy
+    __shared__ __attribute__((aligned(16))) uint32_t sP32[3][KL];           // Mx, My, W (a window's sums stay below 2^32: differences are exact)
+    __shared__ double sErr[KL];
+    __shared__ uint8_t sKsz[KL];
+    __shared__ unsigned long long sScan64[3][4];
+    __shared__ uint32_t sScan32[3][4];
+    __shared__ uint32_t sCnt[16];
+    double *sS = reinterpret_cast<double *>(&sP64[0][0]); // smoothed errors, once the sums are dead
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int frame = blockIdx.y;
+    const uint32_t *counters = ws.d_counters + (size_t)frame * CK_CNT_STRIDE;
+    const uint32_t ext_total = min(counters[CK_CNT_POINTS], (uint32_t)ws.point_cap) + (uint32_t)CK_EXT_HALO * min(counters[CK_CNT_CLUSTERS], (uint32_t)ws.cluster_cap);
+    const uint32_t *xy = ws.d_ext_xy + (size_t)frame * ws.ext_cap;
+    const uint16_t *w16 = ws.d_ext_w + (size_t)frame * ws.ext_cap;
+    double *mval = ws.d_maxval + (size_t)frame * (ws.ext_cap / 2);
+    uint16_t *mpos = ws.d_maxpos + (size_t)frame * (ws.ext_cap / 2);
+    unsigned long long *mmask = ws.d_maxmask + (size_t)frame * (ws.ext_cap / 64);
+    uint16_t *mpre = ws.d_maxpre + (size_t)frame * (ws.ext_cap / 64);
+    long long *blk = ws.d_blk + (size_t)frame * 6 * (ws.ext_cap / 32);
+    for (uint32_t s = blockIdx.x; (unsigned long long)s * CK_SPAN < ext_total; s += gridDim.x) {
+        // 1. four consecutive positions per thread: moments, running sums, one scan over the workgroup
+        const long long p0 = (long long)s * CK_SPAN - KOFF + 4 * tid;
+        uint4 x4 = make_uint4(0, 0, 0, 0);
+        uint2 w2 = make_uint2(0, 0);
+        if (p0 >= 0 && p0 + 4 <= (long long)ws.ext_cap) {
+            x4 = *reinterpret_cast<const uint4 *>(xy + p0);
+            w2 = *reinterpret_cast<const uint2 *>(w16 + p0);
+        }
+        const uint32_t xw[4] = {x4.x, x4.y, x4.z, x4.w};
+        const uint32_t ww[4] = {w2.x & 0x1FFu, (w2.x >> 16) & 0x1FFu, w2.y & 0x1FFu, (w2.y >> 16) & 0x1FFu}; // (9 bits hold every weight; unwritten positions stay bounded)
+        unsigned long long l64[4][3];
+        uint32_t l32[4][3];
+        unsigned long long a64[3] = {0, 0, 0};
+        uint32_t a32[3] = {0, 0, 0};
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const M6 m = moments_of(xw[e] & 0x3FFFFFFu, ww[e]);
+            a64[0] += (unsigned long long)m.Mxx; a64[1] += (unsigned long long)m.Mxy; a64[2] += (unsigned long long)m.Myy;
+            a32[0] += (uint32_t)m.Mx; a32[1] += (uint32_t)m.My; a32[2] += (uint32_t)m.W;
+#pragma unroll
+            for (int q = 0; q < 3; q++) { l64[e][q] = a64[q]; l32[e][q] = a32[q]; }
+        }
+        unsigned long long x64[3];
+        uint32_t x32[3];
+#pragma unroll
+        for (int q = 0; q < 3; q++) { x64[q] = wave_scan_u64(a64[q]); x32[q] = wave_scan_u32(a32[q]); }
+        __syncthreads(); // the previous span's readers are done with every array
+        if (lane == 63)
+#pragma unroll
+            for (int q = 0; q < 3; q++) { sScan64[q][wv] = x64[q]; sScan32[q][wv] = x32[q]; }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+            unsigned long long b64 = 0;
+            uint32_t b32 = 0;
+            for (int k = 0; k < wv; k++) { b64 += sScan64[q][k]; b32 += sScan32[q][k]; }
+            x64[q] += b64 - a64[q]; x32[q] += b32 - a32[q]; // exclusive of this thread's four
+        }
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const int j = 4 * tid + e;
+#pragma unroll
+            for (int q = 0; q < 3; q++) { sP64[q][j] = l64[e][q] + x64[q]; sP32[q][j] = l32[e][q] + x32[q]; }
+            const uint32_t k = (xw[e] >> 26) & 31u;
+            sKsz[j] = (uint8_t)(k > 20u ? 20u : k);
+        }
+        __syncthreads();
+        // 2. moment sums of the span's 30 aligned blocks of 32 positions (Mx, My, Mxx, Mxy, Myy, W: the order of M6)
+        if (tid < 180) {
+            const int b = tid / 6, q = tid - 6 * b;
+            const int jh = KOFF + 32 * b + 31, jl = jh - 32;
+            long long d;
+            if (q == 0) d = (long long)(uint32_t)(sP32[0][jh] - sP32[0][jl]);
+            else if (q == 1) d = (long long)(uint32_t)(sP32[1][jh] - sP32[1][jl]);
+            else if (q == 5) d = (long long)(uint32_t)(sP32[2][jh] - sP32[2][jl]);
+            else d = (long long)(sP64[q - 2][jh] - sP64[q - 2][jl]);
+            blk[((size_t)s * (CK_SPAN / 32) + b) * 6 + q] = d;
+        }
+        // 3. windowed line-fit error of the positions whose smoothed value is needed (k_fit's chunk loop, same operations)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int j = tid + 256 * r;
+            if (j >= KOFF - 4 && j < KOFF + CK_SPAN + 4) {
+                const int ksz = (int)sKsz[j];
+                const int hi = j + ksz, lo = j - ksz - 1;
+                const uint32_t mx = sP32[0][hi] - sP32[0][lo], my = sP32[1][hi] - sP32[1][lo], mw = sP32[2][hi] - sP32[2][lo];
+                M6 m;
+                m.Mxx = (long long)(sP64[0][hi] - sP64[0][lo]); m.Mxy = (long long)(sP64[1][hi] - sP64[1][lo]); m.Myy = (long long)(sP64[2][hi] - sP64[2][lo]);
+                const double inv = 1.0 / (double)mw;
+                const double Ex = (0.5 * (double)mx) * inv, Ey = (0.5 * (double)my) * inv;
+                const double Cxx = (0.25 * (double)m.Mxx) * inv - Ex * Ex;
+                const double Cxy = (0.25 * (double)m.Mxy) * inv - Ex * Ey;
+                const double Cyy = (0.25 * (double)m.Myy) * inv - Ey * Ey;
+                const double d = Cxx - Cyy, q4 = 4.0 * Cxy;
+                const double disc = sqrt(d * d + q4 * Cxy);
+                sErr[j] = (double)(2 * ksz + 1) * (0.5 * ((Cxx + Cyy) - disc));
+            }
+        }
+        __syncthreads();
+        // 4. smoothed errors (the oracle's one-value-at-a-time sum, in its order)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int j = tid + 256 * r;
+            if (j >= KOFF - 1 && j < KOFF + CK_SPAN + 1) {
+                double sm = 0.0;
+#pragma unroll
+                for (int q = 0; q < 7; q++) sm += sErr[j + q - 3] * k_smooth[q];
+                sS[j] = sm;
+            }
+        }
+        __syncthreads();
+        // 5. maxima: one word of 64 positions per wave and round
+        unsigned long long bal[4];
+        double myv[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int j = KOFF + tid + 256 * r;
+            bool ismax = false;
+            myv[r] = 0.0;
+            if (j < KOFF + CK_SPAN) {
+                const double v = sS[j];
+                myv[r] = v;
+                ismax = v > sS[j + 1] && v > sS[j - 1];
+            }
+            bal[r] = __ballot(ismax);
+            const int k = 4 * r + wv;
+            if (lane == 0 && k < 16) sCnt[k] = (uint32_t)__popcll(bal[r]);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int k = 4 * r + wv;
+            if (k >= CK_SPAN / 64) continue;
+            uint32_t pre = 0;
+            for (int i = 0; i < k; i++) pre += sCnt[i];
+            if (lane == 0) { mmask[(size_t)s * (CK_SPAN / 64) + k] = bal[r]; mpre[(size_t)s * (CK_SPAN / 64) + k] = (uint16_t)pre; }
+            if ((bal[r] >> lane) & 1ull) {
+                const uint32_t pos = pre + (uint32_t)__popcll(bal[r] & ((1ull << lane) - 1ull));
+                mval[(size_t)s * (CK_SPAN / 2) + pos] = myv[r];
+                mpos[(size_t)s * (CK_SPAN / 2) + pos] = (uint16_t)(tid + 256 * r);
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ double readlane_f64(double v, int l) {
+    const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)u, l), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(u >> 32), l);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+__device__ __forceinline__ long long readlane_i64(long long v, int l) {
+    const unsigned long long u = (unsigned long long)v;
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)u, l), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(u >> 32), l);
+    return (long long)(((unsigned long long)hi << 32) | lo);
+}
+
+// ---- split fit, last kernel: one wave per cluster ----------------------------------------------------------------------------------
+// The cluster's maxima are runs of the position-ordered lists k_chunk left (one run per span the cluster touches); the (max_nmaxima + 1)-th
+// largest smoothed error is the threshold, the survivors in index order are the candidate corners; their moment prefix sums come
+// from the aligned block sums (a wave scan) plus at most 32 points each; from there on the phases are k_fit's (pair fits, 4-subsets,
+// corners and checks, edge refinement) on 64 lanes.  Sums that start at the block boundary before the cluster's first point carry
+// whatever the positions before it hold — the same addend in every prefix sum, so it leaves with the differences.
+constexpr int MAXRUN = 72; // spans a cluster of CK_HUGE_CAP points can touch
+#ifdef CK_FLAT_DEBUG
+__device__ unsigned int g_flat_dbg[32];
+#define FDBG(k) do { if (tid == 0) atomicAdd(&g_flat_dbg[k], 1u); } while (0)
+#define FDBGV(k, v) do { if (tid == 0) atomicAdd(&g_flat_dbg[k], (unsigned)(v)); } while (0)
+#else
+#define FDBG(k)
+#define FDBGV(k, v)
+#endif
+__global__ __launch_bounds__(64) void k_tail(FitArgs a) {
+    constexpr int NTH = 64, T_TAIL = MAXSEL, T_HEAD = MAXSEL + 1;
+    __shared__ __attribute__((aligned(16))) unsigned char sPraw[sizeof(PairFit) * MAXSEL * MAXSEL];
+    __shared__ long long sSelI[2 * MAXSEL][6];
+    __shared__ long long sF6[MAXSEL + 2][6], sPart[MAXSEL + 2][6];
+    __shared__ int sSelIdx[MAXSEL];
+    __shared__ uint32_t sRunStart[MAXRUN], sRunN[MAXRUN], sRunOff[MAXRUN];
+    __shared__ int sRunO[MAXRUN];
+    __shared__ uint32_t sWork;
+    __shared__ int sFlag, sBad;
+    __shared__ double sLines[4][4];
+    __shared__ double sQuad[4][2];
+    long long (*sSelE)[6] = sSelI + MAXSEL;
+    double (*sRefine)[16][2] = reinterpret_cast<double (*)[16][2]>(sPraw);
+    const int tid = threadIdx.x, lane = tid;
+    const ck_stage_ws &ws = a.ws;
+    const uint32_t n_work = min(*a.list_count, (uint32_t)a.list_cap);
+    constexpr uint32_t DQMAX = 16u;
+    const uint32_t per_wg4 = n_work / (gridDim.x * 4u);
+    const uint32_t DQ = per_wg4 < 1u ? 1u : (per_wg4 > DQMAX ? DQMAX : per_wg4);
+    const uint32_t static_total = gridDim.x * DQ;
+    uint32_t chunk_base = blockIdx.x * DQ, chunk_left = DQ, chunk_len = DQ, dq_next = DQ;
+    for (;;) {
+        __syncthreads();
+        if (chunk_left == 0) {
+            if (static_total >= n_work) break;
+            if (tid == 0) sWork = static_total + atomicAdd(a.head, dq_next);
+            __syncthreads();
+            chunk_base = sWork;
+            if (chunk_base >= n_work) break;
+            chunk_left = chunk_len = dq_next;
+            if (a.guided) {
+                const uint32_t g = (n_work - chunk_base) / (gridDim.x * 2u);
+                dq_next = g < 1u ? 1u : (g > DQ ? DQ : g);
+            }
+        }
+        const uint32_t work = chunk_base + (chunk_len - chunk_left);
+        chunk_left--;
+        if (work >= n_work) break;
+        const uint32_t item = a.list[work];
+        const int frame = (int)(item >> 20), ci = (int)(item & 0xFFFFFu);
+        const uint32_t st = ws.d_cstate[(size_t)frame * ws.cluster_cap + ci];
+        const int sz = (int)(st & 0x7FFFFFFFu), reversed = (int)(st >> 31);
+        FDBG(0);
+        if (sz < 24) continue; // rejected before the fit
+        FDBG(1);
+        const ck_cluster_t cl = ws.d_clusters[(size_t)frame * ws.cluster_cap + ci];
+        if (sz > (int)cl.count) continue; // (a state word nobody wrote in this call)
+        if (a.stop_after <= 4) continue;
+        const uint32_t e0 = cl.start + (uint32_t)CK_EXT_HALO * (uint32_t)ci + CK_EXT_PRE, e1 = e0 + (uint32_t)sz; // the cluster's points: positions [e0, e1)
+        const uint32_t *xy = ws.d_ext_xy + (size_t)frame * ws.ext_cap;
+        const uint16_t *w16 = ws.d_ext_w + (size_t)frame * ws.ext_cap;
+        const double *mval = ws.d_maxval + (size_t)frame * (ws.ext_cap / 2);
+        const uint16_t *mpos = ws.d_maxpos + (size_t)frame * (ws.ext_cap / 2);
+        const unsigned long long *mmask = ws.d_maxmask + (size_t)frame * (ws.ext_cap / 64);
+        const uint16_t *mpre = ws.d_maxpre + (size_t)frame * (ws.ext_cap / 64);
+        const long long *blk = ws.d_blk + (size_t)frame * 6 * (ws.ext_cap / 32);
+        const uint8_t *im = a.im + (size_t)frame * a.pitch;
+        auto pt_moments = [&](uint32_t q) { return moments_of(xy[q] & 0x3FFFFFFu, (uint32_t)w16[q] & 0x1FFu); }; // as k_chunk forms them
+
+        // ---- the cluster's maxima: one run of k_chunk's lists per span it touches ------------------------------------------------
+        const uint32_t s_lo = e0 / CK_SPAN, s_hi = (e1 - 1) / CK_SPAN;
+        const int nruns = (int)(s_hi - s_lo) + 1;
+        if (nruns > MAXRUN) continue; // cannot happen: sz <= CK_HUGE_CAP
+        auto rank_excl = [&](uint32_t x, uint32_t s) -> uint32_t { // maxima of span s before position x (clamped: bounded even on garbage)
+            if (x == s * CK_SPAN) return 0u;
+            const uint32_t w = (x - 1) >> 6, nb = x - (w << 6);
+            const unsigned long long m = mmask[w] & (nb >= 64 ? ~0ull : ((1ull << nb) - 1ull));
+            const uint32_t r = (uint32_t)mpre[w] + (uint32_t)__popcll(m);
+            return r > CK_SPAN / 2 ? CK_SPAN / 2 : r;
+        };
+        uint32_t nmax_u = 0;
+        if (tid == 0) sBad = 0;
+        for (int rb = 0; rb < nruns; rb += 64) {
+            const int r = rb + lane;
+            uint32_t n = 0, start = 0;
+            int obase = 0;
+            if (r < nruns) {
+                const uint32_t s = s_lo + (uint32_t)r;
+                const uint32_t lo = max(e0, s * CK_SPAN), hi = min(e1, s * CK_SPAN + CK_SPAN);
+                const uint32_t r0 = rank_excl(lo, s), r1 = rank_excl(hi, s);
+                n = r1 > r0 ? r1 - r0 : 0u;
+                start = s * (CK_SPAN / 2) + r0;
+                obase = (int)(s * CK_SPAN) - (int)e0;
+            }
+            const uint32_t incl = wave_scan_u32(n);
+            if (r < nruns) { sRunStart[r] = start; sRunN[r] = n; sRunOff[r] = nmax_u + incl - n; sRunO[r] = obase; }
+            nmax_u += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        }
+        __syncthreads();
+        const int nmax_all = (int)nmax_u;
+        FDBGV(10, nmax_all);
+        if (nmax_all < 4) continue;
+        FDBG(2);
+
+        // ---- 5a. threshold = (max_nmaxima+1)-th largest smoothed error; survivors in index order ----------------------------------
+        int nsel = 0;
+        const bool use_thr = nmax_all > a.max_nmaxima;
+        if (nmax_all <= 64) { // one maximum per lane
+            double myv = 0.0;
+            int myo = -1;
+            for (int r = 0; r < nruns; r++) {
+                const uint32_t off = sRunOff[r], n = sRunN[r];
+                if ((uint32_t)lane >= off && (uint32_t)lane < off + n) {
+                    const uint32_t idx = sRunStart[r] + ((uint32_t)lane - off);
+                    myv = mval[idx];
+                    myo = sRunO[r] + (int)mpos[idx];
+                }
+            }
+            const bool has = lane < nmax_all;
+            double thr = 0.0;
+            if (use_thr) {
+                int gt = 0, ge = 0;
+                for (int j = 0; j < nmax_all; j++) {
+                    const double u = readlane_f64(myv, j);
+                    gt += (u > myv) ? 1 : 0;
+                    ge += (u >= myv) ? 1 : 0;
+                }
+                const unsigned long long hit = __ballot(has && gt <= a.max_nmaxima && a.max_nmaxima < ge);
+                if (hit == 0ull) continue; // (values that do not order: garbage)
+                thr = readlane_f64(myv, __builtin_ctzll(hit));
+            }
+            const bool keep = has && !(use_thr && myv <= thr);
+            const unsigned long long kb = __ballot(keep);
+            nsel = __popcll(kb);
+            if (keep) {
+                const int pos = __popcll(kb & ((1ull << lane) - 1ull));
+                if (pos < MAXSEL) sSelIdx[pos] = myo;
+                if (myo < 0 || myo >= sz) sBad = 1;
+            }
+        } else {
+            double thr = 0.0;
+            if (use_thr) {
+                double cur = HUGE_VAL;
+                int remaining = a.max_nmaxima + 1;
+                for (int round = 0; round <= a.max_nmaxima; round++) {
+                    double m = -HUGE_VAL;
+                    int cnt = 0;
+                    for (int r = 0; r < nruns; r++) {
+                        const uint32_t n = sRunN[r], st0 = sRunStart[r];
+                        for (uint32_t i = (uint32_t)lane; i < n; i += 64) {
+                            const double v = mval[st0 + i];
+                            if (v < cur) { if (v > m) { m = v; cnt = 1; } else if (v == m) cnt++; }
+                        }
+                    }
+#pragma unroll
+                    for (int d = 32; d >= 1; d >>= 1) {
+                        const double om = __shfl_xor(m, d, 64);
+                        const int oc = __shfl_xor(cnt, d, 64);
+                        if (om > m) { m = om; cnt = oc; } else if (om == m) cnt += oc;
+                    }
+                    if (cnt >= remaining) { thr = m; break; }
+                    remaining -= cnt;
+                    cur = m;
+                }
+            }
+            for (int r = 0; r < nruns; r++) {
+                const uint32_t n = sRunN[r], st0 = sRunStart[r];
+                for (uint32_t ib = 0; ib < n; ib += 64) {
+                    const uint32_t i = ib + (uint32_t)lane;
+                    bool keep = false;
+                    int myo = -1;
+                    if (i < n) { keep = !(use_thr && mval[st0 + i] <= thr); myo = sRunO[r] + (int)mpos[st0 + i]; }
+                    const unsigned long long kb = __ballot(keep);
+                    if (keep) {
+                        const int pos = nsel + __popcll(kb & ((1ull << lane) - 1ull));
+                        if (pos < MAXSEL) sSelIdx[pos] = myo;
+                        if (myo < 0 || myo >= sz) sBad = 1;
+                    }
+                    nsel += __popcll(kb);
+                }
+            }
+        }
+        __syncthreads();
+        FDBGV(11, nsel); FDBGV(12, sBad);
+        if (nsel < 4 || nsel > MAXSEL || sBad) continue;
+        FDBG(3);
+        // (the lists are in position order and so are the runs: the survivors are sorted already)
+
+        if (a.stop_after == 5) continue;
+        // ---- 5b. moment prefix sums at the selected maxima: aligned block sums (wave scan) + the points beyond the last block ----------
+        const uint32_t B0 = e0 >> 5, blk_l = (e1 - 1) >> 5; // blocks of the first and of the last point
+        auto target_pos = [&](int t) -> uint32_t { return t < nsel ? e0 + (uint32_t)sSelIdx[t] : e1 - 1; };
+        for (int i = tid; i < (MAXSEL + 2) * 6; i += NTH) sF6[i / 6][i % 6] = 0;
+        __syncthreads();
+        {
+            const int nfull = (int)(blk_l - B0); // blocks B0 .. blk_l - 1: what a target's prefix can need
+            long long carry[6] = {0, 0, 0, 0, 0, 0};
+            for (int rb = 0; rb < nfull; rb += 64) {
+                const int b = rb + lane;
+                long long v[6] = {0, 0, 0, 0, 0, 0};
+                if (b < nfull) {
+                    const long long *src = blk + (size_t)(B0 + (uint32_t)b) * 6;
+#pragma unroll
+                    for (int q = 0; q < 6; q++) v[q] = src[q];
+                }
+#pragma unroll
+                for (int q = 0; q < 6; q++) v[q] = (long long)wave_scan_u64((unsigned long long)v[q]) + carry[q];
+                // a target in block k needs the sums through block k - 1
+                for (int t = 0; t <= nsel; t++) {
+                    const int tt = t < nsel ? t : T_TAIL;
+                    const int kk = (int)((target_pos(tt) >> 5) - B0) - 1;
+                    if (kk == b)
+#pragma unroll
+                        for (int q = 0; q < 6; q++) sF6[tt][q] = v[q];
+                }
+#pragma unroll
+                for (int q = 0; q < 6; q++) carry[q] = readlane_i64(v[q], 63);
+            }
+        }
+        {   // four lanes per target, eight positions each: from the target's block boundary to the target (head: to the position before the first point)
+            const int t = lane >> 2, part = lane & 3;
+            M6 m = m6_zero();
+            const bool live = t < nsel || t == T_TAIL || t == T_HEAD;
+            if (live && t < MAXSEL + 2) {
+                uint32_t qs, qe; // inclusive range; empty when qe + 1 == qs
+                if (t == T_HEAD) { qs = B0 << 5; qe = e0 - 1; }
+                else { const uint32_t pm = target_pos(t); qs = pm & ~31u; qe = pm; }
+#pragma unroll
+                for (int e = 0; e < 8; e++) {
+                    const uint32_t q = qs + (uint32_t)(part * 8 + e);
+                    if (q <= qe && q >= qs) m = m6_add(m, pt_moments(q));
+                }
+            }
+            long long pv[6] = {m.Mx, m.My, m.Mxx, m.Mxy, m.Myy, m.W};
+#pragma unroll
+            for (int q = 0; q < 6; q++)
+#pragma unroll
+                for (int d = 2; d >= 1; d >>= 1) pv[q] += __shfl_xor(pv[q], d, 64);
+            if (live && t < MAXSEL + 2 && part == 0)
+#pragma unroll
+                for (int q = 0; q < 6; q++) sPart[t][q] = pv[q];
+        }
+        __syncthreads();
+        if (tid < nsel) {
+            const M6 self = pt_moments(e0 + (uint32_t)sSelIdx[tid]);
+            const long long sv[6] = {self.Mx, self.My, self.Mxx, self.Mxy, self.Myy, self.W};
+#pragma unroll
+            for (int q = 0; q < 6; q++) { const long long v = sF6[tid][q] + sPart[tid][q]; sSelI[tid][q] = v; sSelE[tid][q] = v - sv[q]; }
+        }
+        __syncthreads();
+        M6 total; // the cluster's own points only
+        {
+            long long tv[6];
+#pragma unroll
+            for (int q = 0; q < 6; q++) tv[q] = sF6[T_TAIL][q] + sPart[T_TAIL][q] - sPart[T_HEAD][q];
+            total.Mx = tv[0]; total.My = tv[1]; total.Mxx = tv[2]; total.Mxy = tv[3]; total.Myy = tv[4]; total.W = tv[5];
+        }
+        auto rangeM = [&](int sa, int sb, int *N) { // points from maximum sa to maximum sb inclusive, going forward
+            M6 I = {sSelI[sb][0], sSelI[sb][1], sSelI[sb][2], sSelI[sb][3], sSelI[sb][4], sSelI[sb][5]};
+            M6 E = {sSelE[sa][0], sSelE[sa][1], sSelE[sa][2], sSelE[sa][3], sSelE[sa][4], sSelE[sa][5]};
+            int i0 = sSelIdx[sa], i1 = sSelIdx[sb];
+            if (i0 < i1) { *N = i1 - i0 + 1; return m6_sub(I, E); }
+            *N = sz - i0 + i1 + 1;
+            return m6_add(m6_sub(total, E), I);
+        };
+
+        if (a.stop_after == 6) continue;
+        // ---- 5c. one line fit per ordered pair of maxima; the 4-subset search is then table lookups ------------------------
+        PairFit *sF = reinterpret_cast<PairFit *>(sPraw);
+        {
+            const int npf = nsel * (nsel - 1) / 2;
+            for (int k = tid; k < npf; k += NTH) {
+                const int pk = g_pair_table.v[k], sa = pk >> 4, sb = pk & 15;
+                int Nf, Nw;
+                const M6 mf = rangeM(sa, sb, &Nf), mw = rangeM(sb, sa, &Nw);
+                double lp[4], lq[4], ef, msf, ew, msw;
+                fit_line_m(mf, Nf, lp, &ef, &msf);
+                fit_line_m(mw, Nw, lq, &ew, &msw);
+                PairFit f;
+                f.err = ef; f.mse = msf; f.nx = lp[2]; f.ny = lp[3];
+                sF[sa * MAXSEL + sb] = f;
+                f.err = ew; f.mse = msw; f.nx = lq[2]; f.ny = lq[3];
+                sF[sb * MAXSEL + sa] = f;
+            }
+        }
+        __syncthreads();
+        double best = HUGE_VAL;
+        int bestc = 1 << 30;
+        {
+            const int ncomb = nsel * (nsel - 1) * (nsel - 2) * (nsel - 3) / 24;
+            for (int cb = tid; cb < ncomb; cb += NTH) {
+                const int pk = g_combo_table.v[cb];
+                const int m0 = pk >> 12, m1 = (pk >> 8) & 15, m2 = (pk >> 4) & 15, m3 = pk & 15;
+                const PairFit f01 = sF[m0 * MAXSEL + m1];
+                if (f01.mse > a.max_mse) continue;
+                const PairFit f12 = sF[m1 * MAXSEL + m2];
+                if (f12.mse > a.max_mse) continue;
+                double dp = f01.nx * f12.nx + f01.ny * f12.ny;
+                if (fabs(dp) > a.cos_critical) continue;
+                const PairFit f23 = sF[m2 * MAXSEL + m3];
+                if (f23.mse > a.max_mse) continue;
+                const PairFit f30 = sF[m3 * MAXSEL + m0];
+                if (f30.mse > a.max_mse) continue;
+                double e = f01.err + f12.err + f23.err + f30.err;
+                if (e < best || (e == best && pk < bestc)) { best = e; bestc = pk; }
+            }
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            double ob = __shfl_xor(best, d, 64);
+            int oc = __shfl_xor(bestc, d, 64);
+            if (ob < best || (ob == best && oc < bestc)) { best = ob; bestc = oc; }
+        }
+        if (best == HUGE_VAL) continue;
+        FDBG(4);
+        if (best / (double)sz >= a.max_mse) continue;
+        FDBG(5);
+
+        if (a.stop_after == 7) continue;
+        // ---- 5d. lines, corners, geometric checks (k_fit's, lane i of every group of four owns side i / corner i) -----------------
+        {
+            const int li = tid & 3;
+            const int sel[4] = {(bestc >> 12) & 15, (bestc >> 8) & 15, (bestc >> 4) & 15, bestc & 15};
+            int ok = 1;
+            double line[4];
+            {
+                int N;
+                const int s0 = sel[li], s1 = sel[(li + 1) & 3];
+                const M6 m = rangeM(s0, s1, &N);
+                const PairFit pf = sF[s0 * MAXSEL + s1];
+                const double inv = 1.0 / (double)m.W;
+                line[0] = (0.5 * (double)m.Mx) * inv; line[1] = (0.5 * (double)m.My) * inv;
+                line[2] = pf.nx; line[3] = pf.ny;
+                if (pf.mse > a.max_mse) ok = 0;
+            }
+            double ln[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) ln[q] = __shfl(line[q], (tid & ~3) | ((li + 1) & 3), 64);
+            double Px, Py;
+            {
+                double A00 = line[3], A01 = -ln[3], A10 = -line[2], A11 = ln[2];
+                double B0_ = -line[0] + ln[0], B1 = -line[1] + ln[1];
+                double det = A00 * A11 - A10 * A01;
+                if (fabs(det) < 0.001) ok = 0;
+                double W00 = A11 / det, W01 = -A01 / det;
+                double L0 = W00 * B0_ + W01 * B1;
+                Px = line[0] + L0 * A00;
+                Py = line[1] + L0 * A10;
+            }
+            const int g0 = tid & ~3;
+            auto corner_x = [&](int q) { return __shfl(Px, g0 | (q & 3), 64); };
+            auto corner_y = [&](int q) { return __shfl(Py, g0 | (q & 3), 64); };
+            {
+                const int t = li & 1;
+                const int va = t ? 2 : 0, vb = t ? 3 : 1, vc = t ? 0 : 2;
+                const double ax = corner_x(va), ay = corner_y(va), bx = corner_x(vb), by = corner_y(vb), cx = corner_x(vc), cy = corner_y(vc);
+                double len[3];
+                { double ddx = bx - ax, ddy = by - ay; len[0] = sqrt(ddx * ddx + ddy * ddy); }
+                { double ddx = cx - bx, ddy = cy - by; len[1] = sqrt(ddx * ddx + ddy * ddy); }
+                { double ddx = ax - cx, ddy = ay - cy; len[2] = sqrt(ddx * ddx + ddy * ddy); }
+                double pp = (len[0] + len[1] + len[2]) / 2.0;
+                double term = sqrt(pp * (pp - len[0]) * (pp - len[1]) * (pp - len[2]));
+                double t0 = __shfl(term, g0, 64), t1 = __shfl(term, g0 | 1, 64);
+                double area = 0.0;
+                area += t0; area += t1;
+                double tw = (double)a.min_tag_width;
+                if (area < 0.95 * tw * tw) ok = 0;
+            }
+            {
+                const double x1 = corner_x(li + 1), y1 = corner_y(li + 1), x2 = corner_x(li + 2), y2 = corner_y(li + 2);
+                double dx1 = x1 - Px, dy1 = y1 - Py;
+                double dx2 = x2 - x1, dy2 = y2 - y1;
+                double cs = (dx1 * dx2 + dy1 * dy2) / sqrt((dx1 * dx1 + dy1 * dy1) * (dx2 * dx2 + dy2 * dy2));
+                if (cs > a.cos_critical || cs < -a.cos_critical) ok = 0;
+                if (dx1 * dy2 < dy1 * dx2) ok = 0;
+            }
+            const int all_ok = (__ballot(ok != 0) & 0xFull) == 0xFull;
+            if (tid < 4 && all_ok) {
+                double qx = Px, qy = Py;
+                if (a.decimate > 1) { qx = (qx - 0.5) * (double)a.decimate + 0.5; qy = (qy - 0.5) * (double)a.decimate + 0.5; }
+                sQuad[li][0] = qx; sQuad[li][1] = qy;
+            }
+            if (tid == 0) sFlag = all_ok;
+        }
+        __syncthreads();
+        if (!sFlag) continue;
+        FDBG(6);
+        if (a.refine) { // edge refinement (oracle refine_edges), as in k_fit: lane (edge, k) evaluates sample 16 * round + k, one lane per edge accumulates in sample order
+            const int edge = (tid >> 4) & 3, k = tid & 15;
+            const int ea = edge, eb = (edge + 1) & 3;
+            double nx = sQuad[eb][1] - sQuad[ea][1];
+            double ny = -sQuad[eb][0] + sQuad[ea][0];
+            const double mag = sqrt(nx * nx + ny * ny);
+            nx = nx / mag; ny = ny / mag;
+            if (reversed) { nx = -nx; ny = -ny; }
+            int nsamples = (int)(mag / 8.0);
+            if (nsamples < 16) nsamples = 16;
+            int max_samples = nsamples;
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) max_samples = max(max_samples, __shfl_xor(max_samples, d, 64));
+            double Mx = 0, My = 0, Mxx = 0, Mxy = 0, Myy = 0, N = 0;
+            __syncthreads(); // the pair table's bytes become the sample buffer
+            for (int base = 0; base < max_samples; base += 16) {
+                {
+                    const int sidx = base + k;
+                    double bx = __builtin_nan(""), by = 0;
+                    if (sidx < nsamples) {
+                        double alpha = (1.0 + (double)sidx) / ((double)nsamples + 1.0);
+                        double x0 = alpha * sQuad[ea][0] + (1.0 - alpha) * sQuad[eb][0];
+                        double y0 = alpha * sQuad[ea][1] + (1.0 - alpha) * sQuad[eb][1];
+                        double Mn = 0, Mcount = 0;
+                        const int range = a.decimate + 1;
+                        for (int n = -range; n <= range; n++) {
+                            double grange = 1.0;
+                            int x1 = (int)(x0 + ((double)n + grange) * nx), y1 = (int)(y0 + ((double)n + grange) * ny);
+                            if (x1 < 0 || x1 >= a.w || y1 < 0 || y1 >= a.h) continue;
+                            int x2 = (int)(x0 + ((double)n - grange) * nx), y2 = (int)(y0 + ((double)n - grange) * ny);
+                            if (x2 < 0 || x2 >= a.w || y2 < 0 || y2 >= a.h) continue;
+                            int g1 = im[(size_t)y1 * a.stride + x1], g2 = im[(size_t)y2 * a.stride + x2];
+                            if (g1 < g2) continue;
+                            double weight = (double)((g2 - g1) * (g2 - g1));
+                            Mn += weight * (double)n;
+                            Mcount += weight;
+                        }
+                        if (Mcount != 0) {
+                            double n0 = Mn / Mcount;
+                            bx = x0 + n0 * nx; by = y0 + n0 * ny;
+                        }
+                    }
+                    sRefine[edge][k][0] = bx; sRefine[edge][k][1] = by;
+                }
+                __syncthreads();
+                if (k == 0)
+                    for (int q = 0; q < 16 && base + q < nsamples; q++) {
+                        double bx = sRefine[edge][q][0], by = sRefine[edge][q][1];
+                        if (bx != bx) continue;
+                        Mx += bx; My += by; Mxx += bx * bx; Mxy += bx * by; Myy += by * by; N += 1.0;
+                    }
+                __syncthreads();
+            }
+            if (k == 0) {
+                double line[4];
+                if (N < 2.0) {
+                    line[0] = 0.5 * (sQuad[ea][0] + sQuad[eb][0]); line[1] = 0.5 * (sQuad[ea][1] + sQuad[eb][1]);
+                    line[2] = nx; line[3] = ny;
+                } else {
+                    double Ex = Mx / N, Ey = My / N;
+                    double Cxx = Mxx / N - Ex * Ex, Cxy = Mxy / N - Ex * Ey, Cyy = Myy / N - Ey * Ey;
+                    double d = Cxx - Cyy, q4 = 4.0 * Cxy;
+                    double disc = sqrt(d * d + q4 * Cxy);
+                    double eig = 0.5 * (Cxx + Cyy + disc);
+                    double nx1 = Cxx - eig, ny1 = Cxy, M1 = nx1 * nx1 + ny1 * ny1;
+                    double nx2 = Cxy, ny2 = Cyy - eig, M2 = nx2 * nx2 + ny2 * ny2;
+                    double fx, fy, M;
+                    if (M1 > M2) { fx = nx1; fy = ny1; M = M1; } else { fx = nx2; fy = ny2; M = M2; }
+                    double len = sqrt(M);
+                    line[0] = Ex; line[1] = Ey;
+                    if (len < 1e-12) { line[2] = nx; line[3] = ny; }
+                    else { line[2] = fx / len; line[3] = fy / len; }
+                }
+                for (int q = 0; q < 4; q++) sLines[edge][q] = line[q];
+            }
+            __syncthreads();
+            if (tid == 0)
+                for (int i = 0; i < 4; i++) {
+                    int j = (i + 1) & 3;
+                    double A00 = sLines[i][3], A01 = -sLines[j][3], A10 = -sLines[i][2], A11 = sLines[j][2];
+                    double B0_ = -sLines[i][0] + sLines[j][0], B1 = -sLines[i][1] + sLines[j][1];
+                    double det = A00 * A11 - A10 * A01;
+                    if (fabs(det) > 0.001) {
+                        double W00 = A11 / det, W01 = -A01 / det;
+                        double L0 = W00 * B0_ + W01 * B1;
+                        sQuad[j][0] = sLines[i][0] + L0 * A00;
+                        sQuad[j][1] = sLines[i][1] + L0 * A10;
+                    }
+                }
+        }
+        if (tid == 0) {
+            uint32_t *counters = ws.d_counters + (size_t)frame * CK_CNT_STRIDE;
+            uint32_t qi = atomicAdd(&counters[CK_CNT_QUADS], 1u);
+            if (qi < (uint32_t)ws.quad_cap) {
+                ck_quad_t q;
+                for (int i = 0; i < 4; i++) { q.p[i][0] = sQuad[i][0]; q.p[i][1] = sQuad[i][1]; }
+                q.reversed_border = reversed; q.rep0 = cl.rep0; q.rep1 = cl.rep1;
+                ws.d_quads[(size_t)frame * ws.quad_cap + qi] = q;
+            } else atomicOr(&counters[CK_CNT_STATUS], (uint32_t)CK_FRAME_QUADS_OVERFLOW);
+        }
+    }
+}
+
 // Gradient-magnitude weights of a whole batch in one streaming pass (1 B read, 2 B written per pixel): the fitter then needs
 // ONE 2-byte gather per contour point instead of four byte gathers.  Four pixels per thread: three aligned 4-byte loads (row
 // above, row, row below) plus the two bytes beside the group.  Image rows are padded to 16 bytes (staged frames and the decimated
@@ -1301,30 +1983,41 @@ __global__ __launch_bounds__(256) void k_weight_image(const uint8_t *__restrict_
 // builds the per-size-class work lists from the cluster tables: one workgroup per frame counts its clusters per class in
 // LDS, reserves the four list ranges with four global atomics, then writes (the lists' internal order is irrelevant)
 __global__ __launch_bounds__(1024) void k_classify(ck_stage_ws ws, int n, uint32_t *lists, uint32_t *list_counts, int list_cap, int split) {
-    __shared__ uint32_t sCnt[CK_FIT_CLASSES], sBase[CK_FIT_CLASSES];
+    __shared__ uint32_t sCnt[CK_FIT_LISTS], sBase[CK_FIT_LISTS];
     const int frame = blockIdx.x, tid = threadIdx.x;
     const uint32_t *counters = ws.d_counters + (size_t)frame * CK_CNT_STRIDE;
     const uint32_t nc = counters[CK_CNT_CLUSTERS];
     const ck_cluster_t *cls = ws.d_clusters + (size_t)frame * ws.cluster_cap;
     auto class_of = [split](uint32_t c) { return (c <= 256 && (split & 2)) ? 7 : c <= 512 ? 0 : (c <= 1024 && (split & 1)) ? 6 : (c <= 2048 ? 1 : (c <= 4096 ? 2 : (c <= 8192 ? 3 : (c <= 16384 ? 4 : 5)))); };
-    if (tid < CK_FIT_CLASSES) sCnt[tid] = 0;
+    if (tid < CK_FIT_LISTS) sCnt[tid] = 0;
     __syncthreads();
     // (a cluster without points is one k_scan had no room for: skipped)
-    for (uint32_t i = tid; i < nc; i += 1024) if (cls[i].count) atomicAdd(&sCnt[class_of(cls[i].count)], 1u);
+    for (uint32_t i = tid; i < nc; i += 1024) if (cls[i].count) { atomicAdd(&sCnt[class_of(cls[i].count)], 1u); atomicAdd(&sCnt[CK_FIT_CLASSES], 1u); }
     __syncthreads();
-    if (tid < CK_FIT_CLASSES) { sBase[tid] = sCnt[tid] ? atomicAdd(&list_counts[tid], sCnt[tid]) : 0u; }
+    if (tid < CK_FIT_LISTS) { sBase[tid] = sCnt[tid] ? atomicAdd(&list_counts[tid], sCnt[tid]) : 0u; }
     __syncthreads();
-    if (tid < CK_FIT_CLASSES) sCnt[tid] = 0;
+    if (tid < CK_FIT_LISTS) sCnt[tid] = 0;
     __syncthreads();
     for (uint32_t i = tid; i < nc; i += 1024) {
         if (!cls[i].count) continue;
         const int k = class_of(cls[i].count);
         const uint32_t pos = sBase[k] + atomicAdd(&sCnt[k], 1u);
         if (pos < (uint32_t)list_cap) lists[(size_t)k * list_cap + pos] = ((uint32_t)frame << 20) | i;
+        // list CK_FIT_CLASSES: every cluster, whatever its size (the tail kernel of the split fit)
+        const uint32_t pa = sBase[CK_FIT_CLASSES] + atomicAdd(&sCnt[CK_FIT_CLASSES], 1u);
+        if (pa < (uint32_t)list_cap) lists[(size_t)CK_FIT_CLASSES * list_cap + pa] = ((uint32_t)frame << 20) | i;
     }
 }
 } // namespace
 
+#ifdef CK_FLAT_DEBUG
+extern "C" int ck_flat_debug_read(unsigned int *out, int reset) {
+    unsigned int z[32] = {};
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_flat_dbg), sizeof z) != hipSuccess) return -1;
+    if (reset && hipMemcpyToSymbol(HIP_SYMBOL(g_flat_dbg), z, sizeof z) != hipSuccess) return -1;
+    return 0;
+}
+#endif
 #ifdef CK_FIT_PROFILE
 extern "C" int ck_fit_profile_read(unsigned long long *out, int reset) {
     unsigned long long z[3][16] = {};
@@ -1397,9 +2090,28 @@ int ck_launch_fit_quads(ck_handle *h, const uint8_t *qframes, int qstride, size_
     static const int gk_env = getenv("CK_FIT_GK") ? atoi(getenv("CK_FIT_GK")) : 0; // (experiment: bit c set = class c keeps its keys in global memory: small LDS, more workgroups per CU)
     const int gk_mask = ws.d_hscratch ? gk_env : 0;
     static const int skip_mask = getenv("CK_FIT_SKIP") ? atoi(getenv("CK_FIT_SKIP")) : 0; // (diagnostics: bit c set = class c is not launched)
+    // The split fit (k_fit<..., SPLIT> per class -> k_chunk over all positions -> k_tail over all clusters): CK_FIT_FLAT = 0 never,
+    // 1 for calls that run their classes one after the other, 2 always (default 0 while the split path is slower: 10.8 against 9.8 ms)
+    static const int flat_env = getenv("CK_FIT_FLAT") ? atoi(getenv("CK_FIT_FLAT")) : 0;
+    const bool flat = flat_env >= 2 || (flat_env == 1 && !side_by_side);
+    auto launch_split = [&](int c) {
+        switch (c) {
+        case 0: hipLaunchKernelGGL((k_fit<64, 512, 64, true, 4, false, true>), dim3((unsigned)(cus * 16)), dim3(64), 0, cs[c], a); break;
+        case 7: hipLaunchKernelGGL((k_fit<64, 256, 64, true, 4, false, true>), dim3((unsigned)(cus * 16)), dim3(64), 0, cs[c], a); break;
+        case 6: hipLaunchKernelGGL((k_fit<128, 1024, 128, true, 4, false, true>), dim3((unsigned)(cus * 8)), dim3(128), 0, cs[c], a); break;
+        case 1: hipLaunchKernelGGL((k_fit<256, 2048, 224, true, 4, false, true>), dim3((unsigned)(cus * 4)), dim3(256), 0, cs[c], a); break;
+        case 2: hipLaunchKernelGGL((k_fit<256, 4096, 512, true, 2, false, true>), dim3((unsigned)(cus * 2)), dim3(256), 0, cs[c], a); break;
+        case 3: hipLaunchKernelGGL((k_fit<512, 8192, 896, true, 2, false, true>), dim3((unsigned)cus), dim3(512), 0, cs[c], a); break;
+        case 4: hipLaunchKernelGGL((k_fit<512, 16384, 512, false, 2, false, true>), dim3((unsigned)cus), dim3(512), 0, cs[c], a); break;
+        default:
+            if (ws.d_hscratch) hipLaunchKernelGGL((k_fit<512, CK_HUGE_CAP, 896, false, 2, true, true>), dim3((unsigned)CK_HUGE_WGS), dim3(512), 0, cs[c], a);
+            break;
+        }
+    };
     auto launch = [&](int c) {
         if ((skip_mask >> c) & 1) return;
         a.list = lists + (size_t)c * list_cap; a.list_count = list_counts + c; a.head = heads + c;
+        if (flat) { launch_split(c); return; }
         switch (c) {
         case 0: { static const int s_wgs = getenv("CK_FIT_S_WGS") ? atoi(getenv("CK_FIT_S_WGS")) : 12; // (diagnostics: workgroups per CU of the small class)
             hipLaunchKernelGGL((k_fit<64, 512, 64, true, 3>), dim3((unsigned)(cus * s_wgs)), dim3(64), 0, cs[c], a); break; }
@@ -1428,6 +2140,18 @@ int ck_launch_fit_quads(ck_handle *h, const uint8_t *qframes, int qstride, size_
             CK_HIP(hipEventRecord(h->ev_fit_join[k], h->fit_stream[k]));
             CK_HIP(hipStreamWaitEvent(h->stream, h->ev_fit_join[k], 0));
         }
+    if (flat) {
+        // spans per frame and workgroups that share them: a batch gives every workgroup a few spans, a short call one each
+        const unsigned spans = (unsigned)(ws.ext_cap / CK_SPAN);
+        static const int chunk_wgs = getenv("CK_CHUNK_WGS") ? atoi(getenv("CK_CHUNK_WGS")) : 16; // (diagnostics: k_chunk workgroups per CU over the batch)
+        static const int tail_wgs = getenv("CK_TAIL_WGS") ? atoi(getenv("CK_TAIL_WGS")) : 16;    // (diagnostics: k_tail workgroups per CU)
+        unsigned gx = (unsigned)((cus * chunk_wgs + n - 1) / n);
+        if (gx < 8) gx = 8;
+        if (gx > spans) gx = spans;
+        if (a.stop_after > 3) hipLaunchKernelGGL(k_chunk, dim3(gx, (unsigned)n), dim3(256), 0, h->stream, ws);
+        a.list = lists + (size_t)CK_FIT_CLASSES * list_cap; a.list_count = list_counts + CK_FIT_CLASSES; a.head = heads + CK_FIT_CLASSES;
+        hipLaunchKernelGGL(k_tail, dim3((unsigned)(cus * tail_wgs)), dim3(64), 0, h->stream, a);
+    }
     CK_HIP(hipGetLastError());
     return CK_OK;
 }
