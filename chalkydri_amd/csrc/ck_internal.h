@@ -64,8 +64,8 @@ constexpr int CK_FIT_LISTS = 9;    // work lists: one per size class + (index 8)
 // The split quad fit (k_quads.hip: k_fit<..., SPLIT> -> k_chunk -> k_tail) passes a cluster's sorted, de-duplicated points on as an
 // EXTENDED sequence: its last CK_EXT_PRE points, the points, its first CK_EXT_POST points again — so that the windowed line-fit
 // error, its smoothing and the maxima test of every point read neighbours at plain offsets and a kernel can stream over all
-// clusters of a frame without knowing where one ends.  Cluster ci of a frame owns the positions
-// [start + CK_EXT_HALO * ci, + count + CK_EXT_HALO) of the frame's sequence (start/count: its record; counts shrink with the duplicates).
+// clusters of a frame without knowing where one ends.  A cluster's place in the frame's sequence is handed out when it gets there
+// (a per-frame counter); it needs its point count after duplicate removal + CK_EXT_HALO positions.
 constexpr int CK_EXT_PRE = 25, CK_EXT_POST = 24, CK_EXT_HALO = CK_EXT_PRE + CK_EXT_POST;
 constexpr int CK_SPAN = 960;       // positions one k_chunk workgroup decides (15 words of 64), CK_SPAN / 2 = most maxima it can find
 constexpr int CK_HUGE_CAP = 65536, CK_HUGE_WGS = 256; // largest class: points per cluster (3 * 4 * 4095 < 65536), workgroups in its grid
@@ -115,7 +115,7 @@ struct ck_stage_ws {
     unsigned long long *d_maxmask; // [n][ext_cap / 64] bit = position is a maximum
     uint16_t *d_maxpre;        // [n][ext_cap / 64] maxima of the span before this word
     long long *d_blk;          // [n][ext_cap / 32][6] moment sums of every aligned block of 32 positions (Mx, My, Mxx, Mxy, Myy, W)
-    uint32_t *d_cstate;        // [n][cluster_cap] points left after duplicate removal | reversed border << 31; 0: rejected before the fit
+    uint32_t *d_cstate;        // [n][cluster_cap][2] points left after duplicate removal | reversed border << 31 (0: rejected before the fit), first position of the cluster's extended sequence
     ck_run *d_runs;            // [n][run_cap]
     int run_cap;
     unsigned long long *d_lscratch; // [CK_LSCRATCH_WGS][CK_LSCRATCH_PER_WG]: sort scratch / maxima list of the large fit class, per workgroup
@@ -146,6 +146,7 @@ struct ck_stage_ws {
 #define CK_CNT_DETS 4
 #define CK_CNT_STATUS 5
 #define CK_CNT_RUNS 6
+#define CK_CNT_EXT 7 /* split quad fit: positions of the frame's extended sequences handed out so far */
 #define CK_CNT_STRIDE 8
 
 struct ck_handle {

@@ -52,7 +52,7 @@ int ck_stage_alloc(ck_handle *h) {
     CK_ALLOC(ck_malloc_dev(&ws.d_maxmask, sizeof(unsigned long long) * (size_t)(ws.ext_cap / 64) * nb));
     CK_ALLOC(ck_malloc_dev(&ws.d_maxpre, sizeof(uint16_t) * (size_t)(ws.ext_cap / 64) * nb));
     CK_ALLOC(ck_malloc_dev(&ws.d_blk, sizeof(long long) * 6 * (size_t)(ws.ext_cap / 32) * nb));
-    CK_ALLOC(ck_malloc_dev(&ws.d_cstate, sizeof(uint32_t) * (size_t)ws.cluster_cap * nb));
+    CK_ALLOC(ck_malloc_dev(&ws.d_cstate, sizeof(uint32_t) * 2 * (size_t)ws.cluster_cap * nb));
     ws.run_cap = 4 * ws.cluster_cap;
     CK_ALLOC(ck_malloc_dev(&ws.d_runs, sizeof(ck_run) * (size_t)ws.run_cap * nb));
     CK_ALLOC(ck_malloc_dev(&ws.d_lscratch, 2 * sizeof(unsigned long long) * (size_t)CK_LSCRATCH_PER_WG * CK_LSCRATCH_WGS));
@@ -147,7 +147,7 @@ static ck_handle make_view(const ck_handle *h, int f0, bool second_stream = true
     w.d_tmp += f * w.ext_cap; w.d_points += f * w.ext_cap; w.d_runs += f * w.run_cap;
     w.d_ext_xy += f * w.ext_cap; w.d_ext_w += f * w.ext_cap; w.d_maxval += f * (size_t)(w.ext_cap / 2); w.d_maxpos += f * (size_t)(w.ext_cap / 2);
     w.d_maxmask += f * (size_t)(w.ext_cap / 64); w.d_maxpre += f * (size_t)(w.ext_cap / 64); w.d_blk += f * 6 * (size_t)(w.ext_cap / 32);
-    w.d_cstate += f * w.cluster_cap;
+    w.d_cstate += f * 2 * w.cluster_cap;
     if (second_stream) w.d_lscratch += (size_t)CK_LSCRATCH_PER_WG * CK_LSCRATCH_WGS;
     if (second_stream && w.d_hscratch) w.d_hscratch += 2 * (size_t)w.hcap * CK_HUGE_WGS;
     w.d_clusters += f * w.cluster_cap; w.d_counters += f * CK_CNT_STRIDE; w.d_quads += f * w.quad_cap; w.d_dets += f * w.det_cap;

@@ -247,6 +247,10 @@ __device__ unsigned long long g_tile_prof[16];
 #define TCOUNT(k, v)
 #endif
 
+// A barrier that orders LDS traffic only.  __syncthreads() carries a workgroup-scope fence, which the compiler turns into a wait for
+// EVERY outstanding memory operation: the barrier behind the threshold store then waits for HBM to acknowledge it.  Nothing a
+// workgroup of k_tile writes to global memory is read by it again.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 // PRE = false: `frames` are gray images and the tri-state threshold is computed here;
 // PRE = true : `frames` already hold a tri-state map (0 / 127 / 255), e.g. CAT's class map, and only the
 //              segmentation runs (the map is copied through to `thresh` for the merge kernel).
@@ -298,7 +302,7 @@ __global__ __launch_bounds__(KNT) __attribute__((amdgpu_num_sgpr(80))) void k_ti
         if (gy >= 0 && gy < h && gx >= 0 && gx < w) v = *reinterpret_cast<const uint4 *>(img + (size_t)gy * stride + gx);
         *reinterpret_cast<uint4 *>(lds + OFF_IMG + r * IMG_PITCH + 16 * c) = v;
     }
-    __syncthreads();
+    lds_barrier();
     TPROF(0);
 
     if (stop_after == 0) return; // diagnostics (CK_TILE_STOP_AFTER)
@@ -322,7 +326,7 @@ __global__ __launch_bounds__(KNT) __attribute__((amdgpu_num_sgpr(80))) void k_ti
         }
         minmax[item] = mn | (mx << 8); // outside the frame: (255,0) is neutral for the dilation
     }
-    __syncthreads();
+    lds_barrier();
 
     // ---- P2: 3x3 dilation -> per-4x4-tile threshold word (bit 8 = low contrast); column j = 4x4 column c4x + j -------
     uint16_t *thr = reinterpret_cast<uint16_t *>(lds + OFF_THR);
@@ -346,7 +350,7 @@ __global__ __launch_bounds__(KNT) __attribute__((amdgpu_num_sgpr(80))) void k_ti
     // then only stores constants (every threshold word a pixel of this tile can look up is one of the 256 just written)
     // (a flag word set by one lane per wave before the barrier: __syncthreads_or costs two more barriers)
     if (__builtin_amdgcn_ballot_w64(my_contrast != 0) && (tid & 63) == 0) misc[8] = 1;
-    __syncthreads();
+    lds_barrier();
     const int tile_contrast = PRE ? 1 : (int)misc[8];
     TPROF(1);
 
@@ -417,7 +421,7 @@ __global__ __launch_bounds__(KNT) __attribute__((amdgpu_num_sgpr(80))) void k_ti
         any_colour = wbits | bbits;
         // a tile without a coloured pixel has nothing to segment
         if (__builtin_amdgcn_ballot_w64(any_colour != 0) && (tid & 63) == 0) misc[9] = 1;
-        __syncthreads();
+        lds_barrier();
         tile_has_runs = (int)misc[9];
     } else {
         const uint32_t out[4] = {0x7F7F7F7Fu, 0x7F7F7F7Fu, 0x7F7F7F7Fu, 0x7F7F7F7Fu};
@@ -539,7 +543,7 @@ __global__ __launch_bounds__(KNT) __attribute__((amdgpu_num_sgpr(80))) void k_ti
         int r, xl; uint32_t ec;
         if (edge_pixel(mk, tid & 63, tx0, ty0, w, h, r, xl, ec)) parent[r * TW + xl] = (uint16_t)CK_ROOT;
     }
-    __syncthreads();
+    lds_barrier();
     nwhite = misc[0];
     nruns = nwhite + misc[1];
     TPROF(4);
@@ -556,7 +560,7 @@ __global__ __launch_bounds__(KNT) __attribute__((amdgpu_num_sgpr(80))) void k_ti
         const uint32_t g = parent[q & 0xFFFu]; // (a root's own entry has no parent to look at: the read is harmless, the result unused)
         if (!(q & CK_ROOT) && !(g & CK_ROOT)) parent[pe] = (uint16_t)g;
     }
-    if (sweeps) __syncthreads(); // (uniform)
+    if (sweeps) lds_barrier(); // (uniform)
     TPROF(5);
     if (stop_after == 5) return; // diagnostics (CK_TILE_STOP_AFTER)
     // ---- P5c: the pooled links, one lane per link, through the atomic union ------------------------------------------
@@ -593,7 +597,7 @@ __global__ __launch_bounds__(KNT) __attribute__((amdgpu_num_sgpr(80))) void k_ti
             }
         }
     }
-    __syncthreads(); // halving stores must land before the owners publish final roots; the pool is dead
+    lds_barrier(); // halving stores must land before the owners publish final roots; the pool is dead
     TCOUNT(9, nruns); TCOUNT(10, npool);
     TPROF(6);
     if (stop_after == 6) return; // diagnostics (CK_TILE_STOP_AFTER)
@@ -662,7 +666,7 @@ __global__ __launch_bounds__(KNT) __attribute__((amdgpu_num_sgpr(80))) void k_ti
             ekeep = me | (root << 16);
         }
     }
-    __syncthreads();
+    lds_barrier();
     if (stop_after == 65) return; // diagnostics (CK_TILE_STOP_AFTER): flatten + sizes done, ids not yet
     // ---- P6b: the components that touch the tile ring get their tile-local id (= place in the tile's slice of the frame's list,
     // which takes the root's pixel and the component's pixel count).  One lane per RING PIXEL (320 of them, not one per run): it
@@ -707,7 +711,7 @@ __global__ __launch_bounds__(KNT) __attribute__((amdgpu_num_sgpr(80))) void k_ti
             parent[root] = (uint16_t)(CK_ROOT | CK_RING | CK_CLAIM | id);
         }
     }
-    __syncthreads();
+    lds_barrier();
     } // tile_has_runs
     if (tid == 0) tile_count[(size_t)frame * tiles + tile] = misc[6] | (misc[7] << 16); // white | black << 16
     TPROF(7);
@@ -749,12 +753,12 @@ __global__ __launch_bounds__(KNT) __attribute__((amdgpu_num_sgpr(80))) void k_ti
             if ((uint32_t)(k * KNT) < nruns) lw[k] = label_word(keep[k]);
         }
         elw = label_word(ekeep);
-        __syncthreads();
+        lds_barrier();
 #pragma unroll
         for (int k = 0; k < NPL; k++)
             if ((uint32_t)(k * KNT) < nruns && keep[k] != KEEP_NONE) tab32[keep[k] & 0xFFFu] = lw[k];
         if (ekeep != KEEP_NONE) tab32[ekeep & 0xFFFu] = elw;
-        __syncthreads();
+        lds_barrier();
     }
     // ---- P7: write label words.  Lane L owns the 8-column group L & 15 of pair L >> 4, both rows: the search for a column's node
     // (per colour: the nearest node start at or below it, then the row of that node's lookup pixel) is shared by the column's two

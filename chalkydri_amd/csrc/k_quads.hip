@@ -106,9 +106,16 @@ __device__ __forceinline__ void fit_line_m(const M6 &m, int N, double *lineparm,
 __device__ const double k_smooth[7] = {0.011108996538242306, 0.1353352832366127, 0.6065306597126334, 1.0,
                                        0.6065306597126334, 0.1353352832366127, 0.011108996538242306};
 
+// Barriers that order LDS traffic only.  __syncthreads() carries a workgroup-scope fence, which the compiler turns into a wait for
+// EVERY outstanding memory operation — a prefetch issued for the next cluster would be waited for at the first barrier behind it.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// a workgroup of one wave: its LDS operations are carried out in order, only the compiler has to keep them in place
+__device__ __forceinline__ void wave_sync() { asm volatile("" ::: "memory"); __builtin_amdgcn_wave_barrier(); asm volatile("" ::: "memory"); }
+
 template <int NTH>
 struct Block {
     static constexpr int NW = NTH / 64;
+    __device__ __forceinline__ static void sync() { if constexpr (NTH == 64) wave_sync(); else __syncthreads(); }
     // inclusive sum over the workgroup of one 64-bit value per thread; scratch: NW+1 values of LDS
     __device__ static long long scan_incl(long long v, long long *scratch, long long *total) {
         const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -408,7 +415,7 @@ __device__ __forceinline__ long long keys_bucket_sort(unsigned long long *sKeys,
     dot = B::reduce_add(dot, sScratch);
     *done = true;
     if (!do_sort || !((dot < 0) ? reversed_ok : normal_ok)) return dot; // uniform: rejected by border direction anyway
-    __syncthreads(); // histogram zeroed, every staged point read
+    B::sync(); // histogram zeroed, every staged point read
 #pragma unroll
     for (int e = 0; e < EPLS; e++) {
         const int i = tid + e * NTH;
@@ -420,7 +427,7 @@ __device__ __forceinline__ long long keys_bucket_sort(unsigned long long *sKeys,
             meta[e] = (b << 16) | atomicAdd(&hist[b], 1u);
         }
     }
-    __syncthreads();
+    B::sync();
     {   // exclusive scan of the counts in place (hist[nb] = sz0) and the largest count
         const int per = nb / NTH;
         uint32_t sum = 0, mx = 0;
@@ -428,18 +435,18 @@ __device__ __forceinline__ long long keys_bucket_sort(unsigned long long *sKeys,
         long long total;
         const long long incl = B::scan_incl((long long)sum, sScratch, &total);
         const int worst = -B::reduce_min(-(int)mx, reinterpret_cast<int *>(sScratch));
-        if (worst > BUCKET_LIMIT) { *done = false; __syncthreads(); return dot; }
+        if (worst > BUCKET_LIMIT) { *done = false; B::sync(); return dot; }
         uint32_t run = (uint32_t)(incl - sum);
         for (int q = 0; q < per; q++) { uint32_t c = hist[tid * per + q]; hist[tid * per + q] = run; run += c; }
         if (tid == NTH - 1) hist[nb] = run;
     }
-    __syncthreads();
+    B::sync();
 #pragma unroll
     for (int e = 0; e < EPLS; e++) {
         const int i = tid + e * NTH;
         if (i < sz0) sKeys[hist[meta[e] >> 16] + (meta[e] & 0xFFFFu)] = kreg[e];
     }
-    __syncthreads();
+    B::sync();
     uint32_t pos[EPLS];
 #pragma unroll
     for (int e = 0; e < EPLS; e++) {
@@ -456,7 +463,7 @@ __device__ __forceinline__ long long keys_bucket_sort(unsigned long long *sKeys,
             pos[e] = s0 + rank;
         }
     }
-    __syncthreads();
+    B::sync();
 #pragma unroll
     for (int e = 0; e < EPLS; e++) {
         const int i = tid + e * NTH;
@@ -534,9 +541,7 @@ __device__ __forceinline__ long long keys_bucket_sort_global(unsigned long long 
 
 // NTH threads per cluster, up to CAP points, chunks of CH points; MLDS: the maxima list fits in LDS; GK: the per-point arrays
 // (keys, then coordinates and weights) live in a per-workgroup slice of global memory instead of LDS (the largest class)
-// SPLIT: the kernel ends after the weights and leaves the cluster's EXTENDED point sequence (ck_internal.h) and its state word for
-// k_chunk and k_tail; the per-point arrays of the later phases are then never used (the compiler drops them)
-template <int NTH, int CAP, int CH, bool MLDS, int WPS, bool GK = false, bool SPLIT = false>
+template <int NTH, int CAP, int CH, bool MLDS, int WPS, bool GK = false>
 __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(WPS, 8))) void k_fit(FitArgs a) {
     using B = Block<NTH>;
     constexpr int SL = CH + 2 * HALO;
@@ -630,8 +635,6 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(WPS, 8))) v
         if (sz0 > CAP) continue; // cannot happen: the class lists are built from the counts
         PROF_DECL;
         PROF(15);
-        uint32_t *cstate = ws.d_cstate + (size_t)frame * ws.cluster_cap + ci;
-        if (SPLIT && tid == 0) *cstate = 0u; // rejected unless the end of the kernel says otherwise (same thread: ordered)
 
         if (a.stop_after == 0) continue;
         // ---- 1. bounding box + border direction ----------------------------------------------------------
@@ -760,22 +763,6 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(WPS, 8))) v
                     sW[i] = (ix >= 0 && ix < a.qw && iy >= 0 && iy < a.qh) ? wq[(size_t)iy * a.qw + ix] : (uint16_t)1;
                 }
             }
-        }
-        if constexpr (SPLIT) {
-            __syncthreads(); // weights written by other threads
-            const size_t es = (size_t)frame * ws.ext_cap + cl.start + (size_t)CK_EXT_HALO * ci;
-            uint32_t *exy = ws.d_ext_xy + es;
-            uint16_t *ew = ws.d_ext_w + es;
-            for (int k = tid; k < sz + CK_EXT_HALO; k += NTH) {
-                int src = k - CK_EXT_PRE;              // sz >= 24: at most two steps bring it into [0, sz)
-                if (src < 0) src += sz;
-                if (src < 0) src += sz;
-                if (src >= sz) src -= sz;
-                exy[k] = sXY[src] | ((uint32_t)ksz << 26);
-                ew[k] = sW[src];
-            }
-            if (tid == 0) *cstate = (uint32_t)sz | (reversed ? 0x80000000u : 0u);
-            continue;
         }
         // the cluster's slice of the 8-byte scratch is free again (the sort is done); the large class keeps its maxima there
         double *gval = reinterpret_cast<double *>(scratch8);
@@ -1278,6 +1265,189 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(WPS, 8))) v
     }
 }
 
+// ---- split fit, first kernel: bounding box, border direction, sort, duplicate removal -> the cluster's extended sequence -----------
+// The phases are k_fit's first ones (same helpers).  What is new is how a workgroup gets at its clusters: per cluster the old loop
+// pays a chain of memory round trips (list entry -> record -> points -> weights) with nothing else to do, and the split fit's first
+// kernel is nothing but that chain plus a sort.  Here the HEADS of a chunk's clusters (list entry and record) are fetched by one
+// thread each, all at once, and the points of cluster k + 1 are in flight in registers while cluster k is sorted; the weights
+// are left to k_chunk, which streams.  NTH threads per cluster, up to CAP points; MLDS / GK as in k_fit.
+template <int NTH, int CAP, bool MLDS, int WPS, bool GK>
+__global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(WPS, 8))) void k_seq(FitArgs a) {
+    using B = Block<NTH>;
+    constexpr int EPL = CAP / NTH;
+    constexpr bool PF = EPL <= 16; // the next cluster's points travel in registers
+    constexpr int HB = MLDS ? ((CAP < 2048 ? CAP : 2048) + 1) * 4 : 2 * (1024 + 1) * 4; // the sort's histogram
+    __shared__ unsigned long long sKeysL[GK ? 1 : CAP];
+    __shared__ __attribute__((aligned(16))) unsigned char sHist[HB];
+    __shared__ long long sScratch[6 * (NTH / 64) + 2];
+    __shared__ uint32_t sWork;
+    __shared__ uint32_t sHItem[64], sHStart[64], sHCount[64];
+    const int tid = threadIdx.x;
+    const ck_stage_ws &ws = a.ws;
+    const int capr = GK ? ws.hcap : CAP;
+    unsigned long long *const sKeys = GK ? ws.d_hscratch + (size_t)blockIdx.x * 2 * capr : sKeysL;
+    unsigned long long *scratch8 = GK ? ws.d_hscratch + (size_t)blockIdx.x * 2 * capr + capr : ws.d_lscratch + (size_t)blockIdx.x * CK_LSCRATCH_PER_WG;
+    uint32_t *sXY = reinterpret_cast<uint32_t *>(sKeys);
+    int *iscr = reinterpret_cast<int *>(sScratch);
+    const uint32_t n_work = min(*a.list_count, (uint32_t)a.list_cap);
+    // clusters per dequeue: an add on the one counter of a class costs ~17 ns however many workgroups wait for it (26 000 of them were
+    // 0.45 of the 0.7 ms of the smallest class); the chunks shrink towards the end of the list (guided), so large ones cost no tail
+    constexpr uint32_t DQMAX = CAP <= 512 ? 64u : (CAP <= 1024 ? 32u : (CAP <= 2048 ? 16u : (CAP <= 4096 ? 8u : (CAP <= 8192 ? 4u : 2u))));
+    const uint32_t per_wg4 = n_work / (gridDim.x * 4u);
+    const uint32_t DQ = per_wg4 < 1u ? 1u : (per_wg4 > DQMAX ? DQMAX : per_wg4);
+    const uint32_t static_total = gridDim.x * DQ;
+    uint32_t chunk_base = blockIdx.x * DQ, chunk_len = DQ, dq_next = DQ;
+    bool first_chunk = true;
+    // packed point -> the staged form the sort reads: x | y << 16 | (u8)gx << 32 | (u8)gy << 40
+    auto stage = [](ck_packed_point v) -> unsigned long long {
+        const int k = (int)(v >> 1) & 3, sgn = (v & 1u) ? 1 : -1;
+        const int dx = k == 2 ? -1 : (k == 1 ? 0 : 1), dy = k == 0 ? 0 : 1;
+        return (unsigned long long)((v >> 16) & 0x1FFFu) | ((unsigned long long)((v >> 3) & 0x1FFFu) << 16) |
+               ((unsigned long long)(uint8_t)(int8_t)(dx * sgn) << 32) | ((unsigned long long)(uint8_t)(int8_t)(dy * sgn) << 40);
+    };
+    for (;;) {
+        if (!first_chunk) {
+            if (static_total >= n_work) break;
+            B::sync();
+            if (tid == 0) sWork = static_total + atomicAdd(a.head, dq_next);
+            B::sync();
+            chunk_base = sWork;
+            chunk_len = dq_next;
+            if (a.guided) {
+                const uint32_t g = chunk_base < n_work ? (n_work - chunk_base) / (gridDim.x * 2u) : 0u;
+                dq_next = g < 1u ? 1u : (g > DQ ? DQ : g);
+            }
+        }
+        first_chunk = false;
+        if (chunk_base >= n_work) break;
+        const int len = (int)min(chunk_len, n_work - chunk_base);
+        B::sync(); // the heads of the chunk before this one have been read
+        if (tid < len) {
+            const uint32_t item = a.list[chunk_base + (uint32_t)tid];
+            const ck_cluster_t cl = ws.d_clusters[(size_t)(item >> 20) * ws.cluster_cap + (item & 0xFFFFFu)];
+            sHItem[tid] = item; sHStart[tid] = cl.start; sHCount[tid] = cl.count;
+        }
+        B::sync();
+        ck_packed_point nxt[PF ? EPL : 1];
+        auto fetch = [&](int k) {
+            if constexpr (PF) {
+                const uint32_t item = sHItem[k], cnt = sHCount[k];
+                const ck_packed_point *p = ws.d_points + (size_t)(item >> 20) * ws.ext_cap + sHStart[k];
+#pragma unroll
+                for (int e = 0; e < EPL; e++) { const uint32_t i = (uint32_t)(tid + e * NTH); nxt[e] = (i < cnt && cnt <= (uint32_t)CAP) ? p[i] : 0u; }
+            }
+        };
+        fetch(0);
+        for (int k = 0; k < len; k++) {
+            const uint32_t item = sHItem[k];
+            const int frame = (int)(item >> 20), ci = (int)(item & 0xFFFFFu);
+            const int sz0 = (int)sHCount[k];
+            const ck_packed_point *pts = ws.d_points + (size_t)frame * ws.ext_cap + sHStart[k];
+            ck_packed_point rawp[PF ? EPL : 1];
+            if constexpr (PF) {
+#pragma unroll
+                for (int e = 0; e < EPL; e++) rawp[e] = nxt[e];
+                if (k + 1 < len) fetch(k + 1);
+            }
+            B::sync(); // the cluster before this one is done with the key array
+            uint32_t *cstate = ws.d_cstate + 2 * ((size_t)frame * ws.cluster_cap + ci);
+            if (tid == 0) *cstate = 0u; // rejected unless the end says otherwise (same thread: ordered)
+            if (sz0 > CAP || sz0 < 1) continue; // cannot happen: the class lists are built from the counts
+            if (a.stop_after == 0) continue;
+            // ---- 1. bounding box ---------------------------------------------------------------------------------------------
+            int xmin = 1 << 30, xmax = -(1 << 30), ymin = 1 << 30, ymax = -(1 << 30);
+            if constexpr (PF) {
+#pragma unroll
+                for (int e = 0; e < EPL; e++) {
+                    const int i = tid + e * NTH;
+                    if (i < sz0) {
+                        const unsigned long long raw = stage(rawp[e]);
+                        sKeys[i] = raw;
+                        const int px = (int)(raw & 0xFFFF), py = (int)((raw >> 16) & 0xFFFF);
+                        xmin = min(xmin, px); xmax = max(xmax, px);
+                        ymin = min(ymin, py); ymax = max(ymax, py);
+                    }
+                }
+            } else {
+                for (int i = tid; i < sz0; i += NTH) {
+                    const unsigned long long raw = stage(pts[i]);
+                    sKeys[i] = raw;
+                    const int px = (int)(raw & 0xFFFF), py = (int)((raw >> 16) & 0xFFFF);
+                    xmin = min(xmin, px); xmax = max(xmax, px);
+                    ymin = min(ymin, py); ymax = max(ymax, py);
+                }
+            }
+            {
+                int bb[4] = {xmin, -xmax, ymin, -ymax};
+                B::reduce_min4(bb, iscr);
+                xmin = bb[0]; xmax = -bb[1]; ymin = bb[2]; ymax = -bb[3];
+            }
+            if ((xmax - xmin) * (ymax - ymin) < a.min_tag_width) continue;
+            if (a.stop_after == 10) continue;
+            // ---- 2. border direction, sort ---------------------------------------------------------------------------------------
+            long long dot;
+            {
+                constexpr int EPLS = CAP / NTH;
+                int n2 = NTH;
+                while (n2 < sz0) n2 <<= 1;
+                const int epl = n2 / NTH;
+                B::sync(); // raw points staged by other threads
+                bool sorted = false;
+                if constexpr (MLDS)
+                    dot = keys_bucket_sort<NTH, EPLS>(sKeys, reinterpret_cast<uint32_t *>(sHist), sScratch, sz0, xmin, xmax, ymin, ymax,
+                                                      a.normal_ok, a.reversed_ok, a.stop_after != 11, &sorted);
+                else
+                    dot = keys_bucket_sort_global<NTH, GK>(sKeys, reinterpret_cast<uint32_t *>(sHist), sScratch, scratch8, sz0, xmin, xmax, ymin, ymax,
+                                                           a.normal_ok, a.reversed_ok, a.stop_after != 11, &sorted);
+                if (sorted || GK) {}
+                else if (EPLS >= 32 && epl == 32) dot = keys_sort<NTH, (EPLS >= 32 && !GK ? 32 : 1)>(sKeys, sScratch, sz0, xmin, xmax, ymin, ymax, a.normal_ok, a.reversed_ok, a.stop_after != 11);
+                else if (EPLS >= 16 && epl == 16) dot = keys_sort<NTH, (EPLS >= 16 && !GK ? 16 : 1)>(sKeys, sScratch, sz0, xmin, xmax, ymin, ymax, a.normal_ok, a.reversed_ok, a.stop_after != 11);
+                else if (EPLS >= 8 && epl == 8) dot = keys_sort<NTH, (EPLS >= 8 && !GK ? 8 : 1)>(sKeys, sScratch, sz0, xmin, xmax, ymin, ymax, a.normal_ok, a.reversed_ok, a.stop_after != 11);
+                else if (EPLS >= 4 && epl == 4) dot = keys_sort<NTH, (EPLS >= 4 && !GK ? 4 : 1)>(sKeys, sScratch, sz0, xmin, xmax, ymin, ymax, a.normal_ok, a.reversed_ok, a.stop_after != 11);
+                else if (EPLS >= 2 && epl == 2) dot = keys_sort<NTH, (EPLS >= 2 && !GK ? 2 : 1)>(sKeys, sScratch, sz0, xmin, xmax, ymin, ymax, a.normal_ok, a.reversed_ok, a.stop_after != 11);
+                else dot = keys_sort<NTH, 1>(sKeys, sScratch, sz0, xmin, xmax, ymin, ymax, a.normal_ok, a.reversed_ok, a.stop_after != 11);
+            }
+            const int reversed = dot < 0;
+            if (reversed && !a.reversed_ok) continue;
+            if (!reversed && !a.normal_ok) continue;
+            if (a.stop_after == 1 || a.stop_after == 11) continue;
+            // ---- 3. duplicate removal, packing to (x, y) (k_fit's: the compaction writes below what is still unread) -------------
+            B::sync();
+            int sz = 0;
+            for (int base = 0; base < sz0; base += NTH) {
+                const int i = base + tid;
+                unsigned long long key = 0;
+                int keep = 0;
+                if (i < sz0) { key = sKeys[i]; keep = (i == 0) || (sKeys[i - 1] != key); }
+                int tot = 0;
+                const int incl = B::scan_flag(keep, iscr, &tot);
+                B::sync();
+                if (keep) sXY[sz + (int)incl - 1] = (uint32_t)(key & 0x3FFFFFFu);
+                sz += (int)tot;
+                B::sync();
+            }
+            if (sz < 24) continue;
+            const int ksz = sz / 12 < 20 ? sz / 12 : 20;
+            if (ksz < 2) continue;
+            if (a.stop_after == 2) continue;
+            // ---- 4. the extended sequence.  Its place in the frame is handed out in the order the clusters get here (k_chunk and k_tail
+            // do not care where a cluster lies), so the positions k_chunk works through are all live ones --------------------------
+            if (tid == 0) sWork = atomicAdd(ws.d_counters + (size_t)frame * CK_CNT_STRIDE + CK_CNT_EXT, (uint32_t)(sz + CK_EXT_HALO));
+            B::sync();
+            const uint32_t es32 = sWork;
+            uint32_t *exy = ws.d_ext_xy + (size_t)frame * ws.ext_cap + es32;
+            for (int q = tid; q < sz + CK_EXT_HALO; q += NTH) {
+                int src = q - CK_EXT_PRE; // sz >= 24: at most two steps bring it into [0, sz)
+                if (src < 0) src += sz;
+                if (src < 0) src += sz;
+                if (src >= sz) src -= sz;
+                exy[q] = sXY[src] | ((uint32_t)ksz << 26);
+            }
+            if (tid == 0) { cstate[1] = es32; cstate[0] = (uint32_t)sz | (reversed ? 0x80000000u : 0u); }
+        }
+    }
+}
+
 // ---- split fit, middle kernel: windowed line-fit error, smoothing and maxima of EVERY position of a frame's extended sequences --------
 // One workgroup decides CK_SPAN = 960 consecutive positions (15 words of 64) from 1024 loaded ones; it knows nothing about clusters:
 // a cluster's extended sequence carries its own neighbours (ck_internal.h), the window half-width travels in the point word, and
@@ -1287,7 +1457,7 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(WPS, 8))) v
 // the doubles are formed by the operations of k_fit's chunk loop in the same order: the same bits.
 constexpr int KL = 1024, KOFF = 32;
 static_assert(CK_SPAN == 960 && KOFF >= CK_EXT_PRE + 3 && KL - KOFF - CK_SPAN >= CK_EXT_POST + 4, "span geometry");
-__global__ __launch_bounds__(256) void k_chunk(ck_stage_ws ws) {
+__global__ __launch_bounds__(256) void k_chunk(ck_stage_ws ws, int qw, int qh) {
     __shared__ __attribute__((aligned(16))) unsigned long long sP64[3][KL]; // inclusive sums from the first loaded position: Mxx, Mxy, Myy
     __shared__ __attribute__((aligned(16))) uint32_t sP32[3][KL];           // Mx, My, W (a window's sums stay below 2^32: differences are exact)
     __shared__ double sErr[KL];
@@ -1299,25 +1469,37 @@ __global__ __launch_bounds__(256) void k_chunk(ck_stage_ws ws) {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int frame = blockIdx.y;
     const uint32_t *counters = ws.d_counters + (size_t)frame * CK_CNT_STRIDE;
-    const uint32_t ext_total = min(counters[CK_CNT_POINTS], (uint32_t)ws.point_cap) + (uint32_t)CK_EXT_HALO * min(counters[CK_CNT_CLUSTERS], (uint32_t)ws.cluster_cap);
+    const uint32_t ext_total = min(counters[CK_CNT_EXT], (uint32_t)ws.ext_cap); // positions k_seq handed out
     const uint32_t *xy = ws.d_ext_xy + (size_t)frame * ws.ext_cap;
-    const uint16_t *w16 = ws.d_ext_w + (size_t)frame * ws.ext_cap;
+    uint16_t *w16 = ws.d_ext_w + (size_t)frame * ws.ext_cap;
+    const uint16_t *wq = ws.d_wimg + (size_t)frame * qw * qh;
     double *mval = ws.d_maxval + (size_t)frame * (ws.ext_cap / 2);
     uint16_t *mpos = ws.d_maxpos + (size_t)frame * (ws.ext_cap / 2);
     unsigned long long *mmask = ws.d_maxmask + (size_t)frame * (ws.ext_cap / 64);
     uint16_t *mpre = ws.d_maxpre + (size_t)frame * (ws.ext_cap / 64);
     long long *blk = ws.d_blk + (size_t)frame * 6 * (ws.ext_cap / 32);
+    // the gradient weight of every point: one gather from the weight image (k_fit's phase 3; a position nobody wrote gathers at
+    // whatever 13-bit coordinates it holds, inside the image or refused), kept for k_tail in the sequence's weight array.  The
+    // span after this one is fetched while this one is worked on: its points at the top, their weights once those have arrived
+    auto load_xy = [&](uint32_t s) -> uint4 {
+        const long long p0 = (long long)s * CK_SPAN - KOFF + 4 * tid;
+        if ((unsigned long long)s * CK_SPAN < ext_total && p0 >= 0 && p0 + 4 <= (long long)ws.ext_cap) return *reinterpret_cast<const uint4 *>(xy + p0);
+        return make_uint4(0, 0, 0, 0);
+    };
+    auto gather_w = [&](uint32_t v) -> uint32_t {
+        const int x = (int)((v >> 13) & 0x1FFFu), y = (int)(v & 0x1FFFu);
+        const int ix = (x + 1) >> 1, iy = (y + 1) >> 1;
+        return (ix < qw && iy < qh) ? (uint32_t)wq[(size_t)iy * qw + ix] : 1u;
+    };
+    uint4 x4 = load_xy(blockIdx.x);
+    uint32_t ww[4] = {gather_w(x4.x), gather_w(x4.y), gather_w(x4.z), gather_w(x4.w)};
     for (uint32_t s = blockIdx.x; (unsigned long long)s * CK_SPAN < ext_total; s += gridDim.x) {
         // 1. four consecutive positions per thread: moments, running sums, one scan over the workgroup
+        const uint4 nx4 = load_xy(s + gridDim.x);
         const long long p0 = (long long)s * CK_SPAN - KOFF + 4 * tid;
-        uint4 x4 = make_uint4(0, 0, 0, 0);
-        uint2 w2 = make_uint2(0, 0);
-        if (p0 >= 0 && p0 + 4 <= (long long)ws.ext_cap) {
-            x4 = *reinterpret_cast<const uint4 *>(xy + p0);
-            w2 = *reinterpret_cast<const uint2 *>(w16 + p0);
-        }
         const uint32_t xw[4] = {x4.x, x4.y, x4.z, x4.w};
-        const uint32_t ww[4] = {w2.x & 0x1FFu, (w2.x >> 16) & 0x1FFu, w2.y & 0x1FFu, (w2.y >> 16) & 0x1FFu}; // (9 bits hold every weight; unwritten positions stay bounded)
+        if (tid >= KOFF / 4 && tid < (KOFF + CK_SPAN) / 4) // the positions this span decides: their weights stay for k_tail
+            *reinterpret_cast<uint2 *>(w16 + p0) = make_uint2(ww[0] | (ww[1] << 16), ww[2] | (ww[3] << 16));
         unsigned long long l64[4][3];
         uint32_t l32[4][3];
         unsigned long long a64[3] = {0, 0, 0};
@@ -1334,11 +1516,11 @@ __global__ __launch_bounds__(256) void k_chunk(ck_stage_ws ws) {
         uint32_t x32[3];
 #pragma unroll
         for (int q = 0; q < 3; q++) { x64[q] = wave_scan_u64(a64[q]); x32[q] = wave_scan_u32(a32[q]); }
-        __syncthreads(); // the previous span's readers are done with every array
+        lds_barrier(); // the previous span's readers are done with every array
         if (lane == 63)
 #pragma unroll
             for (int q = 0; q < 3; q++) { sScan64[q][wv] = x64[q]; sScan32[q][wv] = x32[q]; }
-        __syncthreads();
+        lds_barrier();
 #pragma unroll
         for (int q = 0; q < 3; q++) {
             unsigned long long b64 = 0;
@@ -1354,7 +1536,7 @@ __global__ __launch_bounds__(256) void k_chunk(ck_stage_ws ws) {
             const uint32_t k = (xw[e] >> 26) & 31u;
             sKsz[j] = (uint8_t)(k > 20u ? 20u : k);
         }
-        __syncthreads();
+        lds_barrier();
         // 2. moment sums of the span's 30 aligned blocks of 32 positions (Mx, My, Mxx, Mxy, Myy, W: the order of M6)
         if (tid < 180) {
             const int b = tid / 6, q = tid - 6 * b;
@@ -1386,7 +1568,8 @@ __global__ __launch_bounds__(256) void k_chunk(ck_stage_ws ws) {
                 sErr[j] = (double)(2 * ksz + 1) * (0.5 * ((Cxx + Cyy) - disc));
             }
         }
-        __syncthreads();
+        const uint32_t nww[4] = {gather_w(nx4.x), gather_w(nx4.y), gather_w(nx4.z), gather_w(nx4.w)};
+        lds_barrier();
         // 4. smoothed errors (the oracle's one-value-at-a-time sum, in its order)
 #pragma unroll
         for (int r = 0; r < 4; r++) {
@@ -1398,7 +1581,7 @@ __global__ __launch_bounds__(256) void k_chunk(ck_stage_ws ws) {
                 sS[j] = sm;
             }
         }
-        __syncthreads();
+        lds_barrier();
         // 5. maxima: one word of 64 positions per wave and round
         unsigned long long bal[4];
         double myv[4];
@@ -1416,7 +1599,7 @@ __global__ __launch_bounds__(256) void k_chunk(ck_stage_ws ws) {
             const int k = 4 * r + wv;
             if (lane == 0 && k < 16) sCnt[k] = (uint32_t)__popcll(bal[r]);
         }
-        __syncthreads();
+        lds_barrier();
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             const int k = 4 * r + wv;
@@ -1430,6 +1613,9 @@ __global__ __launch_bounds__(256) void k_chunk(ck_stage_ws ws) {
                 mpos[(size_t)s * (CK_SPAN / 2) + pos] = (uint16_t)(tid + 256 * r);
             }
         }
+        x4 = nx4;
+#pragma unroll
+        for (int e = 0; e < 4; e++) ww[e] = nww[e];
     }
 }
 
@@ -1459,7 +1645,7 @@ __device__ unsigned int g_flat_dbg[32];
 #define FDBG(k)
 #define FDBGV(k, v)
 #endif
-__global__ __launch_bounds__(64) void k_tail(FitArgs a) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_tail(FitArgs a) {
     constexpr int NTH = 64, T_TAIL = MAXSEL, T_HEAD = MAXSEL + 1;
     __shared__ __attribute__((aligned(16))) unsigned char sPraw[sizeof(PairFit) * MAXSEL * MAXSEL];
     __shared__ long long sSelI[2 * MAXSEL][6];
@@ -1476,39 +1662,111 @@ __global__ __launch_bounds__(64) void k_tail(FitArgs a) {
     const int tid = threadIdx.x, lane = tid;
     const ck_stage_ws &ws = a.ws;
     const uint32_t n_work = min(*a.list_count, (uint32_t)a.list_cap);
-    constexpr uint32_t DQMAX = 16u;
+    constexpr uint32_t DQMAX = 64u; // (one lane per head; few adds on the one counter: see k_seq)
     const uint32_t per_wg4 = n_work / (gridDim.x * 4u);
     const uint32_t DQ = per_wg4 < 1u ? 1u : (per_wg4 > DQMAX ? DQMAX : per_wg4);
     const uint32_t static_total = gridDim.x * DQ;
-    uint32_t chunk_base = blockIdx.x * DQ, chunk_left = DQ, chunk_len = DQ, dq_next = DQ;
+    uint32_t chunk_base = blockIdx.x * DQ, chunk_len = DQ, dq_next = DQ;
+    bool first_chunk = true;
+    auto rank_excl = [](const unsigned long long *mmask, const uint16_t *mpre, uint32_t x, uint32_t s) -> uint32_t {
+        // maxima of span s before position x (clamped: bounded even on garbage)
+        if (x == s * CK_SPAN) return 0u;
+        const uint32_t w = (x - 1) >> 6, nb = x - (w << 6);
+        const unsigned long long m = mmask[w] & (nb >= 64 ? ~0ull : ((1ull << nb) - 1ull));
+        const uint32_t r = (uint32_t)mpre[w] + (uint32_t)__popcll(m);
+        return r > CK_SPAN / 2 ? CK_SPAN / 2 : r;
+    };
     for (;;) {
-        __syncthreads();
-        if (chunk_left == 0) {
+        // The wave's time is a chain of memory round trips unless they are shared: the HEADS of a chunk's clusters (list entry, state
+        // word, record, the ranks that bound their maxima lists) are fetched by one lane each, all at once; a cluster's maxima and its
+        // first block sums are fetched while the cluster before it is fitted.
+        if (!first_chunk) {
             if (static_total >= n_work) break;
+            wave_sync();
             if (tid == 0) sWork = static_total + atomicAdd(a.head, dq_next);
-            __syncthreads();
+            wave_sync();
             chunk_base = sWork;
-            if (chunk_base >= n_work) break;
-            chunk_left = chunk_len = dq_next;
+            chunk_len = dq_next;
             if (a.guided) {
-                const uint32_t g = (n_work - chunk_base) / (gridDim.x * 2u);
+                const uint32_t g = chunk_base < n_work ? (n_work - chunk_base) / (gridDim.x * 2u) : 0u;
                 dq_next = g < 1u ? 1u : (g > DQ ? DQ : g);
             }
         }
-        const uint32_t work = chunk_base + (chunk_len - chunk_left);
-        chunk_left--;
-        if (work >= n_work) break;
-        const uint32_t item = a.list[work];
-        const int frame = (int)(item >> 20), ci = (int)(item & 0xFFFFFu);
-        const uint32_t st = ws.d_cstate[(size_t)frame * ws.cluster_cap + ci];
-        const int sz = (int)(st & 0x7FFFFFFFu), reversed = (int)(st >> 31);
+        first_chunk = false;
+        if (chunk_base >= n_work) break;
+        const int len = (int)min(chunk_len, n_work - chunk_base);
+        // ---- heads: lane l takes cluster l of the chunk ----------------------------------------------------------------------
+        uint32_t h_item = 0, h_st = 0, h_e0 = 0, h_rep0 = 0, h_rep1 = 0, h_s0 = 0, h_n0 = 0, h_s1 = 0, h_n1 = 0;
+        int h_nruns = 0;
+        if (lane < len) {
+            h_item = a.list[chunk_base + (uint32_t)lane];
+            const int frame = (int)(h_item >> 20), ci = (int)(h_item & 0xFFFFFu);
+            const uint2 st2 = *reinterpret_cast<const uint2 *>(ws.d_cstate + 2 * ((size_t)frame * ws.cluster_cap + ci));
+            const uint32_t st = st2.x;
+            const ck_cluster_t cl = ws.d_clusters[(size_t)frame * ws.cluster_cap + ci];
+            const uint32_t sz = st & 0x7FFFFFFFu;
+            // (below 24: rejected before the fit; above the count or beyond the buffer: a state nobody wrote in this call)
+            if (sz >= 24u && sz <= cl.count && (unsigned long long)st2.y + sz + CK_EXT_HALO <= (unsigned long long)ws.ext_cap) {
+                h_st = st; h_rep0 = cl.rep0; h_rep1 = cl.rep1;
+                const uint32_t e0 = st2.y + CK_EXT_PRE, e1 = e0 + sz;
+                h_e0 = e0;
+                const uint32_t s_lo = e0 / CK_SPAN, s_hi = (e1 - 1) / CK_SPAN;
+                h_nruns = (int)(s_hi - s_lo) + 1;
+                if (h_nruns <= 2) {
+                    const unsigned long long *mmask = ws.d_maxmask + (size_t)frame * (ws.ext_cap / 64);
+                    const uint16_t *mpre = ws.d_maxpre + (size_t)frame * (ws.ext_cap / 64);
+                    const uint32_t hi0 = min(e1, s_lo * CK_SPAN + CK_SPAN);
+                    const uint32_t r0 = rank_excl(mmask, mpre, e0, s_lo), r1 = rank_excl(mmask, mpre, hi0, s_lo);
+                    h_s0 = s_lo * (CK_SPAN / 2) + r0; h_n0 = r1 > r0 ? r1 - r0 : 0u;
+                    if (h_nruns == 2) { h_s1 = s_hi * (CK_SPAN / 2); h_n1 = rank_excl(mmask, mpre, e1, s_hi); }
+                }
+            }
+        }
+        // what lane `lane` of cluster k needs first: its maximum (if the cluster has at most 64, in at most two runs) and the
+        // sums of the cluster's first 64 blocks
+        struct Pre { double v; uint32_t pos; long long b[6]; };
+        auto prefetch = [&](int k) -> Pre {
+            Pre p;
+            p.v = 0.0; p.pos = 0;
+#pragma unroll
+            for (int q = 0; q < 6; q++) p.b[q] = 0;
+            if (k >= len) return p;
+            const uint32_t st = (uint32_t)__builtin_amdgcn_readlane((int)h_st, k);
+            if (!st) return p;
+            const uint32_t item = (uint32_t)__builtin_amdgcn_readlane((int)h_item, k), e0 = (uint32_t)__builtin_amdgcn_readlane((int)h_e0, k);
+            const int frame = (int)(item >> 20);
+            const int nruns = __builtin_amdgcn_readlane(h_nruns, k);
+            const uint32_t n0 = (uint32_t)__builtin_amdgcn_readlane((int)h_n0, k), n1 = (uint32_t)__builtin_amdgcn_readlane((int)h_n1, k);
+            if (nruns <= 2 && n0 + n1 <= 64u && (uint32_t)lane < n0 + n1) {
+                const uint32_t s0 = (uint32_t)__builtin_amdgcn_readlane((int)h_s0, k), s1 = (uint32_t)__builtin_amdgcn_readlane((int)h_s1, k);
+                const uint32_t idx = (uint32_t)lane < n0 ? s0 + (uint32_t)lane : s1 + ((uint32_t)lane - n0);
+                p.v = (ws.d_maxval + (size_t)frame * (ws.ext_cap / 2))[idx];
+                p.pos = (ws.d_maxpos + (size_t)frame * (ws.ext_cap / 2))[idx];
+            }
+            const uint32_t sz = st & 0x7FFFFFFFu;
+            const uint32_t B0 = e0 >> 5, blk_l = (e0 + sz - 1) >> 5;
+            if ((uint32_t)lane < blk_l - B0) {
+                const long long *src = ws.d_blk + (size_t)frame * 6 * (ws.ext_cap / 32) + (size_t)(B0 + (uint32_t)lane) * 6;
+#pragma unroll
+                for (int q = 0; q < 6; q++) p.b[q] = src[q];
+            }
+            return p;
+        };
+        Pre nxt = prefetch(0);
+        for (int k = 0; k < len; k++) {
+        const Pre cur = nxt;
+        nxt = prefetch(k + 1);
+        wave_sync();
+        const uint32_t st = (uint32_t)__builtin_amdgcn_readlane((int)h_st, k);
         FDBG(0);
-        if (sz < 24) continue; // rejected before the fit
-        FDBG(1);
-        const ck_cluster_t cl = ws.d_clusters[(size_t)frame * ws.cluster_cap + ci];
-        if (sz > (int)cl.count) continue; // (a state word nobody wrote in this call)
+        if (!st) continue;
+        FDBG(1); FDBGV(13, st & 0x7FFFFFFFu);
+        const uint32_t item = (uint32_t)__builtin_amdgcn_readlane((int)h_item, k);
+        const int frame = (int)(item >> 20);
+        const int sz = (int)(st & 0x7FFFFFFFu), reversed = (int)(st >> 31);
+        const uint32_t rep0 = (uint32_t)__builtin_amdgcn_readlane((int)h_rep0, k), rep1 = (uint32_t)__builtin_amdgcn_readlane((int)h_rep1, k);
         if (a.stop_after <= 4) continue;
-        const uint32_t e0 = cl.start + (uint32_t)CK_EXT_HALO * (uint32_t)ci + CK_EXT_PRE, e1 = e0 + (uint32_t)sz; // the cluster's points: positions [e0, e1)
+        const uint32_t e0 = (uint32_t)__builtin_amdgcn_readlane((int)h_e0, k), e1 = e0 + (uint32_t)sz; // the cluster's points: positions [e0, e1)
         const uint32_t *xy = ws.d_ext_xy + (size_t)frame * ws.ext_cap;
         const uint16_t *w16 = ws.d_ext_w + (size_t)frame * ws.ext_cap;
         const double *mval = ws.d_maxval + (size_t)frame * (ws.ext_cap / 2);
@@ -1517,21 +1775,23 @@ __global__ __launch_bounds__(64) void k_tail(FitArgs a) {
         const uint16_t *mpre = ws.d_maxpre + (size_t)frame * (ws.ext_cap / 64);
         const long long *blk = ws.d_blk + (size_t)frame * 6 * (ws.ext_cap / 32);
         const uint8_t *im = a.im + (size_t)frame * a.pitch;
-        auto pt_moments = [&](uint32_t q) { return moments_of(xy[q] & 0x3FFFFFFu, (uint32_t)w16[q] & 0x1FFu); }; // as k_chunk forms them
 
         // ---- the cluster's maxima: one run of k_chunk's lists per span it touches ------------------------------------------------
         const uint32_t s_lo = e0 / CK_SPAN, s_hi = (e1 - 1) / CK_SPAN;
         const int nruns = (int)(s_hi - s_lo) + 1;
         if (nruns > MAXRUN) continue; // cannot happen: sz <= CK_HUGE_CAP
-        auto rank_excl = [&](uint32_t x, uint32_t s) -> uint32_t { // maxima of span s before position x (clamped: bounded even on garbage)
-            if (x == s * CK_SPAN) return 0u;
-            const uint32_t w = (x - 1) >> 6, nb = x - (w << 6);
-            const unsigned long long m = mmask[w] & (nb >= 64 ? ~0ull : ((1ull << nb) - 1ull));
-            const uint32_t r = (uint32_t)mpre[w] + (uint32_t)__popcll(m);
-            return r > CK_SPAN / 2 ? CK_SPAN / 2 : r;
-        };
         uint32_t nmax_u = 0;
         if (tid == 0) sBad = 0;
+        bool prefetched = false; // this lane's maximum is in `cur`
+        if (nruns <= 2) { // bounded by the head lane already
+            const uint32_t n0 = (uint32_t)__builtin_amdgcn_readlane((int)h_n0, k), n1 = (uint32_t)__builtin_amdgcn_readlane((int)h_n1, k);
+            if (tid == 0) {
+                sRunStart[0] = (uint32_t)__builtin_amdgcn_readlane((int)h_s0, k); sRunN[0] = n0; sRunOff[0] = 0; sRunO[0] = (int)(s_lo * CK_SPAN) - (int)e0;
+                sRunStart[1] = (uint32_t)__builtin_amdgcn_readlane((int)h_s1, k); sRunN[1] = n1; sRunOff[1] = n0; sRunO[1] = (int)(s_hi * CK_SPAN) - (int)e0;
+            }
+            nmax_u = n0 + n1;
+            prefetched = nmax_u <= 64u;
+        } else
         for (int rb = 0; rb < nruns; rb += 64) {
             const int r = rb + lane;
             uint32_t n = 0, start = 0;
@@ -1539,7 +1799,7 @@ __global__ __launch_bounds__(64) void k_tail(FitArgs a) {
             if (r < nruns) {
                 const uint32_t s = s_lo + (uint32_t)r;
                 const uint32_t lo = max(e0, s * CK_SPAN), hi = min(e1, s * CK_SPAN + CK_SPAN);
-                const uint32_t r0 = rank_excl(lo, s), r1 = rank_excl(hi, s);
+                const uint32_t r0 = rank_excl(mmask, mpre, lo, s), r1 = rank_excl(mmask, mpre, hi, s);
                 n = r1 > r0 ? r1 - r0 : 0u;
                 start = s * (CK_SPAN / 2) + r0;
                 obase = (int)(s * CK_SPAN) - (int)e0;
@@ -1548,7 +1808,7 @@ __global__ __launch_bounds__(64) void k_tail(FitArgs a) {
             if (r < nruns) { sRunStart[r] = start; sRunN[r] = n; sRunOff[r] = nmax_u + incl - n; sRunO[r] = obase; }
             nmax_u += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
         }
-        __syncthreads();
+        wave_sync();
         const int nmax_all = (int)nmax_u;
         FDBGV(10, nmax_all);
         if (nmax_all < 4) continue;
@@ -1560,6 +1820,9 @@ __global__ __launch_bounds__(64) void k_tail(FitArgs a) {
         if (nmax_all <= 64) { // one maximum per lane
             double myv = 0.0;
             int myo = -1;
+            if (prefetched) {
+                if (lane < nmax_all) { myv = cur.v; myo = sRunO[(uint32_t)lane < sRunN[0] ? 0 : 1] + (int)cur.pos; }
+            } else
             for (int r = 0; r < nruns; r++) {
                 const uint32_t off = sRunOff[r], n = sRunN[r];
                 if ((uint32_t)lane >= off && (uint32_t)lane < off + n) {
@@ -1632,7 +1895,7 @@ __global__ __launch_bounds__(64) void k_tail(FitArgs a) {
                 }
             }
         }
-        __syncthreads();
+        wave_sync();
         FDBGV(11, nsel); FDBGV(12, sBad);
         if (nsel < 4 || nsel > MAXSEL || sBad) continue;
         FDBG(3);
@@ -1642,64 +1905,83 @@ __global__ __launch_bounds__(64) void k_tail(FitArgs a) {
         // ---- 5b. moment prefix sums at the selected maxima: aligned block sums (wave scan) + the points beyond the last block ----------
         const uint32_t B0 = e0 >> 5, blk_l = (e1 - 1) >> 5; // blocks of the first and of the last point
         auto target_pos = [&](int t) -> uint32_t { return t < nsel ? e0 + (uint32_t)sSelIdx[t] : e1 - 1; };
+        // four lanes per target, eight positions each: from the target's block boundary to the target (head: to the position before
+        // the first point).  Their loads are issued first and are under way while the block sums are scanned
+        const int pt = lane >> 2, ppart = lane & 3;
+        const bool plive = pt < nsel || pt == T_TAIL || pt == T_HEAD;
+        uint32_t pqs = 1, pqe = 0; // inclusive range; empty when pqe + 1 == pqs
+        if (plive) {
+            if (pt == T_HEAD) { pqs = B0 << 5; pqe = e0 - 1; }
+            else { const uint32_t pm = target_pos(pt); pqs = pm & ~31u; pqe = pm; }
+        }
+        uint32_t pxy[8], pw[8];
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            const uint32_t q = pqs + (uint32_t)(ppart * 8 + e);
+            pxy[e] = 0; pw[e] = 0;
+            if (plive && q <= pqe && q >= pqs) { pxy[e] = xy[q]; pw[e] = w16[q]; }
+        }
         for (int i = tid; i < (MAXSEL + 2) * 6; i += NTH) sF6[i / 6][i % 6] = 0;
-        __syncthreads();
+        wave_sync();
         {
             const int nfull = (int)(blk_l - B0); // blocks B0 .. blk_l - 1: what a target's prefix can need
+            // lane t (< 13) knows where target t's prefix ends: the sums through the block before the target's
+            const int my_kk = lane <= nsel ? (int)((target_pos(lane < nsel ? lane : T_TAIL) >> 5) - B0) - 1 : -2;
             long long carry[6] = {0, 0, 0, 0, 0, 0};
             for (int rb = 0; rb < nfull; rb += 64) {
                 const int b = rb + lane;
                 long long v[6] = {0, 0, 0, 0, 0, 0};
-                if (b < nfull) {
+                if (rb == 0) {
+#pragma unroll
+                    for (int q = 0; q < 6; q++) v[q] = cur.b[q]; // (fetched while the cluster before this one was fitted; 0 past the cluster's blocks)
+                } else if (b < nfull) {
                     const long long *src = blk + (size_t)(B0 + (uint32_t)b) * 6;
 #pragma unroll
                     for (int q = 0; q < 6; q++) v[q] = src[q];
                 }
 #pragma unroll
                 for (int q = 0; q < 6; q++) v[q] = (long long)wave_scan_u64((unsigned long long)v[q]) + carry[q];
-                // a target in block k needs the sums through block k - 1
-                for (int t = 0; t <= nsel; t++) {
-                    const int tt = t < nsel ? t : T_TAIL;
-                    const int kk = (int)((target_pos(tt) >> 5) - B0) - 1;
-                    if (kk == b)
+                // lane t picks its target's prefix from the lane that holds it
+                const int srcl = my_kk - rb;
+                const bool mine = srcl >= 0 && srcl < 64;
 #pragma unroll
-                        for (int q = 0; q < 6; q++) sF6[tt][q] = v[q];
+                for (int q = 0; q < 6; q++) {
+                    const long long got = __shfl(v[q], mine ? srcl : 0, 64);
+                    if (mine) sF6[lane < nsel ? lane : T_TAIL][q] = got;
                 }
 #pragma unroll
                 for (int q = 0; q < 6; q++) carry[q] = readlane_i64(v[q], 63);
             }
         }
-        {   // four lanes per target, eight positions each: from the target's block boundary to the target (head: to the position before the first point)
-            const int t = lane >> 2, part = lane & 3;
-            M6 m = m6_zero();
-            const bool live = t < nsel || t == T_TAIL || t == T_HEAD;
-            if (live && t < MAXSEL + 2) {
-                uint32_t qs, qe; // inclusive range; empty when qe + 1 == qs
-                if (t == T_HEAD) { qs = B0 << 5; qe = e0 - 1; }
-                else { const uint32_t pm = target_pos(t); qs = pm & ~31u; qe = pm; }
+        wave_sync(); // the block prefixes are in place
+        {
+            M6 m = m6_zero(), self = m6_zero();
 #pragma unroll
-                for (int e = 0; e < 8; e++) {
-                    const uint32_t q = qs + (uint32_t)(part * 8 + e);
-                    if (q <= qe && q >= qs) m = m6_add(m, pt_moments(q));
+            for (int e = 0; e < 8; e++) {
+                const uint32_t q = pqs + (uint32_t)(ppart * 8 + e);
+                if (plive && q <= pqe && q >= pqs) {
+                    const M6 pm6 = moments_of(pxy[e] & 0x3FFFFFFu, pw[e] & 0x1FFu); // as k_chunk forms them
+                    m = m6_add(m, pm6);
+                    if (q == pqe) self = pm6;
                 }
             }
             long long pv[6] = {m.Mx, m.My, m.Mxx, m.Mxy, m.Myy, m.W};
+            long long sv[6] = {self.Mx, self.My, self.Mxx, self.Mxy, self.Myy, self.W};
 #pragma unroll
             for (int q = 0; q < 6; q++)
 #pragma unroll
-                for (int d = 2; d >= 1; d >>= 1) pv[q] += __shfl_xor(pv[q], d, 64);
-            if (live && t < MAXSEL + 2 && part == 0)
+                for (int d = 2; d >= 1; d >>= 1) { pv[q] += __shfl_xor(pv[q], d, 64); sv[q] += __shfl_xor(sv[q], d, 64); }
+            if (plive && ppart == 0) {
+                if (pt < nsel) {
 #pragma unroll
-                for (int q = 0; q < 6; q++) sPart[t][q] = pv[q];
-        }
-        __syncthreads();
-        if (tid < nsel) {
-            const M6 self = pt_moments(e0 + (uint32_t)sSelIdx[tid]);
-            const long long sv[6] = {self.Mx, self.My, self.Mxx, self.Mxy, self.Myy, self.W};
+                    for (int q = 0; q < 6; q++) { const long long v = sF6[pt][q] + pv[q]; sSelI[pt][q] = v; sSelE[pt][q] = v - sv[q]; }
+                } else {
 #pragma unroll
-            for (int q = 0; q < 6; q++) { const long long v = sF6[tid][q] + sPart[tid][q]; sSelI[tid][q] = v; sSelE[tid][q] = v - sv[q]; }
+                    for (int q = 0; q < 6; q++) sPart[pt][q] = pv[q];
+                }
+            }
         }
-        __syncthreads();
+        wave_sync();
         M6 total; // the cluster's own points only
         {
             long long tv[6];
@@ -1735,7 +2017,7 @@ __global__ __launch_bounds__(64) void k_tail(FitArgs a) {
                 sF[sb * MAXSEL + sa] = f;
             }
         }
-        __syncthreads();
+        wave_sync();
         double best = HUGE_VAL;
         int bestc = 1 << 30;
         {
@@ -1834,7 +2116,7 @@ __global__ __launch_bounds__(64) void k_tail(FitArgs a) {
             }
             if (tid == 0) sFlag = all_ok;
         }
-        __syncthreads();
+        wave_sync();
         if (!sFlag) continue;
         FDBG(6);
         if (a.refine) { // edge refinement (oracle refine_edges), as in k_fit: lane (edge, k) evaluates sample 16 * round + k, one lane per edge accumulates in sample order
@@ -1851,7 +2133,7 @@ __global__ __launch_bounds__(64) void k_tail(FitArgs a) {
 #pragma unroll
             for (int d = 32; d >= 1; d >>= 1) max_samples = max(max_samples, __shfl_xor(max_samples, d, 64));
             double Mx = 0, My = 0, Mxx = 0, Mxy = 0, Myy = 0, N = 0;
-            __syncthreads(); // the pair table's bytes become the sample buffer
+            wave_sync(); // the pair table's bytes become the sample buffer
             for (int base = 0; base < max_samples; base += 16) {
                 {
                     const int sidx = base + k;
@@ -1881,14 +2163,14 @@ __global__ __launch_bounds__(64) void k_tail(FitArgs a) {
                     }
                     sRefine[edge][k][0] = bx; sRefine[edge][k][1] = by;
                 }
-                __syncthreads();
+                wave_sync();
                 if (k == 0)
                     for (int q = 0; q < 16 && base + q < nsamples; q++) {
                         double bx = sRefine[edge][q][0], by = sRefine[edge][q][1];
                         if (bx != bx) continue;
                         Mx += bx; My += by; Mxx += bx * bx; Mxy += bx * by; Myy += by * by; N += 1.0;
                     }
-                __syncthreads();
+                wave_sync();
             }
             if (k == 0) {
                 double line[4];
@@ -1912,7 +2194,7 @@ __global__ __launch_bounds__(64) void k_tail(FitArgs a) {
                 }
                 for (int q = 0; q < 4; q++) sLines[edge][q] = line[q];
             }
-            __syncthreads();
+            wave_sync();
             if (tid == 0)
                 for (int i = 0; i < 4; i++) {
                     int j = (i + 1) & 3;
@@ -1933,10 +2215,11 @@ __global__ __launch_bounds__(64) void k_tail(FitArgs a) {
             if (qi < (uint32_t)ws.quad_cap) {
                 ck_quad_t q;
                 for (int i = 0; i < 4; i++) { q.p[i][0] = sQuad[i][0]; q.p[i][1] = sQuad[i][1]; }
-                q.reversed_border = reversed; q.rep0 = cl.rep0; q.rep1 = cl.rep1;
+                q.reversed_border = reversed; q.rep0 = rep0; q.rep1 = rep1;
                 ws.d_quads[(size_t)frame * ws.quad_cap + qi] = q;
             } else atomicOr(&counters[CK_CNT_STATUS], (uint32_t)CK_FRAME_QUADS_OVERFLOW);
         }
+        } // clusters of the chunk
     }
 }
 
@@ -2090,21 +2373,23 @@ int ck_launch_fit_quads(ck_handle *h, const uint8_t *qframes, int qstride, size_
     static const int gk_env = getenv("CK_FIT_GK") ? atoi(getenv("CK_FIT_GK")) : 0; // (experiment: bit c set = class c keeps its keys in global memory: small LDS, more workgroups per CU)
     const int gk_mask = ws.d_hscratch ? gk_env : 0;
     static const int skip_mask = getenv("CK_FIT_SKIP") ? atoi(getenv("CK_FIT_SKIP")) : 0; // (diagnostics: bit c set = class c is not launched)
-    // The split fit (k_fit<..., SPLIT> per class -> k_chunk over all positions -> k_tail over all clusters): CK_FIT_FLAT = 0 never,
-    // 1 for calls that run their classes one after the other, 2 always (default 0 while the split path is slower: 10.8 against 9.8 ms)
-    static const int flat_env = getenv("CK_FIT_FLAT") ? atoi(getenv("CK_FIT_FLAT")) : 0;
-    const bool flat = flat_env >= 2 || (flat_env == 1 && !side_by_side);
+    // The split fit (k_seq per class -> k_chunk over all positions -> k_tail over all clusters): CK_FIT_FLAT = 0 never, 2 always,
+    // 1 (default): for calls that run their classes one after the other AND bring enough pixels — its three stages each ramp a
+    // persistent grid up and down, which a quarter-size batch notices (1280x800 x 256 at quad_decimate 2: 2.85 against 2.52 ms
+    // unsplit; at full resolution 9.75 against 9.94, 1920x1080 21.4 against 22.7, 2448x2048 x 128 27.8 against 31.5)
+    static const int flat_env = getenv("CK_FIT_FLAT") ? atoi(getenv("CK_FIT_FLAT")) : 1;
+    const bool flat = flat_env >= 2 || (flat_env == 1 && !side_by_side && (size_t)n * (size_t)h->qw * (size_t)h->qh >= ((size_t)100 << 20));
     auto launch_split = [&](int c) {
         switch (c) {
-        case 0: hipLaunchKernelGGL((k_fit<64, 512, 64, true, 4, false, true>), dim3((unsigned)(cus * 16)), dim3(64), 0, cs[c], a); break;
-        case 7: hipLaunchKernelGGL((k_fit<64, 256, 64, true, 4, false, true>), dim3((unsigned)(cus * 16)), dim3(64), 0, cs[c], a); break;
-        case 6: hipLaunchKernelGGL((k_fit<128, 1024, 128, true, 4, false, true>), dim3((unsigned)(cus * 8)), dim3(128), 0, cs[c], a); break;
-        case 1: hipLaunchKernelGGL((k_fit<256, 2048, 224, true, 4, false, true>), dim3((unsigned)(cus * 4)), dim3(256), 0, cs[c], a); break;
-        case 2: hipLaunchKernelGGL((k_fit<256, 4096, 512, true, 2, false, true>), dim3((unsigned)(cus * 2)), dim3(256), 0, cs[c], a); break;
-        case 3: hipLaunchKernelGGL((k_fit<512, 8192, 896, true, 2, false, true>), dim3((unsigned)cus), dim3(512), 0, cs[c], a); break;
-        case 4: hipLaunchKernelGGL((k_fit<512, 16384, 512, false, 2, false, true>), dim3((unsigned)cus), dim3(512), 0, cs[c], a); break;
+        case 0: hipLaunchKernelGGL((k_seq<64, 512, true, 4, false>), dim3((unsigned)(cus * 16)), dim3(64), 0, cs[c], a); break;
+        case 7: hipLaunchKernelGGL((k_seq<64, 256, true, 4, false>), dim3((unsigned)(cus * 16)), dim3(64), 0, cs[c], a); break;
+        case 6: hipLaunchKernelGGL((k_seq<128, 1024, true, 4, false>), dim3((unsigned)(cus * 8)), dim3(128), 0, cs[c], a); break;
+        case 1: hipLaunchKernelGGL((k_seq<256, 2048, true, 4, false>), dim3((unsigned)(cus * 4)), dim3(256), 0, cs[c], a); break;
+        case 2: hipLaunchKernelGGL((k_seq<256, 4096, true, 2, false>), dim3((unsigned)(cus * 2)), dim3(256), 0, cs[c], a); break;
+        case 3: hipLaunchKernelGGL((k_seq<512, 8192, true, 2, false>), dim3((unsigned)cus), dim3(512), 0, cs[c], a); break;
+        case 4: hipLaunchKernelGGL((k_seq<512, 16384, false, 2, false>), dim3((unsigned)cus), dim3(512), 0, cs[c], a); break;
         default:
-            if (ws.d_hscratch) hipLaunchKernelGGL((k_fit<512, CK_HUGE_CAP, 896, false, 2, true, true>), dim3((unsigned)CK_HUGE_WGS), dim3(512), 0, cs[c], a);
+            if (ws.d_hscratch) hipLaunchKernelGGL((k_seq<512, CK_HUGE_CAP, false, 2, true>), dim3((unsigned)CK_HUGE_WGS), dim3(512), 0, cs[c], a);
             break;
         }
     };
@@ -2148,7 +2433,7 @@ int ck_launch_fit_quads(ck_handle *h, const uint8_t *qframes, int qstride, size_
         unsigned gx = (unsigned)((cus * chunk_wgs + n - 1) / n);
         if (gx < 8) gx = 8;
         if (gx > spans) gx = spans;
-        if (a.stop_after > 3) hipLaunchKernelGGL(k_chunk, dim3(gx, (unsigned)n), dim3(256), 0, h->stream, ws);
+        if (a.stop_after > 3) hipLaunchKernelGGL(k_chunk, dim3(gx, (unsigned)n), dim3(256), 0, h->stream, ws, h->qw, h->qh);
         a.list = lists + (size_t)CK_FIT_CLASSES * list_cap; a.list_count = list_counts + CK_FIT_CLASSES; a.head = heads + CK_FIT_CLASSES;
         hipLaunchKernelGGL(k_tail, dim3((unsigned)(cus * tail_wgs)), dim3(64), 0, h->stream, a);
     }

@@ -48,3 +48,17 @@ def test_stress_ingest(built):
 def test_stress_sqpnp(oracle):
     import stress_sqpnp
     assert stress_sqpnp.run(256, 108) == 0
+
+
+@pytest.mark.parametrize("caps", [False, True])
+def test_stress_detect_split_fit_on_small_calls(oracle, caps):
+    """A call of a few frames runs the unsplit quad fit (its size classes side by side); a batch runs the split one (k_seq -> k_chunk ->
+    k_tail).  CK_FIT_FLAT=2 (read once per process, hence the child) sends the small calls of the stress cases through the split
+    path too — with undersized, poisoned buffers in the second run."""
+    import os, subprocess, sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, CK_FIT_FLAT="2")
+    if caps: env.update(STRESS_CAPS="1", CK_POISON="1")
+    r = subprocess.run([sys.executable, os.path.join(here, "stress_detect.py"), "40", "111" if caps else "109"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert '"mismatching_frames": 0' in r.stdout, r.stdout[-2000:]

@@ -1,0 +1,5 @@
+#!/bin/bash
+# split quad fit: stage time with k_tail cut short after phase k (4: heads only, 5: selection, 6: prefix sums at the maxima, 7: pair fits + subsets, 99: all)
+for s in ${STOPS:-4 5 6 7 99}; do
+  CK_FIT_FLAT=1 CK_FIT_STOP_AFTER=$s python tools/bench_detect.py 1280 800 256 3 1 2>/dev/null | tail -n 1 | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('stop=$s', 'quads', d['quads'])"
+done
