@@ -1345,6 +1345,7 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(WPS, 8))) v
             const ck_packed_point *pts = ws.d_points + (size_t)frame * ws.ext_cap + sHStart[k];
             ck_packed_point rawp[PF ? EPL : 1];
             if constexpr (PF) {
+                __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): this cluster's points are here before the next one's are asked for (see k_tail)
 #pragma unroll
                 for (int e = 0; e < EPL; e++) rawp[e] = nxt[e];
                 if (k + 1 < len) fetch(k + 1);
@@ -1457,7 +1458,7 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(WPS, 8))) v
 // the doubles are formed by the operations of k_fit's chunk loop in the same order: the same bits.
 constexpr int KL = 1024, KOFF = 32;
 static_assert(CK_SPAN == 960 && KOFF >= CK_EXT_PRE + 3 && KL - KOFF - CK_SPAN >= CK_EXT_POST + 4, "span geometry");
-__global__ __launch_bounds__(256) void k_chunk(ck_stage_ws ws, int qw, int qh) {
+__device__ __forceinline__ void k_chunk_body(const ck_stage_ws &ws, int qw, int qh) {
     __shared__ __attribute__((aligned(16))) unsigned long long sP64[3][KL]; // inclusive sums from the first loaded position: Mxx, Mxy, Myy
     __shared__ __attribute__((aligned(16))) uint32_t sP32[3][KL];           // Mx, My, W (a window's sums stay below 2^32: differences are exact)
     __shared__ double sErr[KL];
@@ -1495,7 +1496,7 @@ __global__ __launch_bounds__(256) void k_chunk(ck_stage_ws ws, int qw, int qh) {
     uint32_t ww[4] = {gather_w(x4.x), gather_w(x4.y), gather_w(x4.z), gather_w(x4.w)};
     for (uint32_t s = blockIdx.x; (unsigned long long)s * CK_SPAN < ext_total; s += gridDim.x) {
         // 1. four consecutive positions per thread: moments, running sums, one scan over the workgroup
-        const uint4 nx4 = load_xy(s + gridDim.x);
+        __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): this span's points and weights (asked for during the span before) are here
         const long long p0 = (long long)s * CK_SPAN - KOFF + 4 * tid;
         const uint32_t xw[4] = {x4.x, x4.y, x4.z, x4.w};
         if (tid >= KOFF / 4 && tid < (KOFF + CK_SPAN) / 4) // the positions this span decides: their weights stay for k_tail
@@ -1536,6 +1537,9 @@ __global__ __launch_bounds__(256) void k_chunk(ck_stage_ws ws, int qw, int qh) {
             const uint32_t k = (xw[e] >> 26) & 31u;
             sKsz[j] = (uint8_t)(k > 20u ? 20u : k);
         }
+        // the next span's points: asked for here, behind this span's own wait (the compiler's waits are for "everything outstanding":
+        // at the top of the loop the request would be waited for at once); their weights once the errors are done
+        const uint4 nx4 = load_xy(s + gridDim.x);
         lds_barrier();
         // 2. moment sums of the span's 30 aligned blocks of 32 positions (Mx, My, Mxx, Mxy, Myy, W: the order of M6)
         if (tid < 180) {
@@ -1619,6 +1623,8 @@ __global__ __launch_bounds__(256) void k_chunk(ck_stage_ws ws, int qw, int qh) {
     }
 }
 
+__global__ __launch_bounds__(256) void k_chunk(ck_stage_ws ws, int qw, int qh) { k_chunk_body(ws, qw, qh); }
+
 __device__ __forceinline__ double readlane_f64(double v, int l) {
     const unsigned long long u = (unsigned long long)__double_as_longlong(v);
     const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)u, l), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(u >> 32), l);
@@ -1645,7 +1651,7 @@ __device__ unsigned int g_flat_dbg[32];
 #define FDBG(k)
 #define FDBGV(k, v)
 #endif
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_tail(FitArgs a) {
+__device__ __forceinline__ void k_tail_body(const FitArgs &a) {
     constexpr int NTH = 64, T_TAIL = MAXSEL, T_HEAD = MAXSEL + 1;
     __shared__ __attribute__((aligned(16))) unsigned char sPraw[sizeof(PairFit) * MAXSEL * MAXSEL];
     __shared__ long long sSelI[2 * MAXSEL][6];
@@ -1722,18 +1728,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
                 }
             }
         }
-        // what lane `lane` of cluster k needs first: its maximum (if the cluster has at most 64, in at most two runs) and the
-        // sums of the cluster's first 64 blocks
-        struct Pre { double v; uint32_t pos; long long b[6]; };
+        // what lane `lane` of cluster k needs first: its maximum (if the cluster has at most 64, in at most two runs).  (The sums of the
+        // cluster's first 64 blocks travelled this way too: twelve more registers per stage, seven spilled — and a build of this kernel
+        // that spills has returned wrong results, see the note at the kernel's definition)
+        struct Pre { double v; uint32_t pos; };
         auto prefetch = [&](int k) -> Pre {
             Pre p;
             p.v = 0.0; p.pos = 0;
-#pragma unroll
-            for (int q = 0; q < 6; q++) p.b[q] = 0;
             if (k >= len) return p;
             const uint32_t st = (uint32_t)__builtin_amdgcn_readlane((int)h_st, k);
             if (!st) return p;
-            const uint32_t item = (uint32_t)__builtin_amdgcn_readlane((int)h_item, k), e0 = (uint32_t)__builtin_amdgcn_readlane((int)h_e0, k);
+            const uint32_t item = (uint32_t)__builtin_amdgcn_readlane((int)h_item, k);
             const int frame = (int)(item >> 20);
             const int nruns = __builtin_amdgcn_readlane(h_nruns, k);
             const uint32_t n0 = (uint32_t)__builtin_amdgcn_readlane((int)h_n0, k), n1 = (uint32_t)__builtin_amdgcn_readlane((int)h_n1, k);
@@ -1743,17 +1748,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
                 p.v = (ws.d_maxval + (size_t)frame * (ws.ext_cap / 2))[idx];
                 p.pos = (ws.d_maxpos + (size_t)frame * (ws.ext_cap / 2))[idx];
             }
-            const uint32_t sz = st & 0x7FFFFFFFu;
-            const uint32_t B0 = e0 >> 5, blk_l = (e0 + sz - 1) >> 5;
-            if ((uint32_t)lane < blk_l - B0) {
-                const long long *src = ws.d_blk + (size_t)frame * 6 * (ws.ext_cap / 32) + (size_t)(B0 + (uint32_t)lane) * 6;
-#pragma unroll
-                for (int q = 0; q < 6; q++) p.b[q] = src[q];
-            }
             return p;
         };
         Pre nxt = prefetch(0);
         for (int k = 0; k < len; k++) {
+        // what was fetched for this cluster has to be here BEFORE the next cluster's fetch is issued: the compiler's waits inside the
+        // loops below are for "everything outstanding", and would otherwise sit on the fetch just issued
+        __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0)
         const Pre cur = nxt;
         nxt = prefetch(k + 1);
         wave_sync();
@@ -1822,29 +1823,35 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
             int myo = -1;
             if (prefetched) {
                 if (lane < nmax_all) { myv = cur.v; myo = sRunO[(uint32_t)lane < sRunN[0] ? 0 : 1] + (int)cur.pos; }
-            } else
-            for (int r = 0; r < nruns; r++) {
-                const uint32_t off = sRunOff[r], n = sRunN[r];
-                if ((uint32_t)lane >= off && (uint32_t)lane < off + n) {
-                    const uint32_t idx = sRunStart[r] + ((uint32_t)lane - off);
-                    myv = mval[idx];
-                    myo = sRunO[r] + (int)mpos[idx];
+            } else {
+                for (int r = 0; r < nruns; r++) {
+                    const uint32_t off = sRunOff[r], n = sRunN[r];
+                    if ((uint32_t)lane >= off && (uint32_t)lane < off + n) {
+                        const uint32_t idx = sRunStart[r] + ((uint32_t)lane - off);
+                        myv = mval[idx];
+                        myo = sRunO[r] + (int)mpos[idx];
+                    }
                 }
+                __builtin_amdgcn_s_waitcnt(0x0F70); // (here, not inside the loop below, where it would also hold up the common path)
             }
             const bool has = lane < nmax_all;
-            double thr = 0.0;
+            // the values are compared through their order-preserving integer image (one 64-bit integer compare against an f64 compare and
+            // its wait states, twice per round of the loop): a cluster's smoothed errors are never NaN and never -0 (the sums start from +0)
+            const unsigned long long myb = (unsigned long long)__double_as_longlong(myv);
+            const unsigned long long myk = (myb >> 63) ? ~myb : (myb | (1ull << 63));
+            unsigned long long thrk = 0ull;
             if (use_thr) {
                 int gt = 0, ge = 0;
                 for (int j = 0; j < nmax_all; j++) {
-                    const double u = readlane_f64(myv, j);
-                    gt += (u > myv) ? 1 : 0;
-                    ge += (u >= myv) ? 1 : 0;
+                    const unsigned long long u = (unsigned long long)readlane_i64((long long)myk, j);
+                    gt += (u > myk) ? 1 : 0;
+                    ge += (u >= myk) ? 1 : 0;
                 }
                 const unsigned long long hit = __ballot(has && gt <= a.max_nmaxima && a.max_nmaxima < ge);
                 if (hit == 0ull) continue; // (values that do not order: garbage)
-                thr = readlane_f64(myv, __builtin_ctzll(hit));
+                thrk = (unsigned long long)readlane_i64((long long)myk, __builtin_ctzll(hit));
             }
-            const bool keep = has && !(use_thr && myv <= thr);
+            const bool keep = has && !(use_thr && myk <= thrk);
             const unsigned long long kb = __ballot(keep);
             nsel = __popcll(kb);
             if (keep) {
@@ -1921,6 +1928,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
             pxy[e] = 0; pw[e] = 0;
             if (plive && q <= pqe && q >= pqs) { pxy[e] = xy[q]; pw[e] = w16[q]; }
         }
+        uint32_t sxy = 0, sw = 0; // the target itself (the exclusive sum is the inclusive one less its moments)
+        if (pt < nsel && ppart == 0) { sxy = xy[pqe]; sw = w16[pqe]; }
         for (int i = tid; i < (MAXSEL + 2) * 6; i += NTH) sF6[i / 6][i % 6] = 0;
         wave_sync();
         {
@@ -1931,10 +1940,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
             for (int rb = 0; rb < nfull; rb += 64) {
                 const int b = rb + lane;
                 long long v[6] = {0, 0, 0, 0, 0, 0};
-                if (rb == 0) {
-#pragma unroll
-                    for (int q = 0; q < 6; q++) v[q] = cur.b[q]; // (fetched while the cluster before this one was fitted; 0 past the cluster's blocks)
-                } else if (b < nfull) {
+                if (b < nfull) {
                     const long long *src = blk + (size_t)(B0 + (uint32_t)b) * 6;
 #pragma unroll
                     for (int q = 0; q < 6; q++) v[q] = src[q];
@@ -1955,24 +1961,26 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
         }
         wave_sync(); // the block prefixes are in place
         {
-            M6 m = m6_zero(), self = m6_zero();
+            // eight points per lane: the first-order sums fit 32 bits (8 x 511 x 8192), a position outside the range holds weight 0
+            uint32_t aMx = 0, aMy = 0, aW = 0;
+            unsigned long long aMxx = 0, aMxy = 0, aMyy = 0;
 #pragma unroll
             for (int e = 0; e < 8; e++) {
-                const uint32_t q = pqs + (uint32_t)(ppart * 8 + e);
-                if (plive && q <= pqe && q >= pqs) {
-                    const M6 pm6 = moments_of(pxy[e] & 0x3FFFFFFu, pw[e] & 0x1FFu); // as k_chunk forms them
-                    m = m6_add(m, pm6);
-                    if (q == pqe) self = pm6;
-                }
+                const uint32_t X = ((pxy[e] >> 13) & 0x1FFFu) + 1, Y = (pxy[e] & 0x1FFFu) + 1, Wt = pw[e] & 0x1FFu; // as k_chunk forms them
+                const uint32_t wx = Wt * X, wy = Wt * Y;
+                aMx += wx; aMy += wy; aW += Wt;
+                aMxx += (unsigned long long)wx * X; aMxy += (unsigned long long)wx * Y; aMyy += (unsigned long long)wy * Y;
             }
-            long long pv[6] = {m.Mx, m.My, m.Mxx, m.Mxy, m.Myy, m.W};
-            long long sv[6] = {self.Mx, self.My, self.Mxx, self.Mxy, self.Myy, self.W};
 #pragma unroll
-            for (int q = 0; q < 6; q++)
-#pragma unroll
-                for (int d = 2; d >= 1; d >>= 1) { pv[q] += __shfl_xor(pv[q], d, 64); sv[q] += __shfl_xor(sv[q], d, 64); }
+            for (int d = 2; d >= 1; d >>= 1) {
+                aMx += __shfl_xor(aMx, d, 64); aMy += __shfl_xor(aMy, d, 64); aW += __shfl_xor(aW, d, 64);
+                aMxx += __shfl_xor(aMxx, d, 64); aMxy += __shfl_xor(aMxy, d, 64); aMyy += __shfl_xor(aMyy, d, 64);
+            }
             if (plive && ppart == 0) {
+                const long long pv[6] = {(long long)aMx, (long long)aMy, (long long)aMxx, (long long)aMxy, (long long)aMyy, (long long)aW};
                 if (pt < nsel) {
+                    const M6 self = moments_of(sxy & 0x3FFFFFFu, sw & 0x1FFu);
+                    const long long sv[6] = {self.Mx, self.My, self.Mxx, self.Mxy, self.Myy, self.W};
 #pragma unroll
                     for (int q = 0; q < 6; q++) { const long long v = sF6[pt][q] + pv[q]; sSelI[pt][q] = v; sSelE[pt][q] = v - sv[q]; }
                 } else {
@@ -2223,6 +2231,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
     }
 }
 
+// Register budget: four waves per SIMD (126 registers, nothing spilled).  A build for five (96 registers, 59 of them spilled) looked 7 %
+// faster and was WRONG: detections went missing at 1920x1080 and 2448x2048 and copies of one frame differed — the heads of a
+// chunk live in registers that other lanes read with v_readlane, and did not survive being spilled.  Do not let this kernel spill.
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_tail(FitArgs a) { k_tail_body(a); }
+
 // Gradient-magnitude weights of a whole batch in one streaming pass (1 B read, 2 B written per pixel): the fitter then needs
 // ONE 2-byte gather per contour point instead of four byte gathers.  Four pixels per thread: three aligned 4-byte loads (row
 // above, row, row below) plus the two bytes beside the group.  Image rows are padded to 16 bytes (staged frames and the decimated
@@ -2379,13 +2392,17 @@ int ck_launch_fit_quads(ck_handle *h, const uint8_t *qframes, int qstride, size_
     // unsplit; at full resolution 9.75 against 9.94, 1920x1080 21.4 against 22.7, 2448x2048 x 128 27.8 against 31.5)
     static const int flat_env = getenv("CK_FIT_FLAT") ? atoi(getenv("CK_FIT_FLAT")) : 1;
     const bool flat = flat_env >= 2 || (flat_env == 1 && !side_by_side && (size_t)n * (size_t)h->qw * (size_t)h->qh >= ((size_t)100 << 20));
+    static const int seq_alt = getenv("CK_SEQ_ALT") ? atoi(getenv("CK_SEQ_ALT")) : 0; // (diagnostics: bit c = class c of k_seq with a tighter register budget)
     auto launch_split = [&](int c) {
         switch (c) {
+        // (tighter register budgets for the four classes below — six / eight / five / five waves per SIMD — measured: no difference)
         case 0: hipLaunchKernelGGL((k_seq<64, 512, true, 4, false>), dim3((unsigned)(cus * 16)), dim3(64), 0, cs[c], a); break;
         case 7: hipLaunchKernelGGL((k_seq<64, 256, true, 4, false>), dim3((unsigned)(cus * 16)), dim3(64), 0, cs[c], a); break;
         case 6: hipLaunchKernelGGL((k_seq<128, 1024, true, 4, false>), dim3((unsigned)(cus * 8)), dim3(128), 0, cs[c], a); break;
         case 1: hipLaunchKernelGGL((k_seq<256, 2048, true, 4, false>), dim3((unsigned)(cus * 4)), dim3(256), 0, cs[c], a); break;
-        case 2: hipLaunchKernelGGL((k_seq<256, 4096, true, 2, false>), dim3((unsigned)(cus * 2)), dim3(256), 0, cs[c], a); break;
+        case 2: if (seq_alt & 16) hipLaunchKernelGGL((k_seq<256, 4096, true, 2, false>), dim3((unsigned)(cus * 2)), dim3(256), 0, cs[c], a);
+                else hipLaunchKernelGGL((k_seq<256, 4096, true, 3, false>), dim3((unsigned)(cus * 3)), dim3(256), 0, cs[c], a); // (three workgroups per CU at 168 registers: 8.58 against 8.78 ms with two at 256)
+                break;
         case 3: hipLaunchKernelGGL((k_seq<512, 8192, true, 2, false>), dim3((unsigned)cus), dim3(512), 0, cs[c], a); break;
         case 4: hipLaunchKernelGGL((k_seq<512, 16384, false, 2, false>), dim3((unsigned)cus), dim3(512), 0, cs[c], a); break;
         default:
@@ -2433,6 +2450,7 @@ int ck_launch_fit_quads(ck_handle *h, const uint8_t *qframes, int qstride, size_
         unsigned gx = (unsigned)((cus * chunk_wgs + n - 1) / n);
         if (gx < 8) gx = 8;
         if (gx > spans) gx = spans;
+        // (k_chunk's register count capped at 96 / 80: no difference — three workgroups per CU either way, its LDS decides)
         if (a.stop_after > 3) hipLaunchKernelGGL(k_chunk, dim3(gx, (unsigned)n), dim3(256), 0, h->stream, ws, h->qw, h->qh);
         a.list = lists + (size_t)CK_FIT_CLASSES * list_cap; a.list_count = list_counts + CK_FIT_CLASSES; a.head = heads + CK_FIT_CLASSES;
         hipLaunchKernelGGL(k_tail, dim3((unsigned)(cus * tail_wgs)), dim3(64), 0, h->stream, a);
