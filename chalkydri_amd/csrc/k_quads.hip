@@ -1742,8 +1742,10 @@ __device__ __forceinline__ void k_tail_body(const FitArgs &a) {
             const int frame = (int)(item >> 20);
             const int nruns = __builtin_amdgcn_readlane(h_nruns, k);
             const uint32_t n0 = (uint32_t)__builtin_amdgcn_readlane((int)h_n0, k), n1 = (uint32_t)__builtin_amdgcn_readlane((int)h_n1, k);
+            // (every v_readlane at a place all lanes reach: what it returns for a lane that is switched off is not defined — a build
+            // that spilled these registers restored only the active lanes around such a read, and lost detections)
+            const uint32_t s0 = (uint32_t)__builtin_amdgcn_readlane((int)h_s0, k), s1 = (uint32_t)__builtin_amdgcn_readlane((int)h_s1, k);
             if (nruns <= 2 && n0 + n1 <= 64u && (uint32_t)lane < n0 + n1) {
-                const uint32_t s0 = (uint32_t)__builtin_amdgcn_readlane((int)h_s0, k), s1 = (uint32_t)__builtin_amdgcn_readlane((int)h_s1, k);
                 const uint32_t idx = (uint32_t)lane < n0 ? s0 + (uint32_t)lane : s1 + ((uint32_t)lane - n0);
                 p.v = (ws.d_maxval + (size_t)frame * (ws.ext_cap / 2))[idx];
                 p.pos = (ws.d_maxpos + (size_t)frame * (ws.ext_cap / 2))[idx];
@@ -1786,9 +1788,10 @@ __device__ __forceinline__ void k_tail_body(const FitArgs &a) {
         bool prefetched = false; // this lane's maximum is in `cur`
         if (nruns <= 2) { // bounded by the head lane already
             const uint32_t n0 = (uint32_t)__builtin_amdgcn_readlane((int)h_n0, k), n1 = (uint32_t)__builtin_amdgcn_readlane((int)h_n1, k);
+            const uint32_t rs0 = (uint32_t)__builtin_amdgcn_readlane((int)h_s0, k), rs1 = (uint32_t)__builtin_amdgcn_readlane((int)h_s1, k);
             if (tid == 0) {
-                sRunStart[0] = (uint32_t)__builtin_amdgcn_readlane((int)h_s0, k); sRunN[0] = n0; sRunOff[0] = 0; sRunO[0] = (int)(s_lo * CK_SPAN) - (int)e0;
-                sRunStart[1] = (uint32_t)__builtin_amdgcn_readlane((int)h_s1, k); sRunN[1] = n1; sRunOff[1] = n0; sRunO[1] = (int)(s_hi * CK_SPAN) - (int)e0;
+                sRunStart[0] = rs0; sRunN[0] = n0; sRunOff[0] = 0; sRunO[0] = (int)(s_lo * CK_SPAN) - (int)e0;
+                sRunStart[1] = rs1; sRunN[1] = n1; sRunOff[1] = n0; sRunO[1] = (int)(s_hi * CK_SPAN) - (int)e0;
             }
             nmax_u = n0 + n1;
             prefetched = nmax_u <= 64u;
@@ -2231,9 +2234,11 @@ __device__ __forceinline__ void k_tail_body(const FitArgs &a) {
     }
 }
 
-// Register budget: four waves per SIMD (126 registers, nothing spilled).  A build for five (96 registers, 59 of them spilled) looked 7 %
-// faster and was WRONG: detections went missing at 1920x1080 and 2448x2048 and copies of one frame differed — the heads of a
-// chunk live in registers that other lanes read with v_readlane, and did not survive being spilled.  Do not let this kernel spill.
+// Register budget: four waves per SIMD (128 registers, nothing spilled).  A build for five (96 registers, 59 of them spilled) once
+// looked 7 % faster and was WRONG (detections missing at 1920x1080 and 2448x2048, copies of one frame differing): two v_readlane
+// reads of the chunk heads stood inside `if (lane < ...)` / `if (tid == 0)` blocks, where the lane they read may be switched off, and
+// the spill code restores active lanes only.  With every v_readlane where all lanes are active that build is correct — and 3 %
+// slower than this one (9.35 against 9.05 ms).
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_tail(FitArgs a) { k_tail_body(a); }
 
 // Gradient-magnitude weights of a whole batch in one streaming pass (1 B read, 2 B written per pixel): the fitter then needs
