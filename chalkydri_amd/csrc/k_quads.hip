@@ -1655,12 +1655,20 @@ __device__ __forceinline__ void k_tail_body(const FitArgs &a) {
     constexpr int NTH = 64, T_TAIL = MAXSEL, T_HEAD = MAXSEL + 1;
     __shared__ __attribute__((aligned(16))) unsigned char sPraw[sizeof(PairFit) * MAXSEL * MAXSEL];
     __shared__ long long sSelI[2 * MAXSEL][6];
-    __shared__ long long sF6[MAXSEL + 2][6], sPart[MAXSEL + 2][6];
+    __shared__ long long sFP[2 * (MAXSEL + 2)][6]; // block prefixes and partial sums of the targets (5b) ...
+    long long (*sF6)[6] = sFP, (*sPart)[6] = sFP + (MAXSEL + 2);
+    static_assert(sizeof(long long) * 6 * 2 * (MAXSEL + 2) >= 4 * 4 * MAXRUN, "the run tables live in the prefix tables' bytes");
+    uint32_t *sRunStart = reinterpret_cast<uint32_t *>(sFP), *sRunN = sRunStart + MAXRUN, *sRunOff = sRunN + MAXRUN; // ... which hold the runs of the maxima lists until the selection is done
+    int *sRunO = reinterpret_cast<int *>(sRunOff + MAXRUN);
     __shared__ int sSelIdx[MAXSEL];
-    __shared__ uint32_t sRunStart[MAXRUN], sRunN[MAXRUN], sRunOff[MAXRUN];
-    __shared__ int sRunO[MAXRUN];
+    // The corner phase uses four lanes per cluster: the clusters that get that far leave a record per side here and are worked off
+    // eight at a time (32 lanes) — an eighth of the instructions per cluster
+    constexpr int BATCH = 8;
+    struct SideRec { long long Mx, My, W; double nx, ny, mse; };
+    __shared__ SideRec sB[BATCH][4];
+    __shared__ uint32_t sBMeta[BATCH][4]; // frame, reversed border, rep0, rep1
     __shared__ uint32_t sWork;
-    __shared__ int sFlag, sBad;
+    __shared__ int sBad;
     __shared__ double sLines[4][4];
     __shared__ double sQuad[4][2];
     long long (*sSelE)[6] = sSelI + MAXSEL;
@@ -1752,6 +1760,183 @@ __device__ __forceinline__ void k_tail_body(const FitArgs &a) {
             }
             return p;
         };
+        int nb = 0; // clusters waiting for the corner phase
+        auto flush = [&]() {
+            // ---- 5d. lines, corners, geometric checks: lane 4 c + i owns side i / corner i of waiting cluster c; every value is formed by
+            // the same operations as in the oracle's sequential code, and the verdict is the conjunction of all checks ---------
+            const int c = tid >> 2, li = tid & 3;
+            const bool mine = c < nb;
+            int ok = mine ? 1 : 0;
+            double line[4] = {0, 0, 0, 0};
+            if (mine) {
+                const SideRec r = sB[c][li];
+                const double inv = 1.0 / (double)r.W;
+                line[0] = (0.5 * (double)r.Mx) * inv; line[1] = (0.5 * (double)r.My) * inv;
+                line[2] = r.nx; line[3] = r.ny;
+                if (r.mse > a.max_mse) ok = 0;
+            }
+            double ln[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) ln[q] = __shfl(line[q], (tid & ~3) | ((li + 1) & 3), 64);
+            double Px, Py;
+            {
+                double A00 = line[3], A01 = -ln[3], A10 = -line[2], A11 = ln[2];
+                double B0_ = -line[0] + ln[0], B1 = -line[1] + ln[1];
+                double det = A00 * A11 - A10 * A01;
+                if (fabs(det) < 0.001) ok = 0;
+                double W00 = A11 / det, W01 = -A01 / det;
+                double L0 = W00 * B0_ + W01 * B1;
+                Px = line[0] + L0 * A00;
+                Py = line[1] + L0 * A10;
+            }
+            const int g0 = tid & ~3;
+            auto corner_x = [&](int q) { return __shfl(Px, g0 | (q & 3), 64); };
+            auto corner_y = [&](int q) { return __shfl(Py, g0 | (q & 3), 64); };
+            {
+                const int t = li & 1;
+                const int va = t ? 2 : 0, vb = t ? 3 : 1, vc = t ? 0 : 2;
+                const double ax = corner_x(va), ay = corner_y(va), bx = corner_x(vb), by = corner_y(vb), cx = corner_x(vc), cy = corner_y(vc);
+                double len[3];
+                { double ddx = bx - ax, ddy = by - ay; len[0] = sqrt(ddx * ddx + ddy * ddy); }
+                { double ddx = cx - bx, ddy = cy - by; len[1] = sqrt(ddx * ddx + ddy * ddy); }
+                { double ddx = ax - cx, ddy = ay - cy; len[2] = sqrt(ddx * ddx + ddy * ddy); }
+                double pp = (len[0] + len[1] + len[2]) / 2.0;
+                double term = sqrt(pp * (pp - len[0]) * (pp - len[1]) * (pp - len[2]));
+                double t0 = __shfl(term, g0, 64), t1 = __shfl(term, g0 | 1, 64);
+                double area = 0.0;
+                area += t0; area += t1;
+                double tw = (double)a.min_tag_width;
+                if (area < 0.95 * tw * tw) ok = 0;
+            }
+            {
+                const double x1 = corner_x(li + 1), y1 = corner_y(li + 1), x2 = corner_x(li + 2), y2 = corner_y(li + 2);
+                double dx1 = x1 - Px, dy1 = y1 - Py;
+                double dx2 = x2 - x1, dy2 = y2 - y1;
+                double cs = (dx1 * dx2 + dy1 * dy2) / sqrt((dx1 * dx1 + dy1 * dy1) * (dx2 * dx2 + dy2 * dy2));
+                if (cs > a.cos_critical || cs < -a.cos_critical) ok = 0;
+                if (dx1 * dy2 < dy1 * dx2) ok = 0;
+            }
+            const unsigned long long okb = __ballot(ok != 0);
+            wave_sync(); // every side record has been read: the accepted clusters' corners take their first bytes
+            if (mine && ((okb >> (4 * c)) & 0xFull) == 0xFull) {
+                double qx = Px, qy = Py;
+                if (a.decimate > 1) { qx = (qx - 0.5) * (double)a.decimate + 0.5; qy = (qy - 0.5) * (double)a.decimate + 0.5; }
+                double *dst = reinterpret_cast<double *>(&sB[c][li]);
+                dst[0] = qx; dst[1] = qy;
+            }
+            wave_sync();
+            for (int cc = 0; cc < nb; cc++) {
+                if (((okb >> (4 * cc)) & 0xFull) != 0xFull) continue;
+                FDBG(6);
+                const int frame = (int)sBMeta[cc][0], reversed = (int)sBMeta[cc][1];
+                const uint32_t rep0 = sBMeta[cc][2], rep1 = sBMeta[cc][3];
+                const uint8_t *im = a.im + (size_t)frame * a.pitch;
+                if (tid < 4) { const double *src = reinterpret_cast<const double *>(&sB[cc][tid]); sQuad[tid][0] = src[0]; sQuad[tid][1] = src[1]; }
+                wave_sync();
+                if (a.refine) { // edge refinement (oracle refine_edges), as in k_fit: lane (edge, k) evaluates sample 16 * round + k, one lane per edge accumulates in sample order
+                    const int edge = (tid >> 4) & 3, k = tid & 15;
+                    const int ea = edge, eb = (edge + 1) & 3;
+                    double nx = sQuad[eb][1] - sQuad[ea][1];
+                    double ny = -sQuad[eb][0] + sQuad[ea][0];
+                    const double mag = sqrt(nx * nx + ny * ny);
+                    nx = nx / mag; ny = ny / mag;
+                    if (reversed) { nx = -nx; ny = -ny; }
+                    int nsamples = (int)(mag / 8.0);
+                    if (nsamples < 16) nsamples = 16;
+                    int max_samples = nsamples;
+        #pragma unroll
+                    for (int d = 32; d >= 1; d >>= 1) max_samples = max(max_samples, __shfl_xor(max_samples, d, 64));
+                    double Mx = 0, My = 0, Mxx = 0, Mxy = 0, Myy = 0, N = 0;
+                    wave_sync(); // the pair table's bytes become the sample buffer
+                    for (int base = 0; base < max_samples; base += 16) {
+                        {
+                            const int sidx = base + k;
+                            double bx = __builtin_nan(""), by = 0;
+                            if (sidx < nsamples) {
+                                double alpha = (1.0 + (double)sidx) / ((double)nsamples + 1.0);
+                                double x0 = alpha * sQuad[ea][0] + (1.0 - alpha) * sQuad[eb][0];
+                                double y0 = alpha * sQuad[ea][1] + (1.0 - alpha) * sQuad[eb][1];
+                                double Mn = 0, Mcount = 0;
+                                const int range = a.decimate + 1;
+                                for (int n = -range; n <= range; n++) {
+                                    double grange = 1.0;
+                                    int x1 = (int)(x0 + ((double)n + grange) * nx), y1 = (int)(y0 + ((double)n + grange) * ny);
+                                    if (x1 < 0 || x1 >= a.w || y1 < 0 || y1 >= a.h) continue;
+                                    int x2 = (int)(x0 + ((double)n - grange) * nx), y2 = (int)(y0 + ((double)n - grange) * ny);
+                                    if (x2 < 0 || x2 >= a.w || y2 < 0 || y2 >= a.h) continue;
+                                    int g1 = im[(size_t)y1 * a.stride + x1], g2 = im[(size_t)y2 * a.stride + x2];
+                                    if (g1 < g2) continue;
+                                    double weight = (double)((g2 - g1) * (g2 - g1));
+                                    Mn += weight * (double)n;
+                                    Mcount += weight;
+                                }
+                                if (Mcount != 0) {
+                                    double n0 = Mn / Mcount;
+                                    bx = x0 + n0 * nx; by = y0 + n0 * ny;
+                                }
+                            }
+                            sRefine[edge][k][0] = bx; sRefine[edge][k][1] = by;
+                        }
+                        wave_sync();
+                        if (k == 0)
+                            for (int q = 0; q < 16 && base + q < nsamples; q++) {
+                                double bx = sRefine[edge][q][0], by = sRefine[edge][q][1];
+                                if (bx != bx) continue;
+                                Mx += bx; My += by; Mxx += bx * bx; Mxy += bx * by; Myy += by * by; N += 1.0;
+                            }
+                        wave_sync();
+                    }
+                    if (k == 0) {
+                        double line[4];
+                        if (N < 2.0) {
+                            line[0] = 0.5 * (sQuad[ea][0] + sQuad[eb][0]); line[1] = 0.5 * (sQuad[ea][1] + sQuad[eb][1]);
+                            line[2] = nx; line[3] = ny;
+                        } else {
+                            double Ex = Mx / N, Ey = My / N;
+                            double Cxx = Mxx / N - Ex * Ex, Cxy = Mxy / N - Ex * Ey, Cyy = Myy / N - Ey * Ey;
+                            double d = Cxx - Cyy, q4 = 4.0 * Cxy;
+                            double disc = sqrt(d * d + q4 * Cxy);
+                            double eig = 0.5 * (Cxx + Cyy + disc);
+                            double nx1 = Cxx - eig, ny1 = Cxy, M1 = nx1 * nx1 + ny1 * ny1;
+                            double nx2 = Cxy, ny2 = Cyy - eig, M2 = nx2 * nx2 + ny2 * ny2;
+                            double fx, fy, M;
+                            if (M1 > M2) { fx = nx1; fy = ny1; M = M1; } else { fx = nx2; fy = ny2; M = M2; }
+                            double len = sqrt(M);
+                            line[0] = Ex; line[1] = Ey;
+                            if (len < 1e-12) { line[2] = nx; line[3] = ny; }
+                            else { line[2] = fx / len; line[3] = fy / len; }
+                        }
+                        for (int q = 0; q < 4; q++) sLines[edge][q] = line[q];
+                    }
+                    wave_sync();
+                    if (tid == 0)
+                        for (int i = 0; i < 4; i++) {
+                            int j = (i + 1) & 3;
+                            double A00 = sLines[i][3], A01 = -sLines[j][3], A10 = -sLines[i][2], A11 = sLines[j][2];
+                            double B0_ = -sLines[i][0] + sLines[j][0], B1 = -sLines[i][1] + sLines[j][1];
+                            double det = A00 * A11 - A10 * A01;
+                            if (fabs(det) > 0.001) {
+                                double W00 = A11 / det, W01 = -A01 / det;
+                                double L0 = W00 * B0_ + W01 * B1;
+                                sQuad[j][0] = sLines[i][0] + L0 * A00;
+                                sQuad[j][1] = sLines[i][1] + L0 * A10;
+                            }
+                        }
+                }
+                if (tid == 0) {
+                    uint32_t *counters = ws.d_counters + (size_t)frame * CK_CNT_STRIDE;
+                    uint32_t qi = atomicAdd(&counters[CK_CNT_QUADS], 1u);
+                    if (qi < (uint32_t)ws.quad_cap) {
+                        ck_quad_t q;
+                        for (int i = 0; i < 4; i++) { q.p[i][0] = sQuad[i][0]; q.p[i][1] = sQuad[i][1]; }
+                        q.reversed_border = reversed; q.rep0 = rep0; q.rep1 = rep1;
+                        ws.d_quads[(size_t)frame * ws.quad_cap + qi] = q;
+                    } else atomicOr(&counters[CK_CNT_STATUS], (uint32_t)CK_FRAME_QUADS_OVERFLOW);
+                }
+                wave_sync(); // the quad has been written out: the next accepted cluster may take the corner slots
+            }
+            nb = 0;
+        };
         Pre nxt = prefetch(0);
         for (int k = 0; k < len; k++) {
         // what was fetched for this cluster has to be here BEFORE the next cluster's fetch is issued: the compiler's waits inside the
@@ -1777,7 +1962,6 @@ __device__ __forceinline__ void k_tail_body(const FitArgs &a) {
         const unsigned long long *mmask = ws.d_maxmask + (size_t)frame * (ws.ext_cap / 64);
         const uint16_t *mpre = ws.d_maxpre + (size_t)frame * (ws.ext_cap / 64);
         const long long *blk = ws.d_blk + (size_t)frame * 6 * (ws.ext_cap / 32);
-        const uint8_t *im = a.im + (size_t)frame * a.pitch;
 
         // ---- the cluster's maxima: one run of k_chunk's lists per span it touches ------------------------------------------------
         const uint32_t s_lo = e0 / CK_SPAN, s_hi = (e1 - 1) / CK_SPAN;
@@ -2062,175 +2246,23 @@ __device__ __forceinline__ void k_tail_body(const FitArgs &a) {
         FDBG(5);
 
         if (a.stop_after == 7) continue;
-        // ---- 5d. lines, corners, geometric checks (k_fit's, lane i of every group of four owns side i / corner i) -----------------
-        {
-            const int li = tid & 3;
+        // ---- 5d. the four sides' records; the corner phase runs when eight clusters wait (or the chunk ends) -----------------------
+        if (tid < 4) {
             const int sel[4] = {(bestc >> 12) & 15, (bestc >> 8) & 15, (bestc >> 4) & 15, bestc & 15};
-            int ok = 1;
-            double line[4];
-            {
-                int N;
-                const int s0 = sel[li], s1 = sel[(li + 1) & 3];
-                const M6 m = rangeM(s0, s1, &N);
-                const PairFit pf = sF[s0 * MAXSEL + s1];
-                const double inv = 1.0 / (double)m.W;
-                line[0] = (0.5 * (double)m.Mx) * inv; line[1] = (0.5 * (double)m.My) * inv;
-                line[2] = pf.nx; line[3] = pf.ny;
-                if (pf.mse > a.max_mse) ok = 0;
-            }
-            double ln[4];
-#pragma unroll
-            for (int q = 0; q < 4; q++) ln[q] = __shfl(line[q], (tid & ~3) | ((li + 1) & 3), 64);
-            double Px, Py;
-            {
-                double A00 = line[3], A01 = -ln[3], A10 = -line[2], A11 = ln[2];
-                double B0_ = -line[0] + ln[0], B1 = -line[1] + ln[1];
-                double det = A00 * A11 - A10 * A01;
-                if (fabs(det) < 0.001) ok = 0;
-                double W00 = A11 / det, W01 = -A01 / det;
-                double L0 = W00 * B0_ + W01 * B1;
-                Px = line[0] + L0 * A00;
-                Py = line[1] + L0 * A10;
-            }
-            const int g0 = tid & ~3;
-            auto corner_x = [&](int q) { return __shfl(Px, g0 | (q & 3), 64); };
-            auto corner_y = [&](int q) { return __shfl(Py, g0 | (q & 3), 64); };
-            {
-                const int t = li & 1;
-                const int va = t ? 2 : 0, vb = t ? 3 : 1, vc = t ? 0 : 2;
-                const double ax = corner_x(va), ay = corner_y(va), bx = corner_x(vb), by = corner_y(vb), cx = corner_x(vc), cy = corner_y(vc);
-                double len[3];
-                { double ddx = bx - ax, ddy = by - ay; len[0] = sqrt(ddx * ddx + ddy * ddy); }
-                { double ddx = cx - bx, ddy = cy - by; len[1] = sqrt(ddx * ddx + ddy * ddy); }
-                { double ddx = ax - cx, ddy = ay - cy; len[2] = sqrt(ddx * ddx + ddy * ddy); }
-                double pp = (len[0] + len[1] + len[2]) / 2.0;
-                double term = sqrt(pp * (pp - len[0]) * (pp - len[1]) * (pp - len[2]));
-                double t0 = __shfl(term, g0, 64), t1 = __shfl(term, g0 | 1, 64);
-                double area = 0.0;
-                area += t0; area += t1;
-                double tw = (double)a.min_tag_width;
-                if (area < 0.95 * tw * tw) ok = 0;
-            }
-            {
-                const double x1 = corner_x(li + 1), y1 = corner_y(li + 1), x2 = corner_x(li + 2), y2 = corner_y(li + 2);
-                double dx1 = x1 - Px, dy1 = y1 - Py;
-                double dx2 = x2 - x1, dy2 = y2 - y1;
-                double cs = (dx1 * dx2 + dy1 * dy2) / sqrt((dx1 * dx1 + dy1 * dy1) * (dx2 * dx2 + dy2 * dy2));
-                if (cs > a.cos_critical || cs < -a.cos_critical) ok = 0;
-                if (dx1 * dy2 < dy1 * dx2) ok = 0;
-            }
-            const int all_ok = (__ballot(ok != 0) & 0xFull) == 0xFull;
-            if (tid < 4 && all_ok) {
-                double qx = Px, qy = Py;
-                if (a.decimate > 1) { qx = (qx - 0.5) * (double)a.decimate + 0.5; qy = (qy - 0.5) * (double)a.decimate + 0.5; }
-                sQuad[li][0] = qx; sQuad[li][1] = qy;
-            }
-            if (tid == 0) sFlag = all_ok;
+            int N;
+            const int s0 = sel[tid], s1 = sel[(tid + 1) & 3];
+            const M6 m = rangeM(s0, s1, &N);
+            const PairFit pf = sF[s0 * MAXSEL + s1];
+            SideRec r;
+            r.Mx = m.Mx; r.My = m.My; r.W = m.W; r.nx = pf.nx; r.ny = pf.ny; r.mse = pf.mse;
+            sB[nb][tid] = r;
         }
+        if (tid == 0) { sBMeta[nb][0] = (uint32_t)frame; sBMeta[nb][1] = (uint32_t)reversed; sBMeta[nb][2] = rep0; sBMeta[nb][3] = rep1; }
+        nb++;
         wave_sync();
-        if (!sFlag) continue;
-        FDBG(6);
-        if (a.refine) { // edge refinement (oracle refine_edges), as in k_fit: lane (edge, k) evaluates sample 16 * round + k, one lane per edge accumulates in sample order
-            const int edge = (tid >> 4) & 3, k = tid & 15;
-            const int ea = edge, eb = (edge + 1) & 3;
-            double nx = sQuad[eb][1] - sQuad[ea][1];
-            double ny = -sQuad[eb][0] + sQuad[ea][0];
-            const double mag = sqrt(nx * nx + ny * ny);
-            nx = nx / mag; ny = ny / mag;
-            if (reversed) { nx = -nx; ny = -ny; }
-            int nsamples = (int)(mag / 8.0);
-            if (nsamples < 16) nsamples = 16;
-            int max_samples = nsamples;
-#pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) max_samples = max(max_samples, __shfl_xor(max_samples, d, 64));
-            double Mx = 0, My = 0, Mxx = 0, Mxy = 0, Myy = 0, N = 0;
-            wave_sync(); // the pair table's bytes become the sample buffer
-            for (int base = 0; base < max_samples; base += 16) {
-                {
-                    const int sidx = base + k;
-                    double bx = __builtin_nan(""), by = 0;
-                    if (sidx < nsamples) {
-                        double alpha = (1.0 + (double)sidx) / ((double)nsamples + 1.0);
-                        double x0 = alpha * sQuad[ea][0] + (1.0 - alpha) * sQuad[eb][0];
-                        double y0 = alpha * sQuad[ea][1] + (1.0 - alpha) * sQuad[eb][1];
-                        double Mn = 0, Mcount = 0;
-                        const int range = a.decimate + 1;
-                        for (int n = -range; n <= range; n++) {
-                            double grange = 1.0;
-                            int x1 = (int)(x0 + ((double)n + grange) * nx), y1 = (int)(y0 + ((double)n + grange) * ny);
-                            if (x1 < 0 || x1 >= a.w || y1 < 0 || y1 >= a.h) continue;
-                            int x2 = (int)(x0 + ((double)n - grange) * nx), y2 = (int)(y0 + ((double)n - grange) * ny);
-                            if (x2 < 0 || x2 >= a.w || y2 < 0 || y2 >= a.h) continue;
-                            int g1 = im[(size_t)y1 * a.stride + x1], g2 = im[(size_t)y2 * a.stride + x2];
-                            if (g1 < g2) continue;
-                            double weight = (double)((g2 - g1) * (g2 - g1));
-                            Mn += weight * (double)n;
-                            Mcount += weight;
-                        }
-                        if (Mcount != 0) {
-                            double n0 = Mn / Mcount;
-                            bx = x0 + n0 * nx; by = y0 + n0 * ny;
-                        }
-                    }
-                    sRefine[edge][k][0] = bx; sRefine[edge][k][1] = by;
-                }
-                wave_sync();
-                if (k == 0)
-                    for (int q = 0; q < 16 && base + q < nsamples; q++) {
-                        double bx = sRefine[edge][q][0], by = sRefine[edge][q][1];
-                        if (bx != bx) continue;
-                        Mx += bx; My += by; Mxx += bx * bx; Mxy += bx * by; Myy += by * by; N += 1.0;
-                    }
-                wave_sync();
-            }
-            if (k == 0) {
-                double line[4];
-                if (N < 2.0) {
-                    line[0] = 0.5 * (sQuad[ea][0] + sQuad[eb][0]); line[1] = 0.5 * (sQuad[ea][1] + sQuad[eb][1]);
-                    line[2] = nx; line[3] = ny;
-                } else {
-                    double Ex = Mx / N, Ey = My / N;
-                    double Cxx = Mxx / N - Ex * Ex, Cxy = Mxy / N - Ex * Ey, Cyy = Myy / N - Ey * Ey;
-                    double d = Cxx - Cyy, q4 = 4.0 * Cxy;
-                    double disc = sqrt(d * d + q4 * Cxy);
-                    double eig = 0.5 * (Cxx + Cyy + disc);
-                    double nx1 = Cxx - eig, ny1 = Cxy, M1 = nx1 * nx1 + ny1 * ny1;
-                    double nx2 = Cxy, ny2 = Cyy - eig, M2 = nx2 * nx2 + ny2 * ny2;
-                    double fx, fy, M;
-                    if (M1 > M2) { fx = nx1; fy = ny1; M = M1; } else { fx = nx2; fy = ny2; M = M2; }
-                    double len = sqrt(M);
-                    line[0] = Ex; line[1] = Ey;
-                    if (len < 1e-12) { line[2] = nx; line[3] = ny; }
-                    else { line[2] = fx / len; line[3] = fy / len; }
-                }
-                for (int q = 0; q < 4; q++) sLines[edge][q] = line[q];
-            }
-            wave_sync();
-            if (tid == 0)
-                for (int i = 0; i < 4; i++) {
-                    int j = (i + 1) & 3;
-                    double A00 = sLines[i][3], A01 = -sLines[j][3], A10 = -sLines[i][2], A11 = sLines[j][2];
-                    double B0_ = -sLines[i][0] + sLines[j][0], B1 = -sLines[i][1] + sLines[j][1];
-                    double det = A00 * A11 - A10 * A01;
-                    if (fabs(det) > 0.001) {
-                        double W00 = A11 / det, W01 = -A01 / det;
-                        double L0 = W00 * B0_ + W01 * B1;
-                        sQuad[j][0] = sLines[i][0] + L0 * A00;
-                        sQuad[j][1] = sLines[i][1] + L0 * A10;
-                    }
-                }
-        }
-        if (tid == 0) {
-            uint32_t *counters = ws.d_counters + (size_t)frame * CK_CNT_STRIDE;
-            uint32_t qi = atomicAdd(&counters[CK_CNT_QUADS], 1u);
-            if (qi < (uint32_t)ws.quad_cap) {
-                ck_quad_t q;
-                for (int i = 0; i < 4; i++) { q.p[i][0] = sQuad[i][0]; q.p[i][1] = sQuad[i][1]; }
-                q.reversed_border = reversed; q.rep0 = rep0; q.rep1 = rep1;
-                ws.d_quads[(size_t)frame * ws.quad_cap + qi] = q;
-            } else atomicOr(&counters[CK_CNT_STATUS], (uint32_t)CK_FRAME_QUADS_OVERFLOW);
-        }
+        if (nb == BATCH) flush();
         } // clusters of the chunk
+        if (nb) flush();
     }
 }
 
