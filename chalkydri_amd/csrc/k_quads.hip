@@ -1461,12 +1461,13 @@ static_assert(CK_SPAN == 960 && KOFF >= CK_EXT_PRE + 3 && KL - KOFF - CK_SPAN >=
 __device__ __forceinline__ void k_chunk_body(const ck_stage_ws &ws, int qw, int qh) {
     __shared__ __attribute__((aligned(16))) unsigned long long sP64[3][KL]; // inclusive sums from the first loaded position: Mxx, Mxy, Myy
     __shared__ __attribute__((aligned(16))) uint32_t sP32[3][KL];           // Mx, My, W (a window's sums stay below 2^32: differences are exact)
-    __shared__ double sErr[KL];
     __shared__ uint8_t sKsz[KL];
     __shared__ unsigned long long sScan64[3][4];
     __shared__ uint32_t sScan32[3][4];
     __shared__ uint32_t sCnt[16];
-    double *sS = reinterpret_cast<double *>(&sP64[0][0]); // smoothed errors, once the sums are dead
+    // the errors and their smoothed values take the place of two of the sums once every window has been formed (the four errors of a
+    // thread wait in registers for the barrier in between): 38 KB instead of 46, four workgroups per CU instead of three
+    double *sS = reinterpret_cast<double *>(&sP64[0][0]), *sErr = reinterpret_cast<double *>(&sP64[1][0]);
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int frame = blockIdx.y;
     const uint32_t *counters = ws.d_counters + (size_t)frame * CK_CNT_STRIDE;
@@ -1553,9 +1554,11 @@ __device__ __forceinline__ void k_chunk_body(const ck_stage_ws &ws, int qw, int 
             blk[((size_t)s * (CK_SPAN / 32) + b) * 6 + q] = d;
         }
         // 3. windowed line-fit error of the positions whose smoothed value is needed (k_fit's chunk loop, same operations)
+        double ev[4];
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             const int j = tid + 256 * r;
+            ev[r] = 0.0;
             if (j >= KOFF - 4 && j < KOFF + CK_SPAN + 4) {
                 const int ksz = (int)sKsz[j];
                 const int hi = j + ksz, lo = j - ksz - 1;
@@ -1569,8 +1572,14 @@ __device__ __forceinline__ void k_chunk_body(const ck_stage_ws &ws, int qw, int 
                 const double Cyy = (0.25 * (double)m.Myy) * inv - Ey * Ey;
                 const double d = Cxx - Cyy, q4 = 4.0 * Cxy;
                 const double disc = sqrt(d * d + q4 * Cxy);
-                sErr[j] = (double)(2 * ksz + 1) * (0.5 * ((Cxx + Cyy) - disc));
+                ev[r] = (double)(2 * ksz + 1) * (0.5 * ((Cxx + Cyy) - disc));
             }
+        }
+        lds_barrier(); // every window has been read: the sums may go
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int j = tid + 256 * r;
+            if (j >= KOFF - 4 && j < KOFF + CK_SPAN + 4) sErr[j] = ev[r];
         }
         const uint32_t nww[4] = {gather_w(nx4.x), gather_w(nx4.y), gather_w(nx4.z), gather_w(nx4.w)};
         lds_barrier();
@@ -2482,7 +2491,7 @@ int ck_launch_fit_quads(ck_handle *h, const uint8_t *qframes, int qstride, size_
     if (flat) {
         // spans per frame and workgroups that share them: a batch gives every workgroup a few spans, a short call one each
         const unsigned spans = (unsigned)(ws.ext_cap / CK_SPAN);
-        static const int chunk_wgs = getenv("CK_CHUNK_WGS") ? atoi(getenv("CK_CHUNK_WGS")) : 16; // (diagnostics: k_chunk workgroups per CU over the batch)
+        static const int chunk_wgs = getenv("CK_CHUNK_WGS") ? atoi(getenv("CK_CHUNK_WGS")) : 32; // (diagnostics: k_chunk workgroups per CU over the batch)
         static const int tail_wgs = getenv("CK_TAIL_WGS") ? atoi(getenv("CK_TAIL_WGS")) : 16;    // (diagnostics: k_tail workgroups per CU)
         unsigned gx = (unsigned)((cus * chunk_wgs + n - 1) / n);
         if (gx < 8) gx = 8;
