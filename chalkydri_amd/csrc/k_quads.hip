@@ -2491,7 +2491,7 @@ int ck_launch_fit_quads(ck_handle *h, const uint8_t *qframes, int qstride, size_
     if (flat) {
         // spans per frame and workgroups that share them: a batch gives every workgroup a few spans, a short call one each
         const unsigned spans = (unsigned)(ws.ext_cap / CK_SPAN);
-        static const int chunk_wgs = getenv("CK_CHUNK_WGS") ? atoi(getenv("CK_CHUNK_WGS")) : 32; // (diagnostics: k_chunk workgroups per CU over the batch)
+        static const int chunk_wgs = getenv("CK_CHUNK_WGS") ? atoi(getenv("CK_CHUNK_WGS")) : 64; // (diagnostics: k_chunk workgroups per CU over the batch)
         static const int tail_wgs = getenv("CK_TAIL_WGS") ? atoi(getenv("CK_TAIL_WGS")) : 16;    // (diagnostics: k_tail workgroups per CU)
         unsigned gx = (unsigned)((cus * chunk_wgs + n - 1) / n);
         if (gx < 8) gx = 8;
