@@ -16,7 +16,7 @@ acc = collections.defaultdict(lambda: collections.defaultdict(float)); disp = co
 for f in glob.glob("$root/gpurun_out/flatpmc_*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         n = r["Kernel_Name"]
-        if not any(k in n for k in ("k_tail", "k_chunk", "k_seq")): continue
+        if not any(k in n for k in ("k_tail", "k_chunk", "k_seq", "k_emit", "k_scatter")): continue
         n = n.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
         acc[n][r["Counter_Name"]] += float(r["Counter_Value"]); disp[(n, r["Counter_Name"])].add(r["Dispatch_Id"])
 for n, c in sorted(acc.items()):
