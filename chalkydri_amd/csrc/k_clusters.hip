@@ -39,6 +39,11 @@ struct EmitArgs {
     ck_stage_ws ws;
 };
 
+// A barrier that orders LDS traffic only: __syncthreads() carries a workgroup-scope fence, i.e. a wait for EVERY outstanding memory
+// operation — the barrier before the point writes would wait for the acknowledgement of the cluster-count adds nobody reads.
+// Nothing a workgroup of k_emit writes to global memory is read by it again.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 __global__ __launch_bounds__(NT) void k_emit(EmitArgs a) {
     __shared__ uint8_t sT[LH][LW + 2];
     __shared__ uint32_t sR[LH][LW];
@@ -101,7 +106,7 @@ __global__ __launch_bounds__(NT) void k_emit(EmitArgs a) {
             sR[ly][lx] = r;
         }
     }
-    __syncthreads();
+    lds_barrier();
     if (a.stop_after == 0) return;
 
     const int lx = (tid & 63) + 1; // staged column of this thread's pixels
@@ -169,7 +174,7 @@ __global__ __launch_bounds__(NT) void k_emit(EmitArgs a) {
             }
         }
     }
-    __syncthreads();
+    lds_barrier();
     if (a.stop_after == 1) return;
 
     // pass 2: one reservation of temp space and of run records per tile (exclusive scans of the per-key counts / used
@@ -185,7 +190,7 @@ __global__ __launch_bounds__(NT) void k_emit(EmitArgs a) {
         ridx0 = (uint32_t)(__popcll(b0 & below) + __popcll(b1 & below)); // rank of this thread's first used slot in its wave
         if ((tid & 63) == 63) sWave[tid >> 6] = incl;
         if ((tid & 63) == 0) sRunW[tid >> 6] = (uint32_t)(__popcll(b0) + __popcll(b1));
-        __syncthreads();
+        lds_barrier();
         uint32_t before = 0, total = 0, rbefore = 0, rtotal = 0;
 #pragma unroll
         for (int wv = 0; wv < NT / 64; wv++) {
@@ -194,7 +199,7 @@ __global__ __launch_bounds__(NT) void k_emit(EmitArgs a) {
             total += t; rtotal += r;
         }
         ridx0 += rbefore;
-        __syncthreads(); // every thread has read the per-wave totals before thread 0 reuses the arrays' last entries
+        lds_barrier(); // every thread has read the per-wave totals before thread 0 reuses the arrays' last entries
         if (tid == 0) {
             sWave[NT / 64] = total ? atomicAdd(&counters[CK_CNT_TMP], total) : 0u;
             sRunW[NT / 64] = rtotal ? atomicAdd(&counters[CK_CNT_RUNS], rtotal) : 0u;
@@ -227,7 +232,7 @@ __global__ __launch_bounds__(NT) void k_emit(EmitArgs a) {
         if (found0 != SKIP) atomicAdd(&gcount[found0], c0); // result unused: nothing waits for these
         if (found1 != SKIP) atomicAdd(&gcount[found1], c1);
     }
-    __syncthreads();
+    lds_barrier();
     if (a.stop_after == 2) return;
 
     // pass 3: write the points

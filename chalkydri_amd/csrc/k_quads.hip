@@ -2425,6 +2425,12 @@ int ck_launch_fit_quads(ck_handle *h, const uint8_t *qframes, int qstride, size_
     const bool tails_aside = !side_by_side && tails_aside_ok;
     if (side_by_side) { cs[3] = h->fit_stream[0]; cs[2] = h->fit_stream[1]; cs[4] = h->fit_stream[1]; }
     if (tails_aside) { cs[4] = h->fit_stream[0]; cs[5] = h->fit_stream[0]; cs[3] = h->fit_stream[0]; }
+    // (diagnostics: CK_FIT_ASIDE: bit c set = class c on side stream 0, bit 8 + c = on side stream 1.  Split fit, measured: the three
+    // largest classes aside (0x38) 8.59 ms · with the 2049-4096 class 8.68 · with the 1025-2048 class too 8.65 · the 4097-8192 class back
+    // on the handle's stream 8.57 · or on the second side stream 8.52 · ...: all within the noise of one box)
+    static const int aside_env = getenv("CK_FIT_ASIDE") ? (int)strtol(getenv("CK_FIT_ASIDE"), nullptr, 0) : -1;
+    if (tails_aside && aside_env >= 0)
+        for (int c = 0; c < CK_FIT_CLASSES; c++) cs[c] = ((aside_env >> c) & 1) ? h->fit_stream[0] : (((aside_env >> (8 + c)) & 1) ? h->fit_stream[1] : h->stream);
     if (side_by_side || tails_aside) {
         CK_HIP(hipEventRecord(h->ev_fit_fork, h->stream));
         for (int k = 0; k < CK_FIT_SIDE_STREAMS; k++) CK_HIP(hipStreamWaitEvent(h->fit_stream[k], h->ev_fit_fork, 0));
