@@ -2445,12 +2445,15 @@ int ck_launch_fit_quads(ck_handle *h, const uint8_t *qframes, int qstride, size_
     static const int flat_env = getenv("CK_FIT_FLAT") ? atoi(getenv("CK_FIT_FLAT")) : 1;
     const bool flat = flat_env >= 2 || (flat_env == 1 && !side_by_side && (size_t)n * (size_t)h->qw * (size_t)h->qh >= ((size_t)100 << 20));
     static const int seq_alt = getenv("CK_SEQ_ALT") ? atoi(getenv("CK_SEQ_ALT")) : 0; // (diagnostics: bit c = class c of k_seq with a tighter register budget)
+    // (diagnostics: workgroups per CU of k_seq's three smallest classes)
+    static const int seq_wgs0 = getenv("CK_SEQ_WGS0") ? atoi(getenv("CK_SEQ_WGS0")) : 16, seq_wgs7 = getenv("CK_SEQ_WGS7") ? atoi(getenv("CK_SEQ_WGS7")) : 16,
+                     seq_wgs6 = getenv("CK_SEQ_WGS6") ? atoi(getenv("CK_SEQ_WGS6")) : 8;
     auto launch_split = [&](int c) {
         switch (c) {
         // (tighter register budgets for the four classes below — six / eight / five / five waves per SIMD — measured: no difference)
-        case 0: hipLaunchKernelGGL((k_seq<64, 512, true, 4, false>), dim3((unsigned)(cus * 16)), dim3(64), 0, cs[c], a); break;
-        case 7: hipLaunchKernelGGL((k_seq<64, 256, true, 4, false>), dim3((unsigned)(cus * 16)), dim3(64), 0, cs[c], a); break;
-        case 6: hipLaunchKernelGGL((k_seq<128, 1024, true, 4, false>), dim3((unsigned)(cus * 8)), dim3(128), 0, cs[c], a); break;
+        case 0: hipLaunchKernelGGL((k_seq<64, 512, true, 4, false>), dim3((unsigned)(cus * seq_wgs0)), dim3(64), 0, cs[c], a); break;
+        case 7: hipLaunchKernelGGL((k_seq<64, 256, true, 4, false>), dim3((unsigned)(cus * seq_wgs7)), dim3(64), 0, cs[c], a); break;
+        case 6: hipLaunchKernelGGL((k_seq<128, 1024, true, 4, false>), dim3((unsigned)(cus * seq_wgs6)), dim3(128), 0, cs[c], a); break;
         case 1: hipLaunchKernelGGL((k_seq<256, 2048, true, 4, false>), dim3((unsigned)(cus * 4)), dim3(256), 0, cs[c], a); break;
         case 2: if (seq_alt & 16) hipLaunchKernelGGL((k_seq<256, 4096, true, 2, false>), dim3((unsigned)(cus * 2)), dim3(256), 0, cs[c], a);
                 else hipLaunchKernelGGL((k_seq<256, 4096, true, 3, false>), dim3((unsigned)(cus * 3)), dim3(256), 0, cs[c], a); // (three workgroups per CU at 168 registers: 8.58 against 8.78 ms with two at 256)
