@@ -1,4 +1,9 @@
-// k_quads.hip — quad fitting: one workgroup per gradient cluster.
+// k_quads.hip — quad fitting.  Two forms of the same function:
+//   * k_fit: one workgroup per gradient cluster through all six phases below (calls of a few frames: the size classes side by
+//     side on three streams; and batches too small for the split form to pay);
+//   * the SPLIT fit of a batch, three kernels cut where the fit's parallelism changes: k_seq (per cluster: phases 1-2, the cluster's
+//     points leave as an "extended sequence", ck_internal.h) -> k_chunk (per POSITION of a frame's sequences, no notion of clusters:
+//     phases 3-4, results filed by position) -> k_tail (one wave per cluster: phases 5-6).  ck_launch_fit_quads decides.
 //
 // Replaces the quad-fit and edge-refinement stages of the external AprilTag-3 detector reached at
 // crates/apriltags/src/lib.rs:301.  Bit-exact with oracle/detector.c (fit_quad, refine_edges): all decisions
