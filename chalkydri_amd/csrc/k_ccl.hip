@@ -457,7 +457,12 @@ __global__ __launch_bounds__(KNT) __attribute__((amdgpu_num_sgpr(80))) void k_ti
     uint32_t *pool = reinterpret_cast<uint32_t *>(lds + OFF_POOL);
     const int c = __builtin_amdgcn_readfirstlane(tid >> 6); // wave-uniform
     const int p = (tid >> 2) & (TH / 2 - 1), wd = tid & 3;
-    if (tid < 2 * 64) {
+    {
+        // All four waves work: waves 0 and 2 on the white pair words, 1 and 3 on the black ones.  The two waves of a colour form the
+        // same masks (what was two idle waves' time) and share the per-node loop — the even-numbered nodes of every word to the
+        // first, the odd-numbered to the second — and the leftover links (vertical ones and the word-boundary flags to the first,
+        // the diagonal ones to the second): the loop runs to HALF the busiest word's node count.
+        const int c = __builtin_amdgcn_readfirstlane((tid >> 6) & 1), half = __builtin_amdgcn_readfirstlane(tid >> 7);
         const bool white = c == 0, has_l = wd > 0, has_u = p > 0, has_r = wd < NWD - 1;
         const int mi = ((2 * p) * NWD + wd) * 2 + c;
         const uint32_t O = ck_origin32(tx0 + 32 * wd, w);
@@ -498,7 +503,9 @@ __global__ __launch_bounds__(KNT) __attribute__((amdgpu_num_sgpr(80))) void k_ti
         uint32_t li = c ? (uint32_t)(LIST_CAP - 1) - (incl - cnt) : incl - cnt; // white from the front, black from the back
         const uint32_t lstep = c ? 0xFFFFFFFFu : 1u, lcol = ((uint32_t)c << 12) | base;
         const uint32_t nMt = ~Mt, nUt = ~Ut;
-        for (uint32_t St = S2; St;) {
+        uint32_t St = S2;
+        if (half) { St &= St - 1u; li += lstep; } // the second wave of the colour starts at the word's second node
+        for (; St; St &= St - 1u, li += 2u * lstep) { // (the step skips the other wave's node)
             const uint32_t low = St & (0u - St);
             const uint32_t s = ffbl_raw(low);
             St ^= low;
@@ -514,12 +521,11 @@ __global__ __launch_bounds__(KNT) __attribute__((amdgpu_num_sgpr(80))) void k_ti
             // the list entry: lookup pixel | colour << 12 | pixel count << 16.  (A tile with more nodes than the list holds — one-pixel
             // patterns — does without it: the index then runs past either end and nothing is stored.)
             if (li < (uint32_t)LIST_CAP) list[li] = lk | lcol | (((uint32_t)__popc(Mt & span) + (uint32_t)__popc(Mb & span)) << 16);
-            li += lstep;
         }
         // (c) what is left: the vertical links one loop, the two diagonal kinds one loop each, then the three links that cross a
         // word boundary (a generic "take the next link" loop cost twice the instructions per link)
-        const uint32_t lEv = Ev & ~F, lDL = DL & ~F, lDR = DR & ~(F & ~DL);
-        const uint32_t fl = ((link & 1u) ? CK_LINK_HLEFT : 0u) | ((K.DL & 1u) ? CK_LINK_CROSS_L : 0u) | ((K.DR >> 31) ? CK_LINK_CROSS_R : 0u);
+        const uint32_t lEv = half ? 0u : Ev & ~F, lDL = half ? DL & ~F : 0u, lDR = half ? DR & ~(F & ~DL) : 0u;
+        const uint32_t fl = half ? 0u : ((link & 1u) ? CK_LINK_HLEFT : 0u) | ((K.DL & 1u) ? CK_LINK_CROSS_L : 0u) | ((K.DR >> 31) ? CK_LINK_CROSS_R : 0u);
         const uint32_t extra = (uint32_t)__popc(lEv) + (uint32_t)__popc(lDL) + (uint32_t)__popc(lDR) + (uint32_t)__popc(fl);
         const uint32_t xincl = wave_scan_u32(extra);
         const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)xincl, 63);
@@ -539,7 +545,8 @@ __global__ __launch_bounds__(KNT) __attribute__((amdgpu_num_sgpr(80))) void k_ti
             if (fl & CK_LINK_CROSS_L) push(base + (((nMt >> 0) & 1u) << 7), info_ul & 0xFFFu);
             if (fl & CK_LINK_CROSS_R) push(lower(31u), upbase + 32u + (((info_ur >> 14) & 1u) ? 0u : (uint32_t)TW));
         }
-    } else if (tid < 3 * 64) {
+    }
+    if (tid >= 2 * 64 && tid < 3 * 64) { // (a lane per pixel of the frame's non-origin columns: entries no pair-word node owns)
         int r, xl; uint32_t ec;
         if (edge_pixel(mk, tid & 63, tx0, ty0, w, h, r, xl, ec)) parent[r * TW + xl] = (uint16_t)CK_ROOT;
     }
