@@ -99,7 +99,10 @@ const ck_family_t *ck_family_builtin(const char *name);
 
 typedef struct ck_config {
     int32_t width, height;        /* frame geometry, fixed per handle (cf. Detector::new(width,height,..)) */
-    int32_t max_batch;            /* frames per ck_detect_batch call the workspace is sized for */
+    int32_t max_batch;            /* frames per ck_detect_batch call the workspace is sized for.  Every stage keeps worst-case capacity
+                                   * resident, about 86 bytes per pixel of quad-stage image and frame at the default capacities
+                                   * (1280 x 800: 88 MB per frame of max_batch; max_points_per_frame / max_clusters_per_frame
+                                   * shrink it); ck_create fails with CK_ENOMEM when the device has no room */
     int32_t device;               /* HIP device ordinal */
     /* AprilTag-3 detector defaults the reference inherits unchanged */
     int32_t quad_decimate;        /* 1 (full resolution) or 2 (AT3 default) */
