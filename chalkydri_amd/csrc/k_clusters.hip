@@ -448,7 +448,10 @@ int ck_launch_clusters(ck_handle *h, int n) {
     int min_cluster = h->cfg.min_cluster_pixels < 24 ? 24 : h->cfg.min_cluster_pixels;
     hipLaunchKernelGGL(k_scan, dim3((unsigned)n), dim3(SNT), 0, h->stream, ws, min_cluster, ws.max_cluster_points);
     if (n <= 4) hipLaunchKernelGGL(k_scatter<8>, dim3(256u, (unsigned)n), dim3(NT), 0, h->stream, ws);
-    else hipLaunchKernelGGL(k_scatter<64>, dim3(32u, (unsigned)n), dim3(NT), 0, h->stream, ws);
+    else {
+        static const unsigned sc_wgs = getenv("CK_SCATTER_WGS") ? (unsigned)atoi(getenv("CK_SCATTER_WGS")) : 32u; // (diagnostics: workgroups per frame)
+        hipLaunchKernelGGL(k_scatter<64>, dim3(sc_wgs, (unsigned)n), dim3(NT), 0, h->stream, ws);
+    }
     CK_HIP(hipGetLastError());
     return CK_OK;
 }
