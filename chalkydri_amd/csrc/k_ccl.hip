@@ -294,13 +294,25 @@ __global__ __launch_bounds__(KNT) __attribute__((amdgpu_num_sgpr(80))) void k_ti
 
     TPROF_DECL;
     // ---- P0: stage the tile and its halo: IMG_ROWS rows of ten 16-byte chunks (16 left | 128 | 16 right) ------------
-    for (int item = tid; item < IMG_ROWS * 10; item += KNT) {
-        const int r = item / 10, c = item - r * 10;
-        const int gy = sy0 + r, gx = sx0 + 16 * c;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        // rows are padded to 16 bytes (frame strides are multiples of 16): a chunk that starts inside the row is readable
-        if (gy >= 0 && gy < h && gx >= 0 && gx < w) v = *reinterpret_cast<const uint4 *>(img + (size_t)gy * stride + gx);
-        *reinterpret_cast<uint4 *>(lds + OFF_IMG + r * IMG_PITCH + 16 * c) = v;
+    {   // a lane's chunks are asked for together, then stored: as a loop (load, wait, store, load, wait, store) the second chunk's
+        // trip to HBM started only when the first had come back
+        constexpr int P0N = (IMG_ROWS * 10 + KNT - 1) / KNT;
+        uint4 v[P0N];
+#pragma unroll
+        for (int q = 0; q < P0N; q++) {
+            const int item = tid + q * KNT;
+            const int r = item / 10, c = item - r * 10;
+            const int gy = sy0 + r, gx = sx0 + 16 * c;
+            v[q] = make_uint4(0, 0, 0, 0);
+            // rows are padded to 16 bytes (frame strides are multiples of 16): a chunk that starts inside the row is readable
+            if (item < IMG_ROWS * 10 && gy >= 0 && gy < h && gx >= 0 && gx < w) v[q] = *reinterpret_cast<const uint4 *>(img + (size_t)gy * stride + gx);
+        }
+#pragma unroll
+        for (int q = 0; q < P0N; q++) {
+            const int item = tid + q * KNT;
+            const int r = item / 10, c = item - r * 10;
+            if (item < IMG_ROWS * 10) *reinterpret_cast<uint4 *>(lds + OFF_IMG + r * IMG_PITCH + 16 * c) = v[q];
+        }
     }
     lds_barrier();
     TPROF(0);
