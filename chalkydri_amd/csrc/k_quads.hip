@@ -111,6 +111,10 @@ __device__ __forceinline__ void fit_line_m(const M6 &m, int N, double *lineparm,
 __device__ const double k_smooth[7] = {0.011108996538242306, 0.1353352832366127, 0.6065306597126334, 1.0,
                                        0.6065306597126334, 0.1353352832366127, 0.011108996538242306};
 
+// s_waitcnt vmcnt(0) as an instruction the compiler's own wait insertion knows about (gfx9 encoding: vmcnt in bits 3:0 and 15:14,
+// expcnt 6:4 and lgkmcnt 11:8 left at "do not wait"): placed BEFORE a prefetch is issued, so that what the iteration is about to use
+// is known to be there and the compiler's later waits (which, inside loops, are for everything outstanding) find nothing to sit on
+constexpr int WAIT_VMCNT0 = 0x0F70;
 // Barriers that order LDS traffic only.  __syncthreads() carries a workgroup-scope fence, which the compiler turns into a wait for
 // EVERY outstanding memory operation — a prefetch issued for the next cluster would be waited for at the first barrier behind it.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
@@ -1350,7 +1354,7 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(WPS, 8))) v
             const ck_packed_point *pts = ws.d_points + (size_t)frame * ws.ext_cap + sHStart[k];
             ck_packed_point rawp[PF ? EPL : 1];
             if constexpr (PF) {
-                __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): this cluster's points are here before the next one's are asked for (see k_tail)
+                __builtin_amdgcn_s_waitcnt(WAIT_VMCNT0); // vmcnt(0): this cluster's points are here before the next one's are asked for (see k_tail)
 #pragma unroll
                 for (int e = 0; e < EPL; e++) rawp[e] = nxt[e];
                 if (k + 1 < len) fetch(k + 1);
@@ -1502,7 +1506,7 @@ __device__ __forceinline__ void k_chunk_body(const ck_stage_ws &ws, int qw, int 
     uint32_t ww[4] = {gather_w(x4.x), gather_w(x4.y), gather_w(x4.z), gather_w(x4.w)};
     for (uint32_t s = blockIdx.x; (unsigned long long)s * CK_SPAN < ext_total; s += gridDim.x) {
         // 1. four consecutive positions per thread: moments, running sums, one scan over the workgroup
-        __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): this span's points and weights (asked for during the span before) are here
+        __builtin_amdgcn_s_waitcnt(WAIT_VMCNT0); // vmcnt(0): this span's points and weights (asked for during the span before) are here
         const long long p0 = (long long)s * CK_SPAN - KOFF + 4 * tid;
         const uint32_t xw[4] = {x4.x, x4.y, x4.z, x4.w};
         if (tid >= KOFF / 4 && tid < (KOFF + CK_SPAN) / 4) // the positions this span decides: their weights stay for k_tail
@@ -1955,7 +1959,7 @@ __device__ __forceinline__ void k_tail_body(const FitArgs &a) {
         for (int k = 0; k < len; k++) {
         // what was fetched for this cluster has to be here BEFORE the next cluster's fetch is issued: the compiler's waits inside the
         // loops below are for "everything outstanding", and would otherwise sit on the fetch just issued
-        __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0)
+        __builtin_amdgcn_s_waitcnt(WAIT_VMCNT0); // vmcnt(0)
         const Pre cur = nxt;
         nxt = prefetch(k + 1);
         wave_sync();
@@ -2033,7 +2037,7 @@ __device__ __forceinline__ void k_tail_body(const FitArgs &a) {
                         myo = sRunO[r] + (int)mpos[idx];
                     }
                 }
-                __builtin_amdgcn_s_waitcnt(0x0F70); // (here, not inside the loop below, where it would also hold up the common path)
+                __builtin_amdgcn_s_waitcnt(WAIT_VMCNT0); // (here, not inside the loop below, where it would also hold up the common path)
             }
             const bool has = lane < nmax_all;
             // the values are compared through their order-preserving integer image (one 64-bit integer compare against an f64 compare and
