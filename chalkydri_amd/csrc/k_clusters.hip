@@ -302,7 +302,8 @@ __global__ __launch_bounds__(SNT) void k_scan(ck_stage_ws ws, int min_cluster, i
     const int seg = ws.ht_size / (SNT / 64); // ht_size is a multiple of SNT, so seg is a multiple of 64
     const int base = wv * seg;
     uint32_t pts = 0, cl = 0;
-    for (int r = 0; r < seg; r += 64) {
+#pragma unroll 8
+    for (int r = 0; r < seg; r += 64) { // (unrolled: eight loads in flight; as a plain loop every 64 slots cost a trip to memory)
         uint32_t c = gcount[base + r + lane];
         bool ok = (int)c >= min_cluster && (int)c <= max_cluster;
         pts += ok ? c : 0u; cl += ok ? 1u : 0u;
@@ -313,9 +314,17 @@ __global__ __launch_bounds__(SNT) void k_scan(ck_stage_ws ws, int min_cluster, i
     __syncthreads();
     uint32_t po = 0, co = 0;
     for (int k = 0; k < wv; k++) { po += sPts[k]; co += sCl[k]; }
-    for (int r = 0; r < seg; r += 64) {
+    // (the counts of four rounds are fetched together, then worked off in order; seg is a multiple of 64, not always of 256)
+    for (int r4 = 0; r4 < seg; r4 += 256) {
+        uint32_t c4[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) c4[q] = r4 + 64 * q < seg ? gcount[base + r4 + 64 * q + lane] : 0u;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int r = r4 + 64 * q;
+        if (r >= seg) continue; // (uniform)
         const int e = base + r + lane;
-        const uint32_t c = gcount[e];
+        const uint32_t c = c4[q];
         const bool ok = (int)c >= min_cluster && (int)c <= max_cluster;
         const uint32_t ip = wave_scan_u32(ok ? c : 0u), ic = wave_scan_u32(ok ? 1u : 0u);
         uint32_t off = SKIP;
@@ -341,6 +350,7 @@ __global__ __launch_bounds__(SNT) void k_scan(ck_stage_ws ws, int min_cluster, i
         goff[e] = off;
         po += (uint32_t)__builtin_amdgcn_readlane((int)ip, 63);
         co += (uint32_t)__builtin_amdgcn_readlane((int)ic, 63);
+    }
     }
     if (tid == SNT - 1) {
         counters[CK_CNT_CLUSTERS] = min(co, (uint32_t)ws.cluster_cap);
