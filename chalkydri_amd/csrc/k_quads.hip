@@ -2400,11 +2400,19 @@ int ck_launch_fit_quads(ck_handle *h, const uint8_t *qframes, int qstride, size_
     FitArgs a;
     a.qim = qframes; a.qw = h->qw; a.qh = h->qh; a.qstride = qstride; a.qpitch = qpitch;
     a.wimg = ws.d_wimg;
-    {
+    auto launch_wimg = [&](hipStream_t st) {
         const int w4 = (h->qw + 3) / 4;
-        hipLaunchKernelGGL(k_weight_image, dim3((unsigned)((w4 + 63) / 64), (unsigned)((h->qh + 3) / 4), (unsigned)n), dim3(256), 0, h->stream, qframes,
+        hipLaunchKernelGGL(k_weight_image, dim3((unsigned)((w4 + 63) / 64), (unsigned)((h->qh + 3) / 4), (unsigned)n), dim3(256), 0, st, qframes,
                            qpitch, qstride, h->qw, h->qh, ws.d_wimg);
-    }
+    };
+    // The split fit needs the weights in its second kernel only: the weight image (a streaming kernel, bound by HBM) then runs on the
+    // second side stream beside the first kernels (bound by their sort) instead of before them (CK_FIT_WIMG_ASIDE=0: as before)
+    static const int flat_env0 = getenv("CK_FIT_FLAT") ? atoi(getenv("CK_FIT_FLAT")) : 1;
+    static const int wimg_aside_env = getenv("CK_FIT_WIMG_ASIDE") ? atoi(getenv("CK_FIT_WIMG_ASIDE")) : 1;
+    static const int tails_aside_ok0 = (getenv("CK_FIT_TAILS_ASIDE") ? atoi(getenv("CK_FIT_TAILS_ASIDE")) : 1) && (getenv("CK_STREAMS") ? atoi(getenv("CK_STREAMS")) : 1) < 2;
+    const bool flat0 = flat_env0 >= 2 || (flat_env0 == 1 && !side_by_side && (size_t)n * (size_t)h->qw * (size_t)h->qh >= ((size_t)100 << 20));
+    const bool wimg_aside = flat0 && !side_by_side && tails_aside_ok0 && wimg_aside_env;
+    if (!wimg_aside) launch_wimg(h->stream);
     a.im = frames; a.w = h->w; a.h = h->h; a.stride = stride; a.pitch = pitch;
     a.decimate = h->cfg.quad_decimate; a.refine = h->cfg.refine_edges; a.max_nmaxima = h->cfg.max_nmaxima;
     a.cos_critical = h->cfg.cos_critical_rad; a.max_mse = h->cfg.max_line_fit_mse;
@@ -2443,6 +2451,7 @@ int ck_launch_fit_quads(ck_handle *h, const uint8_t *qframes, int qstride, size_
     if (side_by_side || tails_aside) {
         CK_HIP(hipEventRecord(h->ev_fit_fork, h->stream));
         for (int k = 0; k < CK_FIT_SIDE_STREAMS; k++) CK_HIP(hipStreamWaitEvent(h->fit_stream[k], h->ev_fit_fork, 0));
+        if (wimg_aside) launch_wimg(h->fit_stream[1]); // (joined with the side streams before k_chunk)
     }
     static const int gk_env = getenv("CK_FIT_GK") ? atoi(getenv("CK_FIT_GK")) : 0; // (experiment: bit c set = class c keeps its keys in global memory: small LDS, more workgroups per CU)
     const int gk_mask = ws.d_hscratch ? gk_env : 0;
