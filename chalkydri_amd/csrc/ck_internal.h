@@ -207,6 +207,24 @@ extern thread_local char ck_err_text[512];
         }                                                                                                   \
     } while (0)
 
+// Diagnostic knobs (CK_TILE_STOP_AFTER, CK_FIT_SKIP, CK_FMERGE_CAP, ...: kernels cut short, classes skipped, paths forced, launch
+// geometry varied) exist only in the -DCK_DIAG build (`make diag` -> chalkydri_amd/lib/diag/libchalkydri_hip.so), which the
+// measurement scripts under tools/ and the path-forcing tests load.  In the product build every knob IS its default: the macro
+// drops the name, so neither the getenv call nor the string is in the library a host links — the environment cannot change what
+// the drop-in returns.  The product library reads exactly two variables: CK_POISON (allocation fill / guard pages, below) and
+// CK_STREAMS (ck_stages.hip: the post-segmentation stages on two streams; the bytes do not depend on it).
+#ifdef CK_DIAG
+static inline int ck_knob_(const char *name, int dflt, int base) { const char *e = getenv(name); return e ? (int)strtol(e, nullptr, base) : dflt; }
+#define CK_KNOB(name, dflt) ck_knob_(name, dflt, 10)
+#define CK_KNOB0(name, dflt) ck_knob_(name, dflt, 0)   /* hexadecimal masks allowed */
+#define CK_KNOB_SET(name) (getenv(name) != nullptr)
+#else
+#define CK_KNOB(name, dflt) (dflt)
+#define CK_KNOB0(name, dflt) (dflt)
+#define CK_KNOB_SET(name) (false)
+#endif
+int ck_streams_wanted(); // ck_stages.hip: CK_STREAMS (1 or 2), read once
+
 // Device allocation of the handle's buffers.  CK_POISON=1 (tests) fills every buffer with 0xA5 bytes, so that a kernel which
 // reads an entry nobody wrote in this call — what an undersized capacity once made of the cluster and run tables — meets the
 // same garbage on every run instead of whatever the allocator happens to hand back.  CK_POISON=2 also lists the buffers.

@@ -58,8 +58,8 @@ int ck_stage_alloc(ck_handle *h) {
     CK_ALLOC(ck_malloc_dev(&ws.d_lscratch, 2 * sizeof(unsigned long long) * (size_t)CK_LSCRATCH_PER_WG * CK_LSCRATCH_WGS));
     ws.d_hscratch = nullptr;
     ws.hcap = (ws.max_cluster_points + 1023) & ~1023; // (1920 x 1080: 18 432 points, 144 MiB instead of the 512 MiB of the class's template capacity)
-    if (ws.hcap < 16384 && getenv("CK_FIT_GK")) ws.hcap = 16384;
-    if (ws.max_cluster_points > 16384 || getenv("CK_FIT_GK")) // (one copy per stream of a split batch)
+    if (ws.hcap < 16384 && CK_KNOB_SET("CK_FIT_GK")) ws.hcap = 16384;
+    if (ws.max_cluster_points > 16384 || CK_KNOB_SET("CK_FIT_GK")) // (one copy per stream of a split batch)
         CK_ALLOC(ck_malloc_dev(&ws.d_hscratch, 2 * sizeof(unsigned long long) * 2 * (size_t)ws.hcap * CK_HUGE_WGS));
     CK_ALLOC(ck_malloc_dev(&ws.d_clusters, sizeof(ck_cluster_t) * (size_t)ws.cluster_cap * nb));
     CK_ALLOC(ck_malloc_dev(&ws.d_counters, sizeof(uint32_t) * CK_CNT_STRIDE * nb));
@@ -126,7 +126,7 @@ void ck_stage_free(ck_handle *h) {
 // batch on the handle's stream (that is the stage the HBM roofline is quoted on); then the later pieces continue
 // on stream2 through a VIEW of the handle — a copy whose per-frame pointers are advanced by n0 frames and whose scratch
 // regions are the second copies allocated for it.  Frames are independent, so the results do not depend on the split.
-static int streams_wanted() {
+int ck_streams_wanted() {
     // default 1: since the fit kernels dequeue their clusters in chunks (no long tail left to fill) two dense kernels side by
     // side only get in each other's way (21.8 vs 22.4 ms per 1280x800x256 batch); CK_STREAMS=2 keeps the split available
     static const int v = getenv("CK_STREAMS") ? atoi(getenv("CK_STREAMS")) : 1;
@@ -186,7 +186,7 @@ struct ck_split {
     bool split() const { return parts > 1; }
 };
 static int parts_wanted() {
-    static const int v = getenv("CK_PARTS") ? atoi(getenv("CK_PARTS")) : 2;
+    static const int v = CK_KNOB("CK_PARTS", 2);
     return v < 1 ? 1 : (v > 8 ? 8 : v);
 }
 
@@ -199,7 +199,7 @@ static int run_pipeline(ck_handle *h, const uint8_t *frames, int stride, size_t 
     CK_HIP(hipEventRecord(ev[2], h->stream));
     int parts = parts_wanted();
     if (parts > n) parts = n;
-    if (!split || parts < 2 || streams_wanted() < 2) {
+    if (!split || parts < 2 || ck_streams_wanted() < 2) {
         if (split) { split->parts = 1; split->first[0] = 0; split->first[1] = n; }
         return run_tail(h, frames, stride, pitch, n, upto, true);
     }

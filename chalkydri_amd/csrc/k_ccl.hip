@@ -1,5 +1,6 @@
 // k_ccl.hip — adaptive threshold + union-find segmentation for gfx950 (the stage scored against the HBM
-// roofline: 7 algorithmic bytes per pixel = 1 R image + 1 W thresholded + 1 R thresholded + 4 W label).
+// roofline on SURVEY §8d's accounting: 7 algorithmic bytes per pixel = 1 R image + 1 W thresholded + 1 R thresholded + 4 W
+// label; the fused kernel below never re-reads the threshold map and writes 2-byte tile-local label words, so it moves fewer).
 //
 // Replaces, in the reference's production path, the threshold and connected-component stages of the external
 // AprilTag-3 detector reached at crates/apriltags/src/lib.rs:301; the connectivity rule is the one CAT spells
@@ -9,13 +10,15 @@
 // Structure (one launch each, batched over frames):
 //   k_tile   one workgroup (256 threads) per 32x128 tile.  Coalesced 16-byte loads of the tile + halo into LDS, 4x4
 //            min/max, 3x3 dilation, tri-state threshold (written once, 16 B/lane) and the rows' colour bits as 32-pixel
-//            words; a tile none of whose 4x4 tiles has contrast only stores constants.  The union-find works on RUNS, one lane
-//            per run from a compacted list (wave prefix sums), so that the phases are balanced: (a) adoption — a run takes ONE
-//            earlier run as parent with a plain store; (b) one pointer-jumping sweep over the static adoption forest; (c) the
-//            remaining links, pooled in LDS, one lane per link, through an atomic-min union; (d) flatten + exact sizes (ds_add
-//            into the roots' own entries); (e) ring-touching roots claimed from the 320 ring pixels and written to the tile's
-//            slice, white ids from 0 up and black ones from the top down; (f) label words written once (64 B/lane).  19.8 KB
-//            of LDS: eight workgroups per CU.  HBM traffic 1.3 R + 1 W + 4 W bytes per pixel.
+//            words; a tile none of whose 4x4 tiles has contrast only stores constants.  The union-find works on NODES = the
+//            components of 2 x 32 pixel blocks (a pair of rows, one word, one colour: ck_links.h), found with bit operations:
+//            (a) one lane per pair word (two waves per colour) lists its nodes and lets every node adopt ONE node of the pair
+//            above with a plain store; (b) the links that are left over, pooled in LDS, one lane per link, through an atomic-min
+//            union; (c) flatten + exact sizes (ds_add into the roots' own entries); (d) ring-touching roots claimed from the 320
+//            ring pixels and written to the tile's slice, white ids from 0 up and black ones from the top down; (e) the 16-bit
+//            label word of every node formed once into a table, one lookup per pixel, 16-byte stores (8 pixels) per lane and
+//            row.  19.6 KB of LDS: eight workgroups per CU.  HBM traffic per pixel: about 1.3 bytes read (tile + halo), 1 byte
+//            threshold + 2 bytes label word + 0.16 bytes ring entries written (measured: profiles/traffic_latest.json).
 //   k_fmerge the ring-touching roots of a frame's tiles are joined across the tile boundaries in LDS (ids and colours along the
 //            boundaries come from k_tile; no label or threshold word is read) and the frame's slot tables get every such
 //            component's frame-level root and size.  One workgroup per frame when its roots fit (both colours in one sweep),
@@ -1583,26 +1586,26 @@ __global__ __launch_bounds__(NT) void k_decimate(const uint8_t *__restrict__ src
 
 int ck_launch_threshold_segment(ck_handle *h, const uint8_t *frames, int stride, size_t frame_pitch, int n, bool precomputed) {
     const int tiles = h->tiles_x * h->tiles_y;
-    static const int stop_after = getenv("CK_TILE_STOP_AFTER") ? atoi(getenv("CK_TILE_STOP_AFTER")) : 99;
-    static const int sweeps = getenv("CK_TILE_SWEEPS") ? atoi(getenv("CK_TILE_SWEEPS")) : 0; // (pointer-jumping sweeps before the pooled unions: 0, 1 and 2 time the same since the nodes are pair components)
+    static const int stop_after = CK_KNOB("CK_TILE_STOP_AFTER", 99);
+    static const int sweeps = CK_KNOB("CK_TILE_SWEEPS", 0); // (pointer-jumping sweeps before the pooled unions: 0, 1 and 2 time the same since the nodes are pair components)
     // frames dealt to XCDs (a frame's tiles share one L2): worth it once there are frames for all eight (CK_TILE_XCD=0/1 forces it)
-    static const int xcd_env = getenv("CK_TILE_XCD") ? atoi(getenv("CK_TILE_XCD")) : -1;
-    static const int fm_stop = getenv("CK_FMERGE_STOP_AFTER") ? atoi(getenv("CK_FMERGE_STOP_AFTER")) : 99;
+    static const int xcd_env = CK_KNOB("CK_TILE_XCD", -1);
+    static const int fm_stop = CK_KNOB("CK_FMERGE_STOP_AFTER", 99);
     // CK_SEG_CHUNKS=k cuts the batch into k chunks of frames (multiples of 8: the XCD dealing) and runs chunk i's k_fmerge — one
     // workgroup per frame, bound by chains of dependent steps — on a side stream beside chunk i + 1's k_tile.  Measured on the
     // bench batch (1280 x 800 x 256, same box): 1.07 ms whole, 1.10 in two chunks, 1.22 in four, 1.77 in eight: the merge's
     // workgroups (16 waves and most of a CU's LDS each) displace more of k_tile than their waiting hides.  So the default is one chunk.
-    static const int chunks_env = getenv("CK_SEG_CHUNKS") ? atoi(getenv("CK_SEG_CHUNKS")) : 0;
+    static const int chunks_env = CK_KNOB("CK_SEG_CHUNKS", 0);
     int chunks = chunks_env > 0 ? chunks_env : 1;
     if (chunks > CK_SEG_CHUNKS_MAX) chunks = CK_SEG_CHUNKS_MAX;
     const int per = ((n + chunks - 1) / chunks + 7) & ~7;
-    const char *cap_env = getenv("CK_FMERGE_CAP"); // tests force the global-memory path with a small value (read per call)
+    const int cap_env = CK_KNOB("CK_FMERGE_CAP", 0); // the path-forcing tests (diag build) force the global-memory path with a small value (read per call)
     // roots the LDS path of one workgroup holds (dense binary noise has about 90 per tile).  A frame whose roots fit is joined by ONE
     // workgroup, both colours in one sweep; a larger one by two, one per colour (1920 x 1080 of dense noise: 23 000 each); a
     // workgroup with more takes the global-memory path.
     int cap = tiles * 120;
     cap = cap < 4096 ? 4096 : (cap > FM_CAP ? FM_CAP : cap);
-    if (cap_env && atoi(cap_env) < cap) cap = atoi(cap_env);
+    if (cap_env > 0 && cap_env < cap) cap = cap_env;
     // (the per-tile arrays and the join queues come first: very large frames leave less room for roots)
     const size_t fixed = (size_t)((tiles + 1 + 3) & ~3) * 4 + (size_t)(FM_NT / 64) * FM_WQS * 4 + (size_t)((tiles + 7) & ~7) * 2 * 3 + (size_t)tiles * 8;
     const size_t lds_max = 160 * 1024 - 512;

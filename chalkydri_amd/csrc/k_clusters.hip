@@ -453,13 +453,13 @@ int ck_launch_clusters(ck_handle *h, int n) {
     a.thresh = h->d_thresh; a.labels = h->d_labels; a.groot = h->d_groot; a.gsize = h->d_gsize; a.slots = (size_t)h->broot_cap;
     a.w = h->qw; a.h = h->qh; a.tiles_x = (h->qw + ETW - 1) / ETW; a.tiles_y = (h->qh + ETH - 1) / ETH;
     a.min_comp = h->cfg.min_component_px; a.ws = ws; a.ccl_tiles_x = h->tiles_x;
-    { static const int stop_after = getenv("CK_EMIT_STOP_AFTER") ? atoi(getenv("CK_EMIT_STOP_AFTER")) : 99; a.stop_after = stop_after; }
+    { static const int stop_after = CK_KNOB("CK_EMIT_STOP_AFTER", 99); a.stop_after = stop_after; }
     hipLaunchKernelGGL(k_emit, dim3((unsigned)(a.tiles_x * a.tiles_y * n)), dim3(NT), 0, h->stream, a);
     int min_cluster = h->cfg.min_cluster_pixels < 24 ? 24 : h->cfg.min_cluster_pixels;
     hipLaunchKernelGGL(k_scan, dim3((unsigned)n), dim3(SNT), 0, h->stream, ws, min_cluster, ws.max_cluster_points);
     if (n <= 4) hipLaunchKernelGGL(k_scatter<8>, dim3(256u, (unsigned)n), dim3(NT), 0, h->stream, ws);
     else {
-        static const unsigned sc_wgs = getenv("CK_SCATTER_WGS") ? (unsigned)atoi(getenv("CK_SCATTER_WGS")) : 32u; // (diagnostics: workgroups per frame)
+        static const unsigned sc_wgs = (unsigned)CK_KNOB("CK_SCATTER_WGS", 32); // (diagnostics: workgroups per frame)
         hipLaunchKernelGGL(k_scatter<64>, dim3(sc_wgs, (unsigned)n), dim3(NT), 0, h->stream, ws);
     }
     CK_HIP(hipGetLastError());

@@ -115,6 +115,9 @@ __device__ const double k_smooth[7] = {0.011108996538242306, 0.1353352832366127,
 // expcnt 6:4 and lgkmcnt 11:8 left at "do not wait"): placed BEFORE a prefetch is issued, so that what the iteration is about to use
 // is known to be there and the compiler's later waits (which, inside loops, are for everything outstanding) find nothing to sit on
 constexpr int WAIT_VMCNT0 = 0x0F70;
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__GFX9__)
+#error "WAIT_VMCNT0 is the gfx9-family encoding of s_waitcnt (this library is written for gfx950): another target needs its own"
+#endif
 // Barriers that order LDS traffic only.  __syncthreads() carries a workgroup-scope fence, which the compiler turns into a wait for
 // EVERY outstanding memory operation — a prefetch issued for the next cluster would be waited for at the first barrier behind it.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
@@ -2387,12 +2390,12 @@ int ck_launch_fit_quads(ck_handle *h, const uint8_t *qframes, int qstride, size_
     const ck_fit_layout fl = ck_fit_scratch_layout(ws, h->cfg.max_batch);
     const int list_cap = fl.list_cap;
     uint32_t *lists = fl.lists, *list_counts = fl.list_counts, *heads = fl.heads;
-    static const int fit_split = getenv("CK_FIT_SPLIT") ? atoi(getenv("CK_FIT_SPLIT")) : 3; // (diagnostics: bit 0 = 513..1024 points have their own class, bit 1 = up to 256 points have)
+    static const int fit_split = CK_KNOB("CK_FIT_SPLIT", 3); // (diagnostics: bit 0 = 513..1024 points have their own class, bit 1 = up to 256 points have)
     // A small call (one frame per call is the reference's own pattern) gives every class a handful of workgroups whose time is
     // one cluster's dependency chain: the classes then run side by side on their own streams instead of one after the other —
     // and without the two youngest classes, which exist for throughput (more clusters in flight per CU) and would only add two
     // more chains to the handle's lane (0.64 -> 0.70 ms per 1280x800 frame at quad_decimate 2).
-    static const int force_par = getenv("CK_FIT_PAR") ? atoi(getenv("CK_FIT_PAR")) : 0;
+    static const int force_par = CK_KNOB("CK_FIT_PAR", 0);
     // (measured at 1280x800: side by side wins up to 16 frames at quad_decimate 1, up to 32 at 2, where the clusters are fewer)
     const bool side_by_side = n <= (h->cfg.quad_decimate > 1 ? 2 * CK_FIT_PARALLEL_MAX_FRAMES : CK_FIT_PARALLEL_MAX_FRAMES) || force_par;
     const int split = side_by_side ? 0 : fit_split;
@@ -2407,9 +2410,9 @@ int ck_launch_fit_quads(ck_handle *h, const uint8_t *qframes, int qstride, size_
     };
     // The split fit needs the weights in its second kernel only: the weight image (a streaming kernel, bound by HBM) then runs on the
     // second side stream beside the first kernels (bound by their sort) instead of before them (CK_FIT_WIMG_ASIDE=0: as before)
-    static const int flat_env0 = getenv("CK_FIT_FLAT") ? atoi(getenv("CK_FIT_FLAT")) : 1;
-    static const int wimg_aside_env = getenv("CK_FIT_WIMG_ASIDE") ? atoi(getenv("CK_FIT_WIMG_ASIDE")) : 1;
-    static const int tails_aside_ok0 = (getenv("CK_FIT_TAILS_ASIDE") ? atoi(getenv("CK_FIT_TAILS_ASIDE")) : 1) && (getenv("CK_STREAMS") ? atoi(getenv("CK_STREAMS")) : 1) < 2;
+    static const int flat_env0 = CK_KNOB("CK_FIT_FLAT", 1);
+    static const int wimg_aside_env = CK_KNOB("CK_FIT_WIMG_ASIDE", 1);
+    static const int tails_aside_ok0 = CK_KNOB("CK_FIT_TAILS_ASIDE", 1) && ck_streams_wanted() < 2;
     const bool flat0 = flat_env0 >= 2 || (flat_env0 == 1 && !side_by_side && (size_t)n * (size_t)h->qw * (size_t)h->qh >= ((size_t)100 << 20));
     const bool wimg_aside = flat0 && !side_by_side && tails_aside_ok0 && wimg_aside_env;
     if (!wimg_aside) launch_wimg(h->stream);
@@ -2425,8 +2428,8 @@ int ck_launch_fit_quads(ck_handle *h, const uint8_t *qframes, int qstride, size_
     a.min_tag_width /= h->cfg.quad_decimate;
     if (a.min_tag_width < 3) a.min_tag_width = 3;
     a.ws = ws; a.list_cap = list_cap;
-    { const char *e = getenv("CK_FIT_STOP_AFTER"); a.stop_after = e ? atoi(e) : 99; }
-    { const char *e = getenv("CK_FIT_GUIDED"); a.guided = e ? atoi(e) : 1; }
+    a.stop_after = CK_KNOB("CK_FIT_STOP_AFTER", 99); // (read per call)
+    a.guided = CK_KNOB("CK_FIT_GUIDED", 1);
     // chunk sizes: 512 points for the multi-wave classes (fewer scans and barriers per point, 9 % less halo work); their LDS
     // then sits at the occupancy steps — 52.9 KB (3 workgroups/CU), 80.5 KB (2/CU), ≈ 124 KB and ≈ 163 KB (1/CU each)
     int cus = 256;
@@ -2437,15 +2440,14 @@ int ck_launch_fit_quads(ck_handle *h, const uint8_t *qframes, int qstride, size_
     // per workgroup on average, so a quarter of the CUs do a third cluster while the rest idle; the largest; 4097..8192): one after
     // the other on a side stream, started first, their tails and barrier waits run under the small classes instead of before
     // them.  (Measured: the 2049..4096 class there as well, or the three on two side streams, is slower than this.)
-    static const int tails_aside_ok = (getenv("CK_FIT_TAILS_ASIDE") ? atoi(getenv("CK_FIT_TAILS_ASIDE")) : 1) &&
-                                      (getenv("CK_STREAMS") ? atoi(getenv("CK_STREAMS")) : 1) < 2;
+    static const int tails_aside_ok = tails_aside_ok0;
     const bool tails_aside = !side_by_side && tails_aside_ok;
     if (side_by_side) { cs[3] = h->fit_stream[0]; cs[2] = h->fit_stream[1]; cs[4] = h->fit_stream[1]; }
     if (tails_aside) { cs[4] = h->fit_stream[0]; cs[5] = h->fit_stream[0]; cs[3] = h->fit_stream[0]; }
     // (diagnostics: CK_FIT_ASIDE: bit c set = class c on side stream 0, bit 8 + c = on side stream 1.  Split fit, measured: the three
     // largest classes aside (0x38) 8.59 ms · with the 2049-4096 class 8.68 · with the 1025-2048 class too 8.65 · the 4097-8192 class back
     // on the handle's stream 8.57 · or on the second side stream 8.52 · ...: all within the noise of one box)
-    static const int aside_env = getenv("CK_FIT_ASIDE") ? (int)strtol(getenv("CK_FIT_ASIDE"), nullptr, 0) : -1;
+    static const int aside_env = CK_KNOB0("CK_FIT_ASIDE", -1);
     if (tails_aside && aside_env >= 0)
         for (int c = 0; c < CK_FIT_CLASSES; c++) cs[c] = ((aside_env >> c) & 1) ? h->fit_stream[0] : (((aside_env >> (8 + c)) & 1) ? h->fit_stream[1] : h->stream);
     if (side_by_side || tails_aside) {
@@ -2453,19 +2455,18 @@ int ck_launch_fit_quads(ck_handle *h, const uint8_t *qframes, int qstride, size_
         for (int k = 0; k < CK_FIT_SIDE_STREAMS; k++) CK_HIP(hipStreamWaitEvent(h->fit_stream[k], h->ev_fit_fork, 0));
         if (wimg_aside) launch_wimg(h->fit_stream[1]); // (joined with the side streams before k_chunk)
     }
-    static const int gk_env = getenv("CK_FIT_GK") ? atoi(getenv("CK_FIT_GK")) : 0; // (experiment: bit c set = class c keeps its keys in global memory: small LDS, more workgroups per CU)
+    static const int gk_env = CK_KNOB("CK_FIT_GK", 0); // (experiment: bit c set = class c keeps its keys in global memory: small LDS, more workgroups per CU)
     const int gk_mask = ws.d_hscratch ? gk_env : 0;
-    static const int skip_mask = getenv("CK_FIT_SKIP") ? atoi(getenv("CK_FIT_SKIP")) : 0; // (diagnostics: bit c set = class c is not launched)
+    static const int skip_mask = CK_KNOB("CK_FIT_SKIP", 0); // (diagnostics: bit c set = class c is not launched)
     // The split fit (k_seq per class -> k_chunk over all positions -> k_tail over all clusters): CK_FIT_FLAT = 0 never, 2 always,
     // 1 (default): for calls that run their classes one after the other AND bring enough pixels — its three stages each ramp a
     // persistent grid up and down, which a quarter-size batch notices (1280x800 x 256 at quad_decimate 2: 2.85 against 2.52 ms
     // unsplit; at full resolution 9.75 against 9.94, 1920x1080 21.4 against 22.7, 2448x2048 x 128 27.8 against 31.5)
-    static const int flat_env = getenv("CK_FIT_FLAT") ? atoi(getenv("CK_FIT_FLAT")) : 1;
+    static const int flat_env = flat_env0;
     const bool flat = flat_env >= 2 || (flat_env == 1 && !side_by_side && (size_t)n * (size_t)h->qw * (size_t)h->qh >= ((size_t)100 << 20));
-    static const int seq_alt = getenv("CK_SEQ_ALT") ? atoi(getenv("CK_SEQ_ALT")) : 0; // (diagnostics: bit c = class c of k_seq with a tighter register budget)
+    static const int seq_alt = CK_KNOB("CK_SEQ_ALT", 0); // (diagnostics: bit c = class c of k_seq with a tighter register budget)
     // (diagnostics: workgroups per CU of k_seq's three smallest classes)
-    static const int seq_wgs0 = getenv("CK_SEQ_WGS0") ? atoi(getenv("CK_SEQ_WGS0")) : 16, seq_wgs7 = getenv("CK_SEQ_WGS7") ? atoi(getenv("CK_SEQ_WGS7")) : 16,
-                     seq_wgs6 = getenv("CK_SEQ_WGS6") ? atoi(getenv("CK_SEQ_WGS6")) : 8;
+    static const int seq_wgs0 = CK_KNOB("CK_SEQ_WGS0", 16), seq_wgs7 = CK_KNOB("CK_SEQ_WGS7", 16), seq_wgs6 = CK_KNOB("CK_SEQ_WGS6", 8);
     auto launch_split = [&](int c) {
         switch (c) {
         // (tighter register budgets for the four classes below — six / eight / five / five waves per SIMD — measured: no difference)
@@ -2488,7 +2489,7 @@ int ck_launch_fit_quads(ck_handle *h, const uint8_t *qframes, int qstride, size_
         a.list = lists + (size_t)c * list_cap; a.list_count = list_counts + c; a.head = heads + c;
         if (flat) { launch_split(c); return; }
         switch (c) {
-        case 0: { static const int s_wgs = getenv("CK_FIT_S_WGS") ? atoi(getenv("CK_FIT_S_WGS")) : 12; // (diagnostics: workgroups per CU of the small class)
+        case 0: { static const int s_wgs = CK_KNOB("CK_FIT_S_WGS", 12); // (diagnostics: workgroups per CU of the small class)
             hipLaunchKernelGGL((k_fit<64, 512, 64, true, 3>), dim3((unsigned)(cus * s_wgs)), dim3(64), 0, cs[c], a); break; }
         case 7: hipLaunchKernelGGL((k_fit<64, 256, 64, true, 4>), dim3((unsigned)(cus * 16)), dim3(64), 0, cs[c], a); break;
         case 6: hipLaunchKernelGGL((k_fit<128, 1024, 128, true, 4>), dim3((unsigned)(cus * 7)), dim3(128), 0, cs[c], a); break;
@@ -2518,8 +2519,8 @@ int ck_launch_fit_quads(ck_handle *h, const uint8_t *qframes, int qstride, size_
     if (flat) {
         // spans per frame and workgroups that share them: a batch gives every workgroup a few spans, a short call one each
         const unsigned spans = (unsigned)(ws.ext_cap / CK_SPAN);
-        static const int chunk_wgs = getenv("CK_CHUNK_WGS") ? atoi(getenv("CK_CHUNK_WGS")) : 64; // (diagnostics: k_chunk workgroups per CU over the batch)
-        static const int tail_wgs = getenv("CK_TAIL_WGS") ? atoi(getenv("CK_TAIL_WGS")) : 16;    // (diagnostics: k_tail workgroups per CU)
+        static const int chunk_wgs = CK_KNOB("CK_CHUNK_WGS", 64); // (diagnostics: k_chunk workgroups per CU over the batch)
+        static const int tail_wgs = CK_KNOB("CK_TAIL_WGS", 16);    // (diagnostics: k_tail workgroups per CU)
         unsigned gx = (unsigned)((cus * chunk_wgs + n - 1) / n);
         if (gx < 8) gx = 8;
         if (gx > spans) gx = spans;

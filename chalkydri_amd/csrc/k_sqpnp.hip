@@ -269,7 +269,7 @@ struct SolveArgs {
     double *world;  // [n][max_points][3]
     int stop_after; // diagnostics (CK_SQ_STOP_AFTER): 1 after Omega, 2 after the eigen-decomposition, 3 after the refinements
 };
-static int sq_stop_after() { static const int v = getenv("CK_SQ_STOP_AFTER") ? atoi(getenv("CK_SQ_STOP_AFTER")) : 99; return v; }
+static int sq_stop_after() { static const int v = CK_KNOB("CK_SQ_STOP_AFTER", 99); return v; }
 
 constexpr int SQ_NT = 128; // two waves: six candidate groups of 16 lanes in the refinement, 128-wide loops elsewhere
 __global__ __launch_bounds__(SQ_NT) void k_sqpnp(SolveArgs a) {

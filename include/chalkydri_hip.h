@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define CK_ABI_VERSION 2
+#define CK_ABI_VERSION 3 /* 3: ck_gather_poses takes (n_valid, rows) — a changed prototype is a new version, like a changed struct */
 
 /* ---- status codes ------------------------------------------------------------------------- */
 enum {
@@ -342,7 +342,7 @@ int ck_process_ingested(ck_ingest_t *ing, int32_t slot, int32_t n, const ck_proc
 /* ---- multi-GPU: the final pose gather ----------------------------------------------------------------------------------
  * Frames shard over GPUs without any data-path collective (one handle, one process or host thread per GPU).  The only
  * exchange is the gather of the 64-byte records (the wire struct of crates/whacknet/src/lib.rs:43-66): ONE ncclAllGather
- * (RCCL over xGMI) of n x 64 bytes per batch on the handle's stream.  The host distributes the 128-byte id that rank 0
+ * (RCCL over xGMI) of n x 64 bytes per batch, on the communicator's own stream beside the handle's next batch.  The host distributes the 128-byte id that rank 0
  * obtains from ck_comm_unique_id over whatever channel it has (the reference has UDP; the Python mirror uses
  * torch.distributed's store).  librccl is opened on first use: CK_EUNSUPPORTED when it cannot be loaded. */
 #define CK_COMM_ID_BYTES 128
@@ -357,10 +357,14 @@ void ck_comm_destroy(ck_comm_t *comm);
  * own, so a wrong count would ship stale records); rows = the common row count of the collective, the same on every rank,
  * n_valid <= rows <= max_batch: the library pads a ragged last shard with empty records (all zero, tag_count = 0 — what a
  * frame without a pose publishes anyway: crates/apriltags/src/lib.rs:365-376).  `out` may be a host or a device pointer.
- * sync = 0 only enqueues on the handle's stream; ck_comm_sync (or the next synchronous call) completes it.  Destroy a
- * communicator before the handle it was made for. */
+ * sync = 0 only enqueues: the handle's stream copies the records aside (the next ck_process_* call may follow at once) and the
+ * collective runs on the communicator's stream; `out` is complete after ck_comm_sync (or a later call with sync = 1) — NOT after
+ * a synchronisation of the handle alone.  A rank whose n_valid fails the local check still takes part with `rows` empty records
+ * and then returns CK_EINVAL, so its peers complete; after any other error of a collective destroy the communicator on every rank.
+ * Destroy a communicator before the handle it was made for. */
 int ck_gather_poses(ck_handle_t *h, ck_comm_t *comm, int32_t n_valid, int32_t rows, ck_vision_measurement_t *out, int32_t sync);
 int ck_comm_sync(ck_comm_t *comm);
+const char *ck_comm_library(const ck_comm_t *comm);      /* path of the librccl the communicator's calls resolved to */
 
 /* OpenCVModel5 unprojection of pixel points to bearings (x,y,1)/norm; ok[i]=0 when it does not converge. */
 int ck_unproject_opencv5(const ck_opencv5_t *cam, const double *px, int32_t n, double *bearings,

@@ -11,7 +11,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(_HERE))
 from chalkydri_amd import _abi as A  # noqa: E402  (POD struct mirrors only)
 
-LIB_PATH = os.path.join(_HERE, "libck_oracle.so")
+# CK_ORACLE_LIB: another build of the same sources (the -O3 -march=native one of the CPU baseline, checked against the goldens)
+LIB_PATH = os.environ.get("CK_ORACLE_LIB") or os.path.join(_HERE, "libck_oracle.so")
 _lib = None
 
 

@@ -1,6 +1,7 @@
 """Replays one case of tests/stress_segment.py (the frames are rebuilt from the case's seeds): python tests/dbg_segment_case.py <cases_seed> <case_index> [threshold|segment]"""
 import os, sys, json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+os.environ.setdefault("CHALKYDRI_HIP_LIB", os.path.join(ROOT, "chalkydri_amd", "lib", "diag", "libchalkydri_hip.so"))  # (CK_FMERGE_CAP: diagnostics build)
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle")); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import stress_segment as S

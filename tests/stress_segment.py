@@ -3,6 +3,8 @@ geometries (ragged widths / heights included), random content mixes, random min_
 CK_FMERGE_CAP, every path of the merge kernel.  usage: python tests/stress_segment.py [cases] [seed]"""
 import os, sys, json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if __name__ == "__main__":   # CK_FMERGE_CAP is a knob of the diagnostics build: as a script this file runs against that library
+    os.environ.setdefault("CHALKYDRI_HIP_LIB", os.path.join(ROOT, "chalkydri_amd", "lib", "diag", "libchalkydri_hip.so"))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle")); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import importlib.util

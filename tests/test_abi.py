@@ -32,7 +32,7 @@ def test_struct_layouts():
     assert C.sizeof(A.Detection) == 96 and C.sizeof(A.ClusterPoint) == 8 and C.sizeof(A.Cluster) == 16
     assert C.sizeof(A.Iso3) == 56 and C.sizeof(A.SqpnpResult) == 144
     L = _lib.lib()
-    assert L.ck_abi_version() == 2
+    assert L.ck_abi_version() == 3
 
 
 def test_defaults_mirror_the_reference(built):
@@ -103,3 +103,61 @@ def test_create_validates_before_touching_a_device(built):
     assert rc() in (A.CK_OK, A.CK_ENODEVICE)                    # a valid config fails only for lack of a device
     if h.value:
         L.ck_destroy(h)
+
+
+def test_product_library_reads_no_diagnostic_knob(built):
+    """The drop-in must not change what it returns with the environment: the measurement / path-forcing knobs (CK_*_STOP_AFTER,
+    CK_FIT_SKIP, CK_FMERGE_CAP, CK_SEG_CHUNKS, ...) exist only in the -DCK_DIAG build (lib/diag/).  The product library names exactly
+    two variables: CK_POISON (allocation fill / guard pages) and CK_STREAMS (post-segmentation stages on two streams: same bytes)."""
+    import re
+    from conftest import DIAG_LIB
+    from chalkydri_amd import _lib
+    prod = open(os.path.join(os.path.dirname(_lib.__file__), "lib", "libchalkydri_hip.so"), "rb").read()
+    names = set(m.decode() for m in re.findall(rb"CK_[A-Z0-9_]{3,}(?=\x00)", prod))
+    # (error-code names appear in ck_strerror's texts; anything else that looks like a knob is a failure)
+    knobs = {n for n in names if not n.startswith(("CK_E", "CK_OK", "CK_FRAME_", "CK_HIP", "CK_ALLOC", "CK_ABI"))}
+    assert knobs <= {"CK_POISON", "CK_STREAMS"}, knobs
+    assert b"STOP_AFTER" not in prod and b"CK_FIT_" not in prod and b"CK_FMERGE" not in prod
+    diag = open(DIAG_LIB, "rb").read()
+    for k in (b"CK_TILE_STOP_AFTER", b"CK_FMERGE_CAP", b"CK_FIT_FLAT", b"CK_FIT_SKIP", b"CK_PARTS", b"CK_EMIT_STOP_AFTER"):
+        assert k in diag, k
+
+
+def test_fit_kernels_keep_their_register_budgets(built):
+    """The split quad fit's kernels read other lanes' registers (v_readlane) around divergent code; a build of k_tail that spilled
+    heavily once lost detections (the reads stood inside divergent blocks, where the spill code restores active lanes
+    only).  The reads are all-lane now and the current build is verified by the full-size tests — this check makes a toolchain or
+    source change that pushes a kernel over its budget fail HERE, on the CPU, instead of silently at 2448x2048: the code
+    object's own metadata (llvm-readelf --notes) must show no spill in k_chunk and k_tile, at most the known 2 registers in
+    k_tail, and no scratch at all in the segmentation kernels."""
+    import shutil
+    import subprocess
+    import tempfile
+    llvm = "/opt/rocm/lib/llvm/bin"
+    if not os.path.exists(os.path.join(llvm, "llvm-objdump")):
+        pytest.skip("no llvm-objdump in this image")
+    build = os.path.join(ROOT, "chalkydri_amd", "csrc", "build")
+    res = {}
+    with tempfile.TemporaryDirectory() as td:
+        for obj in ("k_quads.o", "k_ccl.o"):
+            shutil.copy(os.path.join(build, obj), td)
+            subprocess.check_call([os.path.join(llvm, "llvm-objdump"), "--offloading", obj], cwd=td, stdout=subprocess.DEVNULL)
+            co = [f for f in os.listdir(td) if f.startswith(obj) and "amdgcn" in f][0]
+            notes = subprocess.check_output([os.path.join(llvm, "llvm-readelf"), "--notes", co], cwd=td, text=True)
+            name = None
+            for line in notes.splitlines():
+                m = re.match(r"\s*\.name:\s+(\S+)", line)
+                if m:
+                    name = m.group(1)
+                    res[name] = {}
+                m = re.match(r"\s*\.(vgpr_spill_count|sgpr_spill_count|private_segment_fixed_size|vgpr_count):\s+(\d+)", line)
+                if m and name:
+                    res[name][m.group(1)] = int(m.group(2))
+    pick = lambda frag: [(k, v) for k, v in res.items() if frag in k]
+    assert pick("k_chunk") and pick("k_tail") and pick("k_tile") and pick("k_fmerge")
+    for k, v in pick("k_chunk") + pick("k_tile") + pick("k_fmerge"):
+        assert v["vgpr_spill_count"] == 0 and v["private_segment_fixed_size"] == 0, (k, v)
+    for k, v in pick("k_tail"):
+        assert v["vgpr_spill_count"] <= 2, (k, v)
+    for k, v in pick("k_seq"):   # the sort kernels: budgets as measured (DESIGN.md §5); a jump means the class lost its occupancy step
+        assert v["vgpr_spill_count"] <= 20, (k, v)

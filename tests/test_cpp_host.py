@@ -30,6 +30,29 @@ def test_header_declares_reference_surface():
         assert name in src, name
 
 
+def test_gather_ranks_harness_builds_and_skips_without_a_gpu(built):
+    """tests/cpp/gather_ranks.cpp links against the C ABI alone; with no GPU in the KFD topology it says so and exits 0."""
+    exe = os.path.join(ROOT, "chalkydri_amd", "lib", "gather_ranks")
+    assert os.path.exists(exe)
+    if not os.path.isdir("/sys/class/kfd/kfd/topology/nodes"):
+        r = subprocess.run([exe], capture_output=True, text=True, timeout=60)
+        assert r.returncode == 0 and "GATHER_RANKS_SKIP" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+def test_gather_ranks_one_process_per_gpu(built):
+    """The pose gather the way a Rust / C++ host runs it — no Python, no torch in the ranks: the parent forks one child per visible
+    GPU before any HIP call, the RCCL id travels through pipes, every rank processes two ragged batches, enqueues both gathers
+    (sync = 0: step 1's rendezvous on the communicator's stream beside step 2's kernels) and the parent compares what every rank
+    received with what every rank produced.  One rank on a one-GPU box, N on an N-GPU node (record layout:
+    /root/reference/crates/whacknet/src/lib.rs:43-66)."""
+    exe = os.path.join(ROOT, "chalkydri_amd", "lib", "gather_ranks")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "GATHER_RANKS_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+    assert "librccl" in r.stderr
+
+
 @pytest.mark.gpu
 def test_cpp_host_matches_python_mirror(built, tmp_path):
     import scenes

@@ -95,6 +95,48 @@ def test_tag36h11_verified_prefix_sits_on_the_generator_lattice():
     assert family("tag16h5").contents.n_upstream == 30
 
 
+# 61 further upstream tag36h11 codes, AprilTag-3 form, as recalled by the round-3 review — UNTRUSTED input until the lattice test
+# below has placed every one of them on the generator's walk at the stated, strictly increasing k.
+TAG36H11_AT3_MORE = [
+    0x9de96b718, 0xaff6e5a8a, 0xbae46f029, 0xd225b6d59, 0xdf8ba8c01, 0xe3744a22f, 0xfbb59375d, 0x18a916828, 0x22f29c1ba, 0x286887d58,
+    0x41392322e, 0x75d18ecd1, 0x87c302743, 0x8c6317ba9, 0x9e40f36d7, 0xc0e5a806a, 0xcc78cb87c, 0x12d2f2d01, 0x379f36a21, 0x6973f59ac,
+    0x7789ea9f4, 0x8f1c73e84, 0x8dd287a20, 0x94a4eee4c, 0xa455379b5, 0xa9e92987d, 0xbd25cb40b, 0xbe98d3582, 0xd3d5972b2, 0x14c53d7c7,
+    0x4f1796936, 0x4e71fed1a, 0x66d46fae0, 0xa55abb933, 0xebee1acca, 0x1ad4ba6a4, 0x305b17571, 0x553611351, 0x59ca62775, 0x7819cb6a1,
+    0xedb7bc9eb, 0x5b2694212, 0x72e12d185, 0xed6152e2c, 0x5bcdadbf3, 0x78e0aa0c6, 0xc60a0b909, 0xef9a34b0d, 0x398a6621a, 0xa8a27c944,
+    0x4b564304e, 0x52902b4e2, 0x857280b56, 0xa91b2c84b, 0xe91df939b, 0x1fa405f28, 0x23793ab86, 0x68c17729f, 0x9fbf3b840, 0x36922413c,
+    0x4eb5f946e]
+TAG36H11_K_MORE = [125, 129, 133, 139, 141, 144, 150, 158, 162, 164, 169, 184, 188, 190, 195, 205, 208, 227, 235, 251, 253, 259, 260, 261,
+                   267, 269, 272, 342, 350, 367, 382, 383, 389, 407, 426, 439, 446, 454, 457, 464, 495, 526, 533, 566, 597, 605, 624, 635,
+                   657, 687, 732, 733, 748, 757, 775, 788, 791, 811, 823, 865, 871]
+
+
+def test_tag36h11_entries_39_to_99_are_upstream_codes_on_the_lattice():
+    """Table entries 39..99: upstream codes (not claimed to be upstream INDICES: n_upstream stays 39).  Each recalled AprilTag-3
+    value, carried back to the AprilTag-2 form through the family's own bit layout, is code0 + k * 982451653 mod 2^36 at the
+    stated k; the k's continue the verified prefix's walk (120 < 125 < ... < 871); the table holds them at 39..99 in that
+    order; and (test_tag36h11_layout_anchors_and_distance_11) the whole table keeps distance 11 under rotation, so no stand-in
+    of entries 100..586 lies within 10 bits of a real tag's code."""
+    f, codes = _codes("tag36h11")
+    bx = [f.bit_x[i] for i in range(36)]
+    by = [f.bit_y[i] for i in range(36)]
+
+    def at3_to_at2(c):
+        out = 0
+        for i in range(36):
+            k = (by[i] - 1) * 6 + (bx[i] - 1)
+            out |= ((c >> (35 - i)) & 1) << (35 - k)
+        return out
+
+    prime, mask = 982451653, (1 << 36) - 1
+    inv = pow(prime, -1, 1 << 36)
+    at2 = [at3_to_at2(c) for c in TAG36H11_AT3_MORE]
+    assert [_at2_to_at3(c, bx, by, 6) for c in at2] == TAG36H11_AT3_MORE               # the conversion is a bijection
+    ks = [((c - TAG36H11_AT2_HEAD[0]) * inv) & mask for c in at2]
+    assert ks == TAG36H11_K_MORE and all(b > a for a, b in zip([TAG36H11_K[-1]] + ks, ks))
+    assert codes[39:100].tolist() == TAG36H11_AT3_MORE
+    assert f.n_upstream == 39
+
+
 def test_unknown_family():
     import pytest
     with pytest.raises(KeyError):

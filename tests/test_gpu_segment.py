@@ -63,23 +63,43 @@ def test_threshold_segment_bit_exact(oracle, w, h, kind):
     det.close()
 
 
-@pytest.mark.parametrize("kind,cap", [("noise", 64), ("blobs", 64), ("spiral", 64), ("checker1", 64),
-                                      ("noise", 1200), ("noise", 2000), ("noise", 3000), ("checker1", 2000), ("spiral", 300)])
-def test_merge_paths_beyond_one_workgroups_lds(oracle, kind, cap, monkeypatch):
+MERGE_PATH_CASES = [("noise", 64), ("blobs", 64), ("spiral", 64), ("checker1", 64),
+                    ("noise", 1200), ("noise", 2000), ("noise", 3000), ("checker1", 2000), ("spiral", 300)]
+
+
+def merge_path_cases():
+    """Runs in a child process against the diagnostics build (the knob does not exist in the product library)."""
+    import os
+    import pyoracle
+    from chalkydri_amd import _lib
+    from chalkydri_amd.detector import AprilTagDetector
+    assert b"CK_FMERGE_CAP" in open(_lib.LIB_PATH, "rb").read(), "not the diagnostics build: " + _lib.LIB_PATH
+    w, h, n = 640, 480, 2
+    for kind, cap in MERGE_PATH_CASES:
+        os.environ["CK_FMERGE_CAP"] = str(cap)   # (read per call)
+        frames = _frames(kind, w, h, n, 5)
+        det = AprilTagDetector(w, h, max_batch=n)
+        labels, sizes = det.segment(frames)
+        for i in range(n):
+            ol, osz = pyoracle.segment(pyoracle.threshold(frames[i]))
+            assert np.array_equal(labels[i], ol) and np.array_equal(sizes[i], osz), (kind, cap, i)
+        det.close()
+    print("MERGE_PATHS_OK", len(MERGE_PATH_CASES))
+
+
+def test_merge_paths_beyond_one_workgroups_lds(oracle):
     """A frame with more ring-touching roots than one merge workgroup's LDS holds (parents + keys) is joined by two workgroups,
     one per colour; a workgroup with still more roots keeps only the parents in LDS (up to twice the capacity), and beyond
-    that runs in global memory.  Forced here with small capacities (CK_FMERGE_CAP) on maps whose components span many tiles:
-    640x480 noise has about 3 400 roots per colour, so 64 means global memory, 2000 and 3000 parents-only, 1200 a mix."""
-    from chalkydri_amd.detector import AprilTagDetector
-    monkeypatch.setenv("CK_FMERGE_CAP", str(cap))
-    w, h, n = 640, 480, 2
-    frames = _frames(kind, w, h, n, 5)
-    det = AprilTagDetector(w, h, max_batch=n)
-    labels, sizes = det.segment(frames)
-    for i in range(n):
-        ol, osz = oracle.segment(oracle.threshold(frames[i]))
-        assert np.array_equal(labels[i], ol) and np.array_equal(sizes[i], osz)
-    det.close()
+    that runs in global memory.  Forced with small capacities (CK_FMERGE_CAP, a knob of the diagnostics build: hence the child
+    process) on maps whose components span many tiles: 640x480 noise has about 3 400 roots per colour, so 64 means global memory,
+    2000 and 3000 parents-only, 1200 a mix."""
+    import os, subprocess, sys
+    from conftest import ROOT, diag_env
+    code = ("import sys; sys.path[:0] = [%r, %r, %r]; import importlib.util as u; "
+            "sp = u.spec_from_file_location('tseg', %r); m = u.module_from_spec(sp); sp.loader.exec_module(m); m.merge_path_cases()"
+            % (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests"), os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], env=diag_env(), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "MERGE_PATHS_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
 
 
 @pytest.mark.parametrize("w,h", [(1920, 1080), (2448, 2048), (4092, 2200)])

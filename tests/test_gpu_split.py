@@ -43,6 +43,9 @@ print("HASH", hh.hexdigest(), int(np.sum(valid)))
 
 def _run(env_extra):
     env = dict(os.environ, **env_extra)
+    if "CK_PARTS" in env_extra:   # the number of pieces is a knob of the diagnostics build (the product library cuts in two)
+        from conftest import DIAG_LIB
+        env["CHALKYDRI_HIP_LIB"] = DIAG_LIB
     r = subprocess.run([sys.executable, "-c", SCRIPT % (ROOT, os.path.join(ROOT, "tests"))], capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("HASH")][0].split()

@@ -8,8 +8,18 @@ pytestmark = pytest.mark.gpu
 
 
 def test_stress_segment(oracle):
+    """(a child process against the diagnostics build: the cases draw CK_FMERGE_CAP, which the product library does not read)"""
+    import os, subprocess, sys
+    from conftest import diag_env
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, os.path.join(here, "stress_segment.py"), "60", "101"], env=diag_env(), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and '"mismatching_frames": 0' in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_stress_segment_product_library(oracle):
+    """the same kind of cases on the product library (every frame takes the merge path its size asks for)"""
     import stress_segment
-    assert stress_segment.run(60, 101) == 0
+    assert stress_segment.run(25, 112) == 0
 
 
 def test_stress_detect(oracle):
@@ -57,7 +67,8 @@ def test_stress_detect_split_fit_on_small_calls(oracle, caps):
     path too — with undersized, poisoned buffers in the second run."""
     import os, subprocess, sys
     here = os.path.dirname(os.path.abspath(__file__))
-    env = dict(os.environ, CK_FIT_FLAT="2")
+    from conftest import diag_env
+    env = diag_env(CK_FIT_FLAT="2")   # (a knob of the diagnostics build)
     if caps: env.update(STRESS_CAPS="1", CK_POISON="1")
     r = subprocess.run([sys.executable, os.path.join(here, "stress_detect.py"), "40", "111" if caps else "109"], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]

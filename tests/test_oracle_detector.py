@@ -117,3 +117,17 @@ def test_decimate2_corners_are_full_resolution(oracle):
     for t in truth:
         assert t["id"] in ids
         assert np.abs(ids[t["id"]]["p"] - t["corners"]).max() < 2.0
+
+
+def test_native_build_reproduces_the_goldens(oracle):
+    """bench.py times the oracle as `-O3 -march=native -ffp-contract=off` (oracle/Makefile: native).  That build must be
+    the same function as the -O2 checker: this file's golden-vector test and the SQPnP / CAT ones, re-run in a child process
+    against it (CK_ORACLE_LIB)."""
+    import subprocess, sys
+    root = os.path.dirname(HERE)
+    subprocess.check_call(["make", "-s", "-C", os.path.join(root, "oracle"), "native"])
+    env = dict(os.environ, CK_ORACLE_LIB=os.path.join(root, "oracle", "libck_oracle_native.so"))
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "not gpu", "-k", "golden_vectors",
+                        os.path.join(HERE, "test_oracle_detector.py"), os.path.join(HERE, "test_sqpnp_oracle.py"), os.path.join(HERE, "test_oracle_cat.py")],
+                       capture_output=True, text=True, env=env, timeout=900, cwd=root)
+    assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]

@@ -1,5 +1,7 @@
 #!/bin/bash
 # per-class k_fit durations with every cluster stopped after phase $1 (rocprofv3 kernel trace)
+# (the knobs this script sets exist only in the diagnostics build of the library: ck_internal.h, CK_KNOB)
+export CHALKYDRI_HIP_LIB=${CHALKYDRI_HIP_LIB:-$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)/chalkydri_amd/lib/diag/libchalkydri_hip.so}
 cd /tmp && export TMPDIR=/tmp
 export CK_FIT_STOP_AFTER=$1
 out=$GRAFT_REPO_ROOT/gpurun_out/fitcls_$1

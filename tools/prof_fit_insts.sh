@@ -1,6 +1,8 @@
 #!/bin/bash
 # VALU / SALU / LDS instruction counts and busy cycles of the fit kernels with every cluster stopped after phase $1 (rocprofv3 --pmc);
 # prints one line per k_fit instantiation (averages per launch)
+# (the knobs this script sets exist only in the diagnostics build of the library: ck_internal.h, CK_KNOB)
+export CHALKYDRI_HIP_LIB=${CHALKYDRI_HIP_LIB:-$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)/chalkydri_amd/lib/diag/libchalkydri_hip.so}
 cd /tmp && export TMPDIR=/tmp
 export CK_FIT_STOP_AFTER=$1
 export CK_STREAMS=1

@@ -9,7 +9,7 @@ for f in sorted(os.listdir(src)):
     if f.endswith(".hip"):
         o = os.path.join(out, f + ".o")
         subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=off",
-                               "-DCK_TILE_PROFILE", "-I" + os.path.join(ROOT, "include"), "-I" + src, "-c", os.path.join(src, f), "-o", o])
+                               "-DCK_TILE_PROFILE", "-DCK_DIAG", "-I" + os.path.join(ROOT, "include"), "-I" + src, "-c", os.path.join(src, f), "-o", o])
         objs.append(o)
     elif f.endswith(".c"):
         o = os.path.join(out, f + ".o")

@@ -1,4 +1,6 @@
 #!/bin/bash
+# (the knobs this script sets exist only in the diagnostics build of the library: ck_internal.h, CK_KNOB)
+export CHALKYDRI_HIP_LIB=${CHALKYDRI_HIP_LIB:-$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)/chalkydri_amd/lib/diag/libchalkydri_hip.so}
 python -m pytest tests/test_gpu_segment.py -x -q 2>&1 | tail -2
 for rep in 1 2; do
 for ch in 1 2 4 8; do

@@ -1,5 +1,7 @@
 #!/bin/bash
 # SQ counters of the split quad fit's kernels on the bench batch (two rocprofv3 --pmc passes over tools/bench_detect.py); per-launch averages
+# (the knobs this script sets exist only in the diagnostics build of the library: ck_internal.h, CK_KNOB)
+export CHALKYDRI_HIP_LIB=${CHALKYDRI_HIP_LIB:-$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)/chalkydri_amd/lib/diag/libchalkydri_hip.so}
 cd /tmp && export TMPDIR=/tmp
 root=$GRAFT_REPO_ROOT
 export CK_FIT_FLAT=1

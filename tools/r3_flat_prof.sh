@@ -1,5 +1,7 @@
 #!/bin/bash
 # per-kernel durations of the detector on the bench batch with the split quad fit (CK_FIT_FLAT from the caller, default 1)
+# (the knobs this script sets exist only in the diagnostics build of the library: ck_internal.h, CK_KNOB)
+export CHALKYDRI_HIP_LIB=${CHALKYDRI_HIP_LIB:-$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)/chalkydri_amd/lib/diag/libchalkydri_hip.so}
 cd /tmp && export TMPDIR=/tmp
 out=$GRAFT_REPO_ROOT/gpurun_out/flatprof_${1:-x}
 rm -rf $out

@@ -1,5 +1,7 @@
 #!/bin/bash
 # k_fmerge by phase at 2448 x 2048 (CK_FMERGE_STOP_AFTER: 0 scan + pack, 1 + edge sweep and unions, 2 + flatten, 3 + sizes, 99 all)
+# (the knobs this script sets exist only in the diagnostics build of the library: ck_internal.h, CK_KNOB)
+export CHALKYDRI_HIP_LIB=${CHALKYDRI_HIP_LIB:-$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)/chalkydri_amd/lib/diag/libchalkydri_hip.so}
 cd /tmp && export TMPDIR=/tmp
 for s in ${STOPS:-0 1 2 3 99}; do
   out=$GRAFT_REPO_ROOT/gpurun_out/fmstop_$s

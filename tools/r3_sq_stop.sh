@@ -1,5 +1,7 @@
 #!/bin/bash
 # k_sqpnp by phase (CK_SQ_STOP_AFTER: 1 after Omega, 2 after the eigen-decomposition, 3 after the refinements, 99 all): kernel durations
+# (the knobs this script sets exist only in the diagnostics build of the library: ck_internal.h, CK_KNOB)
+export CHALKYDRI_HIP_LIB=${CHALKYDRI_HIP_LIB:-$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)/chalkydri_amd/lib/diag/libchalkydri_hip.so}
 cd /tmp && export TMPDIR=/tmp
 for s in 1 2 3 99; do
   out=$GRAFT_REPO_ROOT/gpurun_out/sqstop_$s

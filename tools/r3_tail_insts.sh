@@ -1,5 +1,7 @@
 #!/bin/bash
 # vector / scalar / LDS instruction counts of k_tail per launch with the kernel cut short after phase k (rocprofv3 --pmc, one pass per k)
+# (the knobs this script sets exist only in the diagnostics build of the library: ck_internal.h, CK_KNOB)
+export CHALKYDRI_HIP_LIB=${CHALKYDRI_HIP_LIB:-$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)/chalkydri_amd/lib/diag/libchalkydri_hip.so}
 cd /tmp && export TMPDIR=/tmp
 export CK_FIT_FLAT=1
 for s in ${STOPS:-4 5 6 7 99}; do

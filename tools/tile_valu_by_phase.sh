@@ -1,6 +1,8 @@
 #!/bin/bash
 # VALU / SALU / LDS instruction counts of k_tile cut short after each phase (CK_TILE_STOP_AFTER): differences = per-phase counts.
 # usage (through gpurun): [PMC="SQ_..."] tools/tile_valu_by_phase.sh [kind]
+# (the knobs this script sets exist only in the diagnostics build of the library: ck_internal.h, CK_KNOB)
+export CHALKYDRI_HIP_LIB=${CHALKYDRI_HIP_LIB:-$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)/chalkydri_amd/lib/diag/libchalkydri_hip.so}
 cd /tmp && export TMPDIR=/tmp
 root=$GRAFT_REPO_ROOT
 kind=${1:-synth}
