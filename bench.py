@@ -235,7 +235,7 @@ def main():
     # The one collective of the path: the C ABI's ck_gather_poses (ncclAllGather of n x 64 bytes on the handle's stream).  If
     # its communicator cannot be made on some rank, EVERY rank uses the Python mirror's torch.distributed all_gather instead
     # (same bytes, same layout) and the JSON line says which one ran.
-    comm, gather_kind = None, "none (1 GPU)"
+    comm, gather_kind, gather_lib = None, "none (1 GPU)", None
     force_comm = os.environ.get("CK_BENCH_FORCE_COMM") == "1"   # (tests: the C ABI's collective inside this loop on ONE rank)
     if world > 1 or force_comm:
         try:
@@ -252,6 +252,11 @@ def main():
         gather_kind = "ck_gather_poses: RCCL ncclAllGather of 64-byte records (C ABI)" if comm is not None else \
             "torch.distributed all_gather_into_tensor of 64-byte records (RCCL; C-ABI communicator unavailable)"
         d_all = torch.zeros((world * n, 64), dtype=torch.uint8, device=dev)
+        # Two users of RCCL live in this process at N > 1: torch's process group and the C ABI's communicator (dlopen by soname).
+        # Which file each resolved to is printed per rank and carried in the JSON line (they should be one mapped library).
+        mapped = sorted({ln.split()[-1] for ln in open("/proc/self/maps") if "librccl" in ln})
+        gather_lib = {"ck_comm": comm.library() if comm is not None else None, "mapped_librccl": mapped}
+        print(f"[rank {rank}] librccl: ck_comm -> {gather_lib['ck_comm']}; mapped in this process: {mapped}", file=sys.stderr)
 
     def step(record=False):
         nonlocal gathered
@@ -338,7 +343,7 @@ def main():
             "dtype": "u8 (threshold/segment/clusters: integer; quad fit/decode/SQPnP: f64)", "data": "synthetic",
             "config": {"workload": f"{w}x{h} mono8 batch={n}/GPU, tag36h11, {args.tags} field tags/frame (3-D scenes), background ramp+-24 "
                                    f"noise+-{args.noise}, quad_decimate={args.decimate}, detect+pose, one stream per GPU",
-                       "frames_with_pose": round(valid_frac, 4), "post_segment_streams": int(os.environ.get("CK_STREAMS", "1")), "gather": gather_kind, "gather_us": gather_us},
+                       "frames_with_pose": round(valid_frac, 4), "post_segment_streams": int(os.environ.get("CK_STREAMS", "1")), "gather": gather_kind, "gather_us": gather_us, "gather_lib": gather_lib},
             "roofline": {"bound": "hbm", "kernel": "threshold+segment (k_tile + k_fmerge)", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
                          # what `achieved` is: SURVEY §8d's ALGORITHMIC bytes (7 per pixel: 1 R + 1 W threshold, 1 R + 4 W segment) over the

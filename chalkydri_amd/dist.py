@@ -127,6 +127,13 @@ class PoseComm:
         from ._lib import check
         check(self._L.ck_comm_sync(self._c), "ck_comm_sync")
 
+    def library(self):
+        """Path of the librccl this communicator's calls resolved to (ck_comm_library: dladdr of ncclAllGather)."""
+        import ctypes as C
+        self._L.ck_comm_library.restype = C.c_char_p
+        self._L.ck_comm_library.argtypes = [C.c_void_p]
+        return (self._L.ck_comm_library(self._c) or b"").decode()
+
     def close(self):
         if getattr(self, "_c", None):
             self._L.ck_comm_destroy(self._c)

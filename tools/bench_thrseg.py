@@ -16,6 +16,9 @@ if kind == "synth":
     base = np.stack([synth.render(synth.frame_seed(2, i), w, h, 6)[0] for i in range(uniq)])
 elif kind == "clean":
     base = np.stack([synth.render(synth.frame_seed(2, i), w, h, 6, noise_amp=1)[0] for i in range(uniq)])
+elif kind in ("bench", "bench_quiet"):   # the frames bench.py itself times: the headline batch / `also.threshold_segment_low_noise`
+    from chalkydri_amd import scenes
+    base = scenes.bench_stream(2, uniq, w, h, 6, stream=0, unique=uniq, noise_amp=3 if kind == "bench" else 1)[0]
 else:
     base = np.random.default_rng(0).integers(0, 256, (uniq, h, w), dtype=np.uint8)
 frames = np.concatenate([base] * ((n + uniq - 1) // uniq))[:n]
