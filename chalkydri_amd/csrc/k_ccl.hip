@@ -264,7 +264,11 @@ __global__ __launch_bounds__(KNT) __attribute__((amdgpu_num_sgpr(80))) void k_ti
                                              ck_border_root *__restrict__ broots, uint32_t *__restrict__ tile_count,
                                              uint16_t *__restrict__ ring, size_t ring_len, int stop_after, int sweeps) {
     __shared__ __attribute__((aligned(16))) uint8_t lds[LDS_BYTES];
-    const int tid = threadIdx.x;
+    // The waves' ROLES rotate with the workgroup: wave k of every workgroup sits on SIMD k, and the roles are not equally heavy (the
+    // second min/max round, the pooled unions, the second round of ring pixels fall to the first waves) — with fixed roles SIMD 0
+    // of every CU carried the most vector work, and the kernel is bound by vector issue (tools/probes/valu_rate_probe.hip).  Every
+    // index below derives from `tid`; lane numbers (tid & 63) are the hardware's.  Round 4, same box: 0.9608 -> 0.9495 ms.
+    const int tid = (int)((threadIdx.x + 64u * ((blockIdx.x >> 3) & 3u)) & 255u);
     const int tiles = tiles_x * tiles_y;
     int frame, tile;
     if (xcd_map) { // workgroups b and b + 8 share an XCD (their L2): deal whole frames to XCDs, so that the halo rows a tile shares
@@ -477,6 +481,9 @@ __global__ __launch_bounds__(KNT) __attribute__((amdgpu_num_sgpr(80))) void k_ti
         // same masks (what was two idle waves' time) and share the per-node loop — the even-numbered nodes of every word to the
         // first, the odd-numbered to the second — and the leftover links (vertical ones and the word-boundary flags to the first,
         // the diagonal ones to the second): the loop runs to HALF the busiest word's node count.
+        // (Round 4, with the roles rotating: one wave per colour walking ALL of a word's nodes and links while the other two skip the
+        // phase — 550 fewer wave-instructions per workgroup — measured 3.6 % SLOWER, 0.990 against 0.955 ms: the longer chain of the
+        // two working waves costs more than the duplicated mask work.)
         const int c = __builtin_amdgcn_readfirstlane((tid >> 6) & 1), half = __builtin_amdgcn_readfirstlane(tid >> 7);
         const bool white = c == 0, has_l = wd > 0, has_u = p > 0, has_r = wd < NWD - 1;
         const int mi = ((2 * p) * NWD + wd) * 2 + c;
