@@ -78,6 +78,14 @@ constexpr int OFF_S2 = OFF_MASK + TH * NWD * 2 * 4;        // u32[TH/2][NWD][2] 
 constexpr int OFF_MISC = OFF_S2 + (TH / 2) * NWD * 2 * 4;  // u32[16]
 constexpr int LDS_BYTES = OFF_MISC + 64;
 constexpr int RING_CAP = CK_RING_CAP;                      // ring-touching roots of a tile: at most one per ring pixel
+// the label table of P6c / P7 (32-bit words over the dead parent + list arrays and the first bytes of the dead pool): entries
+// [0, 4096) by (pair word * 2 + colour) * 32 + node number, then the pixels of the frame's two non-origin columns (side * 32 + row),
+// then one entry that reads "no component"
+// (a (pair word, colour) owns TAB_STRIDE = 33 entries, not 32: with 32 the small node numbers of all pair words fell on the same
+// dozen LDS banks — nine lanes per bank in a label-pass read against three with 33 (five for the table indexed by lookup pixel);
+// same box: 0.9525 ms with the lookup-pixel table, 0.9631 with stride 32, 0.9141 with stride 33)
+constexpr int TAB_STRIDE = 33, TAB_EDGE = (TH / 2) * NWD * 2 * TAB_STRIDE, TAB_NONE = TAB_EDGE + 64;
+static_assert((TAB_NONE + 1) * 4 <= OFF_POOL + POOL_CAP * 4 && TAB_NONE < (1 << 13), "label table: parent + list arrays + the pool's first bytes; 13-bit indices");
 constexpr uint32_t CK_ROOT = 0x8000u, CK_RING = 0x4000u, CK_CLAIM = 0x2000u, CK_COUNT = 0x1FFFu;
 static_assert(OFF_MINMAX + T4Y * T4X * 4 <= OFF_LIST, "min/max scratch must fit in the parent array");
 static_assert(LDS_BYTES <= 20480, "keep eight workgroups per CU");
@@ -452,7 +460,7 @@ __global__ __launch_bounds__(KNT) __attribute__((amdgpu_num_sgpr(80))) void k_ti
     uint32_t nruns = 0; // nodes in the tile's list
     constexpr int NPL = LIST_CAP / KNT;          // nodes per lane a tile may have for its label words to go through the table
     constexpr uint32_t KEEP_NONE = 0xFFFFFFFFu;
-    uint32_t keep[NPL], ekeep = KEEP_NONE;       // per node this lane flattened: lookup pixel | root pixel << 16 (ekeep: its pixel of a non-origin column)
+    uint32_t keep[NPL], ekeep = KEEP_NONE;       // per node this lane flattened: label-table index | root pixel << 16 (ekeep: its pixel of a non-origin column)
 #pragma unroll
     for (int k = 0; k < NPL; k++) keep[k] = KEEP_NONE;
     bool tabled = false;
@@ -523,11 +531,14 @@ __global__ __launch_bounds__(KNT) __attribute__((amdgpu_num_sgpr(80))) void k_ti
         const uint32_t incl = wave_scan_u32(cnt);
         if ((tid & 63) == 63) misc[c] = incl;
         uint32_t li = c ? (uint32_t)(LIST_CAP - 1) - (incl - cnt) : incl - cnt; // white from the front, black from the back
-        const uint32_t lstep = c ? 0xFFFFFFFFu : 1u, lcol = ((uint32_t)c << 12) | base;
+        // (list entry: lookup pixel | label-table index << 12 | pixel count << 25; the table index of a node is
+        // ((pair word * 2 + colour) * TAB_STRIDE + its number among the word's nodes of that colour): what a pixel of P7 forms with one popcount)
+        const uint32_t lstep = c ? 0xFFFFFFFFu : 1u;
+        uint32_t lcol = base | ((uint32_t)((((p * NWD + wd) * 2 + c) * TAB_STRIDE) + half) << 12);
         const uint32_t nMt = ~Mt, nUt = ~Ut;
         uint32_t St = S2;
         if (half) { St &= St - 1u; li += lstep; } // the second wave of the colour starts at the word's second node
-        for (; St; St &= St - 1u, li += 2u * lstep) { // (the step skips the other wave's node)
+        for (; St; St &= St - 1u, li += 2u * lstep, lcol += 2u << 12) { // (the step skips the other wave's node)
             const uint32_t low = St & (0u - St);
             const uint32_t s = ffbl_raw(low);
             St ^= low;
@@ -542,7 +553,7 @@ __global__ __launch_bounds__(KNT) __attribute__((amdgpu_num_sgpr(80))) void k_ti
             parent[base + mn] = (uint16_t)(e ? t_up : CK_ROOT);  // no link to an earlier node: a root (count 0 for now)
             // the list entry: lookup pixel | colour << 12 | pixel count << 16.  (A tile with more nodes than the list holds — one-pixel
             // patterns — does without it: the index then runs past either end and nothing is stored.)
-            if (li < (uint32_t)LIST_CAP) list[li] = lk | lcol | (((uint32_t)__popc(Mt & span) + (uint32_t)__popc(Mb & span)) << 16);
+            if (li < (uint32_t)LIST_CAP) list[li] = lk | lcol | (((uint32_t)__popc(Mt & span) + (uint32_t)__popc(Mb & span)) << 25);
         }
         // (c) what is left: the vertical links one loop, the two diagonal kinds one loop each, then the three links that cross a
         // word boundary (a generic "take the next link" loop cost twice the instructions per link)
@@ -637,7 +648,7 @@ __global__ __launch_bounds__(KNT) __attribute__((amdgpu_num_sgpr(80))) void k_ti
     // lane: one-pixel patterns; dense binary noise has four per lane) walks its nodes per pair word instead, and its label pass
     // looks every pixel's root up itself.
     auto flatten2 = [&](uint32_t j0, uint32_t &keep0, uint32_t &keep1) {
-        uint32_t node[2], root[2], add[2];
+        uint32_t node[2], root[2], add[2], tix[2];
         bool live[2];
 #pragma unroll
         for (int q = 0; q < 2; q++) {
@@ -645,7 +656,7 @@ __global__ __launch_bounds__(KNT) __attribute__((amdgpu_num_sgpr(80))) void k_ti
             live[q] = j < nruns;
             const uint32_t e = list_at(live[q] ? j : 0u);
             node[q] = e & 0xFFFu; root[q] = node[q];
-            add[q] = e >> 16;
+            add[q] = e >> 25; tix[q] = (e >> 12) & 0x1FFFu;
         }
         for (int it = 0; it < TH * TW; it++) { // plain loads behind a compiler barrier: the two reads of a step go out together
             __asm__ volatile("" ::: "memory");
@@ -662,8 +673,8 @@ __global__ __launch_bounds__(KNT) __attribute__((amdgpu_num_sgpr(80))) void k_ti
                 // other half of the word)
                 atomicAdd(&parent32[root[q] >> 1], add[q] << ((root[q] & 1u) * 16u));
             }
-        keep0 = live[0] ? (node[0] | (root[0] << 16)) : KEEP_NONE;
-        keep1 = live[1] ? (node[1] | (root[1] << 16)) : KEEP_NONE;
+        keep0 = live[0] ? (tix[0] | (root[0] << 16)) : KEEP_NONE;
+        keep1 = live[1] ? (tix[1] | (root[1] << 16)) : KEEP_NONE;
     };
     if (tabled) {
 #pragma unroll
@@ -692,7 +703,7 @@ __global__ __launch_bounds__(KNT) __attribute__((amdgpu_num_sgpr(80))) void k_ti
             for (;;) { __asm__ volatile("" ::: "memory"); const uint32_t n0 = parent[root]; if (n0 & CK_ROOT) break; root = n0; }
             if (root != me) parent[me] = (uint16_t)root;
             atomicAdd(&parent32[root >> 1], 1u << ((root & 1u) * 16u));
-            ekeep = me | (root << 16);
+            ekeep = (uint32_t)(TAB_EDGE + (tid & 63)) | (root << 16); // (its own table entry: side * 32 + row)
         }
     }
     lds_barrier();
@@ -766,7 +777,8 @@ __global__ __launch_bounds__(KNT) __attribute__((amdgpu_num_sgpr(80))) void k_ti
     if (!tile_has_runs || tabled) {
     // ---- P6c: the label word of every node (16 bits: ck_internal.h), formed once per node from its root's entry (interior component:
     // the root's tile pixel, final; ring-touching: the component's tile-local id) and, behind a barrier — every read of the union-find is done —
-    // written to a table of 32-bit words over the parent and list arrays, indexed by the node's lookup pixel.
+    // written to a table of 32-bit words over the parent and list arrays, indexed by pair word, colour and the node's number among
+    // the word's nodes of that colour (TAB_EDGE / TAB_NONE above).
     uint32_t *tab32 = reinterpret_cast<uint32_t *>(lds);
     if (tile_has_runs) {
         auto label_word = [&](uint32_t kp) -> uint32_t {
@@ -785,8 +797,9 @@ __global__ __launch_bounds__(KNT) __attribute__((amdgpu_num_sgpr(80))) void k_ti
         lds_barrier();
 #pragma unroll
         for (int k = 0; k < NPL; k++)
-            if ((uint32_t)(k * KNT) < nruns && keep[k] != KEEP_NONE) tab32[keep[k] & 0xFFFu] = lw[k];
-        if (ekeep != KEEP_NONE) tab32[ekeep & 0xFFFu] = elw;
+            if ((uint32_t)(k * KNT) < nruns && keep[k] != KEEP_NONE) tab32[keep[k] & 0x1FFFu] = lw[k];
+        if (ekeep != KEEP_NONE) tab32[ekeep & 0x1FFFu] = elw;
+        if (tid == 0) tab32[TAB_NONE] = 0xFFFFu;
         lds_barrier();
     }
     // ---- P7: write label words.  Lane L owns the 8-column group L & 15 of pair L >> 4, both rows: the search for a column's node
@@ -798,7 +811,6 @@ __global__ __launch_bounds__(KNT) __attribute__((amdgpu_num_sgpr(80))) void k_ti
         const uint32_t Oo = ck_origin32(tx0 + 32 * wd, w);
         const uint32_t edge8 = (~Oo >> sh) & 255u;    // columns of the group that are non-origin columns of the frame: their pixels are nodes of their own
         if (gx < w && gy < h) {
-            const uint32_t pbase = (uint32_t)((2 * pr) * TW + 32 * wd), cbase = pbase + (uint32_t)sh;
             uint32_t outw[2][4]; // two 16-bit words each
 #pragma unroll
             for (int k = 0; k < 4; k++) outw[0][k] = outw[1][k] = 0xFFFFFFFFu;
@@ -808,33 +820,39 @@ __global__ __launch_bounds__(KNT) __attribute__((amdgpu_num_sgpr(80))) void k_ti
                 const uint32_t any_t = ((m4.x | m4.y) >> sh) & 255u, any_b = ((b4.x | b4.y) >> sh) & 255u;
                 if (any_t | any_b) {
                     const uint2 s2 = *reinterpret_cast<const uint2 *>(&s2w[(pr * NWD + wd) * 2]);
-                    // node starts whose lookup pixel is in the bottom row: the first column has no top pixel
-                    const uint32_t lowW = s2.x & ~(m4.x & Oo), lowB = s2.y & ~(m4.y & Oo);
+                    // A pixel's table entry is its node's: (pair word * 2 + colour) * TAB_STRIDE + the node's number among the word's nodes of
+                    // that colour = the node starts at or below the pixel's column, less one: ONE popcount per column and colour, on the
+                    // start mask shifted to the group (the masks of the eight columns are constants; v_bcnt adds the base itself).
+                    // (Round 4: the table had been indexed by the node's lookup pixel — per column and colour a count-leading-zeros
+                    // for the start, the row of the lookup pixel from a second mask, three shifts and two three-operand ors.)
+                    const uint32_t lowm = (1u << sh) - 1u;
+                    const uint32_t tb = (uint32_t)(((pr * NWD + wd) * 2) * TAB_STRIDE);
+                    const uint32_t bw = tb + (uint32_t)__popc(s2.x & lowm) - 1u, bb = tb + (uint32_t)TAB_STRIDE + (uint32_t)__popc(s2.y & lowm) - 1u;
+                    const uint32_t sw8 = s2.x >> sh, sb8 = s2.y >> sh;
+                    const uint32_t wt8 = m4.x >> sh, bt8 = m4.y >> sh, wb8 = b4.x >> sh, bb8 = b4.y >> sh;
                     uint32_t at[2][8];
 #pragma unroll
                     for (int k = 0; k < 8; k++) {
-                        const uint32_t upto = (2u << (sh + k)) - 1u;
-                        const uint32_t cw = 31u - (uint32_t)__builtin_clz((s2.x & upto) | 1u), cb = 31u - (uint32_t)__builtin_clz((s2.y & upto) | 1u);
-                        const uint32_t atw = pbase + cw + (((lowW >> cw) & 1u) << 7), atb = pbase + cb + (((lowB >> cb) & 1u) << 7);
-                        // (a pixel without a colour looks up a harmless in-range word that is not used)
-                        const uint32_t wt = 0u - ((m4.x >> (sh + k)) & 1u), wbm = 0u - ((b4.x >> (sh + k)) & 1u);
-                        at[0][k] = (atw & wt) | (atb & ~wt);
-                        at[1][k] = (atw & wbm) | (atb & ~wbm);
+                        const uint32_t upto = (2u << k) - 1u;
+                        const uint32_t iw = bw + (uint32_t)__popc(sw8 & upto), ib = bb + (uint32_t)__popc(sb8 & upto);
+                        // (a pixel without a colour reads the entry that says so)
+                        at[0][k] = (wt8 & (1u << k)) ? iw : ((bt8 & (1u << k)) ? ib : (uint32_t)TAB_NONE);
+                        at[1][k] = (wb8 & (1u << k)) ? iw : ((bb8 & (1u << k)) ? ib : (uint32_t)TAB_NONE);
                     }
-                    if (edge8) // (only the lanes at the frame's first and last column)
+                    if (edge8) { // (only the lanes at the frame's first and last column: those pixels are nodes of their own)
 #pragma unroll
                         for (int k = 0; k < 8; k++)
-                            if ((edge8 >> k) & 1u) { at[0][k] = cbase + (uint32_t)k; at[1][k] = cbase + (uint32_t)(TW + k); }
+                            if ((edge8 >> k) & 1u) { // (the frame's column 0 is side 0 of the edge entries, its last column side 1)
+                                const uint32_t eb = (uint32_t)TAB_EDGE + (gx + k == 0 ? 0u : 32u) + (uint32_t)(2 * pr);
+                                at[0][k] = ((any_t >> k) & 1u) ? eb : (uint32_t)TAB_NONE;
+                                at[1][k] = ((any_b >> k) & 1u) ? eb + 1u : (uint32_t)TAB_NONE;
+                            }
+                    }
                     uint32_t lwv[2][8];
 #pragma unroll
                     for (int r = 0; r < 2; r++)
 #pragma unroll
                         for (int k = 0; k < 8; k++) lwv[r][k] = tab32[at[r][k]];
-#pragma unroll
-                    for (int k = 0; k < 8; k++) { // (no colour: all ones)
-                        lwv[0][k] = (lwv[0][k] | (0u - (((any_t >> k) & 1u) ^ 1u))) & 0xFFFFu;
-                        lwv[1][k] = (lwv[1][k] | (0u - (((any_b >> k) & 1u) ^ 1u))) & 0xFFFFu;
-                    }
 #pragma unroll
                     for (int r = 0; r < 2; r++)
 #pragma unroll
