@@ -275,6 +275,25 @@ struct ComboTable {
 };
 __device__ const ComboTable g_combo_table{}; // built at compile time: nothing to upload, valid on every device of the process
 
+// Reciprocals of the window weights of k_chunk: a window holds at most 2 * 20 + 1 points of weight <= 362, so its weight sum is an
+// integer below INV_N and 1.0 / W a table entry — the IEEE quotient, formed by the compiler: the same bits as the device's division
+// (a dozen instructions around v_rcp_f64, 70 clocks of a SIMD per position by tools/probes/valu_rate_probe.hip) for one 8-byte load
+// from a 116 KB table that lives in L2.  A position nobody wrote can hold any weight: beyond the table it divides.
+constexpr int INV_N = 41 * 362 + 1;
+struct InvTable {
+    double v[INV_N];
+    constexpr InvTable() : v() {
+        v[0] = __builtin_huge_val(); // 1.0 / 0.0
+        for (int n = 1; n < INV_N; n++) v[n] = 1.0 / (double)n;
+    }
+};
+__device__ const InvTable g_inv_table{};
+// an integer below 2^52 as a double: its bits under the exponent of 2^52, less 2^52 (exact; the generic 64-bit conversion is two
+// conversions and a scaling).  The moment sums of a window or a cluster side are such integers (<= 49 140 points x 362 x 8192^2 < 2^51).
+__device__ __forceinline__ double f64_of_u52(unsigned long long x) {
+    return __longlong_as_double((long long)(0x4330000000000000ull | x)) - 4503599627370496.0;
+}
+
 __device__ __forceinline__ int wrap_index(int i, int sz) { // i in [-HALO, sz + CH + HALO): bring into [0, sz)
     if (i < 0) i += sz;   // one step each way is enough: i >= -HALO >= -sz, and a span ends before sz + HALO <= 2 * sz
     if (i >= sz) i -= sz;
@@ -1577,11 +1596,11 @@ __device__ __forceinline__ void k_chunk_body(const ck_stage_ws &ws, int qw, int 
                 const uint32_t mx = sP32[0][hi] - sP32[0][lo], my = sP32[1][hi] - sP32[1][lo], mw = sP32[2][hi] - sP32[2][lo];
                 M6 m;
                 m.Mxx = (long long)(sP64[0][hi] - sP64[0][lo]); m.Mxy = (long long)(sP64[1][hi] - sP64[1][lo]); m.Myy = (long long)(sP64[2][hi] - sP64[2][lo]);
-                const double inv = 1.0 / (double)mw;
+                const double inv = mw < (uint32_t)INV_N ? g_inv_table.v[mw] : 1.0 / (double)mw;
                 const double Ex = (0.5 * (double)mx) * inv, Ey = (0.5 * (double)my) * inv;
-                const double Cxx = (0.25 * (double)m.Mxx) * inv - Ex * Ex;
-                const double Cxy = (0.25 * (double)m.Mxy) * inv - Ex * Ey;
-                const double Cyy = (0.25 * (double)m.Myy) * inv - Ey * Ey;
+                const double Cxx = (0.25 * f64_of_u52((unsigned long long)m.Mxx)) * inv - Ex * Ex;
+                const double Cxy = (0.25 * f64_of_u52((unsigned long long)m.Mxy)) * inv - Ex * Ey;
+                const double Cyy = (0.25 * f64_of_u52((unsigned long long)m.Myy)) * inv - Ey * Ey;
                 const double d = Cxx - Cyy, q4 = 4.0 * Cxy;
                 const double disc = sqrt(d * d + q4 * Cxy);
                 ev[r] = (double)(2 * ksz + 1) * (0.5 * ((Cxx + Cyy) - disc));
