@@ -78,14 +78,21 @@ __device__ __forceinline__ uint32_t isqrt_u32(uint32_t v) {
     return r;
 }
 
+// an integer below 2^52 as a double: its bits under the exponent of 2^52, less 2^52 (exact; the generic 64-bit conversion is two
+// conversions and a scaling).  The moment sums of a window or a cluster side are such integers (<= 49 140 points x 362 x 8192^2 < 2^51).
+__device__ __forceinline__ double f64_of_u52(unsigned long long x) {
+    return __longlong_as_double((long long)(0x4330000000000000ull | x)) - 4503599627370496.0;
+}
+
 // line fit from a moment sum over N points (half-pixel units) — mirrors fit_line() of the oracle exactly
 __device__ __forceinline__ void fit_line_m(const M6 &m, int N, double *lineparm, double *err, double *mse) {
-    double inv = 1.0 / (double)m.W; // one reciprocal, five products — same operations as the oracle
-    double Ex = (0.5 * (double)m.Mx) * inv;
-    double Ey = (0.5 * (double)m.My) * inv;
-    double Cxx = (0.25 * (double)m.Mxx) * inv - Ex * Ex;
-    double Cxy = (0.25 * (double)m.Mxy) * inv - Ex * Ey;
-    double Cyy = (0.25 * (double)m.Myy) * inv - Ey * Ey;
+    // (the sums of a cluster side are non-negative integers below 2^52: f64_of_u52 gives the same doubles as the casts)
+    double inv = 1.0 / f64_of_u52((unsigned long long)m.W); // one reciprocal, five products — same operations as the oracle
+    double Ex = (0.5 * f64_of_u52((unsigned long long)m.Mx)) * inv;
+    double Ey = (0.5 * f64_of_u52((unsigned long long)m.My)) * inv;
+    double Cxx = (0.25 * f64_of_u52((unsigned long long)m.Mxx)) * inv - Ex * Ex;
+    double Cxy = (0.25 * f64_of_u52((unsigned long long)m.Mxy)) * inv - Ex * Ey;
+    double Cyy = (0.25 * f64_of_u52((unsigned long long)m.Myy)) * inv - Ey * Ey;
     double d = Cxx - Cyy;
     double q = 4.0 * Cxy;
     double disc = sqrt(d * d + q * Cxy);
@@ -288,11 +295,6 @@ struct InvTable {
     }
 };
 __device__ const InvTable g_inv_table{};
-// an integer below 2^52 as a double: its bits under the exponent of 2^52, less 2^52 (exact; the generic 64-bit conversion is two
-// conversions and a scaling).  The moment sums of a window or a cluster side are such integers (<= 49 140 points x 362 x 8192^2 < 2^51).
-__device__ __forceinline__ double f64_of_u52(unsigned long long x) {
-    return __longlong_as_double((long long)(0x4330000000000000ull | x)) - 4503599627370496.0;
-}
 
 __device__ __forceinline__ int wrap_index(int i, int sz) { // i in [-HALO, sz + CH + HALO): bring into [0, sz)
     if (i < 0) i += sz;   // one step each way is enough: i >= -HALO >= -sz, and a span ends before sz + HALO <= 2 * sz
