@@ -27,6 +27,7 @@
 // No full-frame relabel pass exists: interior components are final when k_tile writes them; the label words of ring-touching
 // ones carry a slot, which consumers resolve with two independent table reads (label word format in ck_internal.h).
 #include <stdlib.h>
+#include <type_traits>
 
 #include "ck_internal.h"
 #include "ck_links.h"
@@ -307,10 +308,15 @@ __global__ __launch_bounds__(KNT) __attribute__((amdgpu_num_sgpr(80))) void k_ti
     const int yoff = ty0 - sy0;                                          // staged row of tile row 0: 4 (8 in the ragged last tile row)
     const int xb = 4 * (c4x - 1) - sx0;                                  // staged byte of min/max column 0: 12 (8 when ragged)
 
+    // Two workgroup-uniform shortcuts (scalar branches): a tile that lies wholly inside the frame (`full`: its pixels need no bounds
+    // tests — every tile of a 1280 x 800 frame) and one whose staged window does, too (`inner`: 74 % of them).  The tests are
+    // compares and exec-mask bookkeeping on the kernel's critical resource, vector and scalar issue.
+    const bool full = (w & 15) == 0 && (h & 3) == 0 && tx0 + TW <= w && ty0 + TH <= h;
+    const bool inner = full && tx0 >= 16 && tx0 + TW + 16 <= w && ty0 >= 4 && ty0 + TH + 4 <= h;
     TPROF_DECL;
     // ---- P0: stage the tile and its halo: IMG_ROWS rows of ten 16-byte chunks (16 left | 128 | 16 right) ------------
-    {   // a lane's chunks are asked for together, then stored: as a loop (load, wait, store, load, wait, store) the second chunk's
-        // trip to HBM started only when the first had come back
+    auto p0 = [&](auto INNERC) { // a lane's chunks are asked for together, then stored: as a loop (load, wait, store, load, wait, store)
+        constexpr bool INNER = decltype(INNERC)::value; // the second chunk's trip to HBM started only when the first had come back
         constexpr int P0N = (IMG_ROWS * 10 + KNT - 1) / KNT;
         uint4 v[P0N];
 #pragma unroll
@@ -320,7 +326,7 @@ __global__ __launch_bounds__(KNT) __attribute__((amdgpu_num_sgpr(80))) void k_ti
             const int gy = sy0 + r, gx = sx0 + 16 * c;
             v[q] = make_uint4(0, 0, 0, 0);
             // rows are padded to 16 bytes (frame strides are multiples of 16): a chunk that starts inside the row is readable
-            if (item < IMG_ROWS * 10 && gy >= 0 && gy < h && gx >= 0 && gx < w) v[q] = *reinterpret_cast<const uint4 *>(img + (size_t)gy * stride + gx);
+            if (item < IMG_ROWS * 10 && (INNER || (gy >= 0 && gy < h && gx >= 0 && gx < w))) v[q] = *reinterpret_cast<const uint4 *>(img + (size_t)gy * stride + gx);
         }
 #pragma unroll
         for (int q = 0; q < P0N; q++) {
@@ -328,19 +334,21 @@ __global__ __launch_bounds__(KNT) __attribute__((amdgpu_num_sgpr(80))) void k_ti
             const int r = item / 10, c = item - r * 10;
             if (item < IMG_ROWS * 10) *reinterpret_cast<uint4 *>(lds + OFF_IMG + r * IMG_PITCH + 16 * c) = v[q];
         }
-    }
+    };
+    if (inner) p0(std::true_type{}); else p0(std::false_type{});
     lds_barrier();
     TPROF(0);
 
     if (stop_after == 0) return; // diagnostics (CK_TILE_STOP_AFTER)
     // ---- P1: min/max of the 4x4 tiles: grid column j = 4x4 column c4x - 1 + j, row i = 4x4 row c4y - 1 + i ----------
     uint32_t *minmax = reinterpret_cast<uint32_t *>(lds + OFF_MINMAX);
-    if (!PRE)
+    auto p1 = [&](auto INNERC) {
+    constexpr bool INNER = decltype(INNERC)::value;
     for (int item = tid; item < T4Y * T4X; item += KNT) {
         const int i = item / T4X, j = item - i * T4X;
         const int g4x = c4x - 1 + j, g4y = c4y - 1 + i;
         uint32_t mn = 255, mx = 0;
-        if (g4x >= 0 && g4x < w4 && g4y >= 0 && g4y < h4) {
+        if (INNER || (g4x >= 0 && g4x < w4 && g4y >= 0 && g4y < h4)) {
 #pragma unroll
             for (int rr = 0; rr < 4; rr++) {
                 uint32_t d = *reinterpret_cast<const uint32_t *>(lds + OFF_IMG + (4 * i + rr) * IMG_PITCH + xb + 4 * j);
@@ -353,6 +361,8 @@ __global__ __launch_bounds__(KNT) __attribute__((amdgpu_num_sgpr(80))) void k_ti
         }
         minmax[item] = mn | (mx << 8); // outside the frame: (255,0) is neutral for the dilation
     }
+    };
+    if (!PRE) { if (inner) p1(std::true_type{}); else p1(std::false_type{}); }
     lds_barrier();
 
     // ---- P2: 3x3 dilation -> per-4x4-tile threshold word (bit 8 = low contrast); column j = 4x4 column c4x + j -------
@@ -386,10 +396,11 @@ __global__ __launch_bounds__(KNT) __attribute__((amdgpu_num_sgpr(80))) void k_ti
     uint16_t *mask16 = reinterpret_cast<uint16_t *>(lds + OFF_MASK); // [r][word][colour][half]
     const bool packed_rows = (w & 3) == 0; // rows of thresh[] / labels[] start 4-pixel aligned: vector stores
     // the lane's 16 threshold bytes to global memory
-    auto store_thresh = [&](int gy, int gx, const uint32_t (&out)[4]) {
-        if (gy < h && gx < w) {
+    auto store_thresh = [&](auto FULLC, int gy, int gx, const uint32_t (&out)[4]) {
+        constexpr bool FULL = decltype(FULLC)::value;
+        if (FULL || (gy < h && gx < w)) {
             uint8_t *dst = thresh + fbase + (size_t)gy * w + gx;
-            if (packed_rows && gx + 16 <= w && (w & 15) == 0) *reinterpret_cast<uint4 *>(dst) = make_uint4(out[0], out[1], out[2], out[3]);
+            if (FULL || (packed_rows && gx + 16 <= w && (w & 15) == 0)) *reinterpret_cast<uint4 *>(dst) = make_uint4(out[0], out[1], out[2], out[3]);
             else if (packed_rows) {
 #pragma unroll
                 for (int k = 0; k < 4; k++)
@@ -402,19 +413,20 @@ __global__ __launch_bounds__(KNT) __attribute__((amdgpu_num_sgpr(80))) void k_ti
     };
     uint32_t any_colour = 0;
     int tile_has_runs = 0;
-    if (tile_contrast) {
+    auto p3 = [&](auto FULLC) {
+        constexpr bool FULL = decltype(FULLC)::value;
         const int r = tid >> 3, c = tid & 7;
         const int gy = ty0 + r, gx = tx0 + 16 * c;
         uint4 px = *reinterpret_cast<const uint4 *>(lds + OFF_IMG + (r + yoff) * IMG_PITCH + 16 + 16 * c);
         uint32_t in[4] = {px.x, px.y, px.z, px.w}, out[4];
         uint32_t wbits = 0, bbits = 0;
-        const int r4 = min(gy >> 2, h4 - 1) - c4y;
+        const int r4 = (FULL ? (gy >> 2) : min(gy >> 2, h4 - 1)) - c4y;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const int x = gx + 4 * k;
-            uint32_t tw_ = PRE ? 0u : thr[r4 * (TW / 4) + min(x >> 2, w4 - 1) - c4x];
+            uint32_t tw_ = PRE ? 0u : thr[r4 * (TW / 4) + (FULL ? (x >> 2) : min(x >> 2, w4 - 1)) - c4x];
             uint32_t o, wn, bn; // the four output bytes and the white / black bits of the group
-            if (gy >= h || x >= w) { o = 0x7F7F7F7Fu; wn = 0; bn = 0; }     // outside the frame: no colour
+            if (!FULL && (gy >= h || x >= w)) { o = 0x7F7F7F7Fu; wn = 0; bn = 0; }     // outside the frame: no colour
             else {
                 if (PRE) { o = in[k]; wn = msb_nibble(o); bn = msb_nibble(~(o << 7)); } // 255 -> bit 7 set; 0 -> bit 0 clear (127 and 255 have it set)
                 else {
@@ -430,7 +442,7 @@ __global__ __launch_bounds__(KNT) __attribute__((amdgpu_num_sgpr(80))) void k_ti
                     const uint32_t t = (pm | (pm >> 14)) & 15u;
                     wn = lowc ? 0u : t; bn = lowc ? 0u : (t ^ 15u);
                 }
-                if (__builtin_amdgcn_ballot_w64(x + 4 > w)) // (scalar branch: only the wave at the frame's right edge, and only when
+                if (!FULL && __builtin_amdgcn_ballot_w64(x + 4 > w)) // (scalar branch: only the wave at the frame's right edge, and only when
                     if (x + 4 > w) {                         // the width is not a multiple of 4: the frame ends inside this group)
                         const uint32_t keep = 0xFFFFFFFFu >> (8 * (x + 4 - w));
                         o = (o & keep) | (0x7F7F7F7Fu & ~keep);
@@ -441,7 +453,7 @@ __global__ __launch_bounds__(KNT) __attribute__((amdgpu_num_sgpr(80))) void k_ti
             wbits |= wn << (4 * k);
             bbits |= bn << (4 * k);
         }
-        store_thresh(gy, gx, out);
+        store_thresh(FULLC, gy, gx, out);
         const int wd = c >> 1, half = c & 1;
         mask16[(((r * NWD + wd) * 2 + 0) << 1) + half] = (uint16_t)wbits;
         mask16[(((r * NWD + wd) * 2 + 1) << 1) + half] = (uint16_t)bbits;
@@ -450,9 +462,12 @@ __global__ __launch_bounds__(KNT) __attribute__((amdgpu_num_sgpr(80))) void k_ti
         if (__builtin_amdgcn_ballot_w64(any_colour != 0) && (tid & 63) == 0) misc[9] = 1;
         lds_barrier();
         tile_has_runs = (int)misc[9];
-    } else {
+    };
+    if (tile_contrast) { if (full) p3(std::true_type{}); else p3(std::false_type{}); }
+    else {
         const uint32_t out[4] = {0x7F7F7F7Fu, 0x7F7F7F7Fu, 0x7F7F7F7Fu, 0x7F7F7F7Fu};
-        store_thresh(ty0 + (tid >> 3), tx0 + 16 * (tid & 7), out);
+        if (full) store_thresh(std::true_type{}, ty0 + (tid >> 3), tx0 + 16 * (tid & 7), out);
+        else store_thresh(std::false_type{}, ty0 + (tid >> 3), tx0 + 16 * (tid & 7), out);
     }
     TPROF(2);
 
@@ -579,7 +594,7 @@ __global__ __launch_bounds__(KNT) __attribute__((amdgpu_num_sgpr(80))) void k_ti
             if (fl & CK_LINK_CROSS_R) push(lower(31u), upbase + 32u + (((info_ur >> 14) & 1u) ? 0u : (uint32_t)TW));
         }
     }
-    if (tid >= 2 * 64 && tid < 3 * 64) { // (a lane per pixel of the frame's non-origin columns: entries no pair-word node owns)
+    if (tid >= 2 * 64 && tid < 3 * 64 && (tx0 == 0 || tx0 + TW >= w)) { // (a lane per pixel of the frame's non-origin columns: entries no pair-word node owns)
         int r, xl; uint32_t ec;
         if (edge_pixel(mk, tid & 63, tx0, ty0, w, h, r, xl, ec)) parent[r * TW + xl] = (uint16_t)CK_ROOT;
     }
