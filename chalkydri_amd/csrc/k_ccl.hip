@@ -730,22 +730,17 @@ __global__ __launch_bounds__(KNT) __attribute__((amdgpu_num_sgpr(80))) void k_ti
     // (id | colour << 15) for the merge stage in a register; ids are complete after the barrier.
     {
         ck_border_root *slice = broots + ((size_t)frame * 2 * tiles + tile) * RING_CAP; // [frame][slices | packed copy]
-#pragma unroll
-        for (int rnd = 0; rnd < 2; rnd++) {
-            const int item = rnd * KNT + tid;
-            if (item >= 2 * TW + 2 * TH) continue;
-            int rr, xx;
-            if (item < TW) { rr = 0; xx = item; }
-            else if (item < 2 * TW) { rr = TH - 1; xx = item - TW; }
-            else if (item < 2 * TW + TH) { rr = item - 2 * TW; xx = 0; }
-            else { rr = item - 2 * TW - TH; xx = TW - 1; }
-            if (ty0 + rr >= h || tx0 + xx >= w) continue;
-            // a pixel on a side behind which another tile lies makes its component ring-touching (that is the definition)
-            const bool side = item < TW ? ty0 > 0 : (item < 2 * TW ? ty0 + TH < h : (item < 2 * TW + TH ? tx0 > 0 : tx0 + TW < w));
+        // (which ring pixel a lane looks at is uniform per wave in the first round — waves 0 and 1 the tile's top row, 2 and 3 its
+        // bottom row — and one compare in the second, which only wave 0 runs: the left column on lanes 0..31, the right one on 32..63;
+        // as a chain of per-lane selects over a running item number this bookkeeping was a fifth of the phase)
+        const int wv6 = __builtin_amdgcn_readfirstlane(tid >> 6);
+        auto ring_pixel = [&](const int rnd, const int rr, const int xx, const bool side) {
+            if (!full && (ty0 + rr >= h || tx0 + xx >= w)) return;
             const int wd = xx >> 5, i = xx & 31;
             const uint32_t Wm = mk[(rr * NWD + wd) * 2], Bm = mk[(rr * NWD + wd) * 2 + 1];
             const uint32_t white = (Wm >> i) & 1u;
-            if (!side || !(((Wm | Bm) >> i) & 1u)) continue;
+            // a pixel on a side behind which another tile lies makes its component ring-touching (that is the definition)
+            if (!side || !(((Wm | Bm) >> i) & 1u)) return;
             const uint32_t Oo = ck_origin32(tx0 + 32 * wd, w);
             const uint32_t node = ((Oo >> i) & 1u) ? node_lookup(mk, s2w, rr, wd, i, white ^ 1u, Oo) : (uint32_t)(rr * TW + xx); // (a non-origin column's pixel is a node of its own)
             const uint32_t e = parent[node];
@@ -753,9 +748,9 @@ __global__ __launch_bounds__(KNT) __attribute__((amdgpu_num_sgpr(80))) void k_ti
             ring_root[rnd] = root; ring_white[rnd] = white;
             const uint32_t sh = (root & 1u) * 16u;
             const uint32_t re = (parent32[root >> 1] >> sh) & 0xFFFFu;
-            if (re & CK_CLAIM) continue;                        // claimed already
+            if (re & CK_CLAIM) return;                        // claimed already
             const uint32_t old = atomicOr(&parent32[root >> 1], (CK_CLAIM | CK_RING) << sh);
-            if ((old >> sh) & CK_CLAIM) continue;               // another lane won
+            if ((old >> sh) & CK_CLAIM) return;               // another lane won
             // white roots take the ids 0, 1, ... and black ones RING_CAP - 1, RING_CAP - 2, ... (the merge stage joins the two
             // colours in separate workgroups); they cannot meet: a ring-touching root owns at least one of the RING_CAP ring pixels
             const uint32_t id = white ? atomicAdd(&misc[6], 1u) : (uint32_t)(RING_CAP - 1) - atomicAdd(&misc[7], 1u);
@@ -764,7 +759,9 @@ __global__ __launch_bounds__(KNT) __attribute__((amdgpu_num_sgpr(80))) void k_ti
             br.size = (old >> sh) & CK_COUNT;
             slice[id] = br;
             parent[root] = (uint16_t)(CK_ROOT | CK_RING | CK_CLAIM | id);
-        }
+        };
+        ring_pixel(0, wv6 >= 2 ? TH - 1 : 0, tid & (TW - 1), wv6 >= 2 ? ty0 + TH < h : ty0 > 0);
+        if (wv6 == 0) ring_pixel(1, tid & 31, (tid & 32) ? TW - 1 : 0, (tid & 32) ? tx0 + TW < w : tx0 > 0);
     }
     lds_barrier();
     } // tile_has_runs
@@ -774,20 +771,21 @@ __global__ __launch_bounds__(KNT) __attribute__((amdgpu_num_sgpr(80))) void k_ti
     if (stop_after == 7) return; // diagnostics (CK_TILE_STOP_AFTER)
     uint16_t *ring_f = ring + (size_t)frame * ring_len;
     // the ring entries of the pixels this lane looked at in P6b (rows: HT / HB, columns: VL / VR; layout in ck_internal.h)
-#pragma unroll
-    for (int rnd = 0; rnd < 2; rnd++) {
-        const int item = rnd * KNT + tid;
-        if (item >= 2 * TW + 2 * TH) continue;
-        int rr, xx;
-        size_t dst;
-        if (item < TW) { rr = 0; xx = item; dst = (size_t)ty * w + (size_t)(tx0 + xx); }
-        else if (item < 2 * TW) { rr = TH - 1; xx = item - TW; dst = (size_t)tiles_y * w + (size_t)ty * w + (size_t)(tx0 + xx); }
-        else if (item < 2 * TW + TH) { rr = item - 2 * TW; xx = 0; dst = 2 * (size_t)tiles_y * w + (size_t)tx * h + (size_t)(ty0 + rr); }
-        else { rr = item - 2 * TW - TH; xx = TW - 1; dst = 2 * (size_t)tiles_y * w + (size_t)tiles_x * h + (size_t)tx * h + (size_t)(ty0 + rr); }
-        if (ty0 + rr >= h || tx0 + xx >= w) continue;
-        uint32_t val = 0xFFFFu;
-        if (tile_has_runs && ring_root[rnd] != 0xFFFFFFFFu) val = ((uint32_t)parent[ring_root[rnd]] & 0x1FFu) | (ring_white[rnd] << 15);
-        ring_f[dst] = (uint16_t)val;
+    {
+        const int wv6 = __builtin_amdgcn_readfirstlane(tid >> 6);
+        auto ring_out = [&](const int rnd, const int rr, const int xx, const size_t dst) {
+            if (!full && (ty0 + rr >= h || tx0 + xx >= w)) return;
+            uint32_t val = 0xFFFFu;
+            if (tile_has_runs && ring_root[rnd] != 0xFFFFFFFFu) val = ((uint32_t)parent[ring_root[rnd]] & 0x1FFu) | (ring_white[rnd] << 15);
+            ring_f[dst] = (uint16_t)val;
+        };
+        const int xx0 = tid & (TW - 1);
+        ring_out(0, wv6 >= 2 ? TH - 1 : 0, xx0, (wv6 >= 2 ? (size_t)tiles_y * w : (size_t)0) + (size_t)ty * w + (size_t)(tx0 + xx0));
+        if (wv6 == 0) {
+            const int rr1 = tid & 31;
+            const bool right = (tid & 32) != 0;
+            ring_out(1, rr1, right ? TW - 1 : 0, 2 * (size_t)tiles_y * w + (right ? (size_t)tiles_x * h : (size_t)0) + (size_t)tx * h + (size_t)(ty0 + rr1));
+        }
     }
     if (!tile_has_runs || tabled) {
     // ---- P6c: the label word of every node (16 bits: ck_internal.h), formed once per node from its root's entry (interior component:
