@@ -133,6 +133,7 @@ extern "C" int ck_create(const ck_config_t *cfg, ck_handle_t **out) {
     CK_TRY(ck_malloc_dev(&h->d_groot, (size_t)h->broot_cap * nb * sizeof(uint32_t)));
     CK_TRY(ck_malloc_dev(&h->d_gsize, (size_t)h->broot_cap * nb * sizeof(uint32_t)));
     CK_TRY(ck_malloc_dev(&h->d_gscratch, 2 * (size_t)h->broot_cap * nb * sizeof(uint32_t)));
+    CK_TRY(ck_malloc_dev(&h->d_xband, 2 * (size_t)h->broot_cap * nb * sizeof(uint32_t)));
     CK_TRY(ck_malloc_dev(&h->d_broots, 2 * (size_t)h->broot_cap * nb * sizeof(ck_border_root)));
     CK_TRY(ck_malloc_dev(&h->d_tile_count, (size_t)h->tiles_x * h->tiles_y * nb * sizeof(uint32_t)));
     CK_TRY(ck_malloc_dev(&h->d_ring, h->ring_len * nb * sizeof(uint16_t)));
@@ -152,7 +153,7 @@ extern "C" void ck_destroy(ck_handle_t *h) {
     if (h->seg_stream) (void)hipStreamSynchronize(h->seg_stream);
     ck_stage_free(h);
     (void)ck_free_dev(h->d_frames); (void)ck_free_dev(h->d_qframes); (void)ck_free_dev(h->d_thresh); (void)ck_free_dev(h->d_labels);
-    (void)ck_free_dev(h->d_groot); (void)ck_free_dev(h->d_gsize); (void)ck_free_dev(h->d_gscratch); (void)ck_free_dev(h->d_broots); (void)ck_free_dev(h->d_tile_count); (void)ck_free_dev(h->d_ring);
+    (void)ck_free_dev(h->d_groot); (void)ck_free_dev(h->d_gsize); (void)ck_free_dev(h->d_gscratch); (void)ck_free_dev(h->d_xband); (void)ck_free_dev(h->d_broots); (void)ck_free_dev(h->d_tile_count); (void)ck_free_dev(h->d_ring);
     for (auto &e : h->ev) if (e) (void)hipEventDestroy(e);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);

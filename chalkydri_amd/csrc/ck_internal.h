@@ -178,6 +178,7 @@ struct ck_handle {
     uint32_t *d_groot;   // [n][broot_cap] slot table: frame-level root (pixel index) of every ring-touching tile-local component
     uint32_t *d_gsize;   // [n][broot_cap] slot table: its pixel count (exact while below min_component_px)
     uint32_t *d_gscratch; // [n][2][broot_cap] parents and sizes of k_fmerge's global-memory path
+    uint32_t *d_xband;    // [n][2][broot_cap] a frame joined in bands of tile rows: every slot's root within its band, the band roots' parents (k_fseam)
     ck_border_root *d_broots; // [n][2][broot_cap]: per tile a slice of CK_RING_CAP entries (k_tile), then the same entries packed (k_fmerge)
     uint32_t *d_tile_count;   // [n][tiles]: entries used in every tile's slice
     int broot_cap;            // tiles * CK_RING_CAP

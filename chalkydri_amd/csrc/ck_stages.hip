@@ -141,7 +141,7 @@ static ck_handle make_view(const ck_handle *h, int f0, bool second_stream = true
     if (h->cfg.quad_decimate > 1) v.d_qframes += f * (size_t)((h->qw + 15) / 16 * 16) * h->qh;
     else v.d_qframes = v.d_frames;
     v.d_thresh += f * npix; v.d_labels += f * npix;
-    v.d_groot += f * h->broot_cap; v.d_gsize += f * h->broot_cap; v.d_gscratch += f * 2 * h->broot_cap;
+    v.d_groot += f * h->broot_cap; v.d_gsize += f * h->broot_cap; v.d_gscratch += f * 2 * h->broot_cap; v.d_xband += f * 2 * h->broot_cap;
     v.d_broots += f * 2 * h->broot_cap; v.d_tile_count += f * (size_t)(h->tiles_x * h->tiles_y); v.d_ring += f * h->ring_len;
     w.d_ht_keys += f * w.ht_size; w.d_ht_count += f * w.ht_size; w.d_ht_off += f * w.ht_size;
     w.d_tmp += f * w.ext_cap; w.d_points += f * w.ext_cap; w.d_runs += f * w.run_cap;

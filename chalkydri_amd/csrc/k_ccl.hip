@@ -1001,6 +1001,7 @@ namespace {
 // pixel, so a union hooks the root with the larger PIXEL under the other one (compare-and-swap on the root's own entry).
 constexpr int FM_NT = 1024;
 constexpr int FM_CAP = 30000;                 // roots a workgroup's LDS path holds with 16-bit pixel keys beside the parents (twice as many without)
+constexpr int FM_BAND_TILES = 256;            // a frame with more tiles is joined in bands of tile rows of at most this many tiles
 constexpr int FM_WQ = 384;                    // joins a wave's queue holds (one round of boundary pixels adds at most 192)
 constexpr int FM_WQS = FM_WQ + 8;             // a queue's stride in LDS: entry FM_WQ takes the joins that are none (stores without a branch)
 constexpr uint32_t NOJ = 0xFFFFFFFFu;         // "no join"
@@ -1012,7 +1013,8 @@ struct FmFrame {
     const uint32_t *numtab;            // [tile][2]: what a white id is added to / a black id subtracted from to give the root's number (LDS)
     const uint16_t *hseg, *vseg;       // the tile edges worth sweeping (LDS): tile row << 5 | tile column of the tile below / on the right
     int nhs, nvs;
-    int w, h, tiles_x, tiles_y;
+    int w, h, tiles_x, tiles_y;        // h: the frame's height (the pitch of the ring columns); tiles_y: tile rows of the BAND
+    int hb;                            // pixel rows of the band this workgroup joins (the frame's height for a frame in one band)
     uint32_t mode;                     // what this workgroup joins: 0 the black roots, 1 the white ones, 2 both (a frame with few roots)
     int diag;                          // diagnostics (CK_FMERGE_STOP_AFTER 20 / 21): 1 the sweep without its loads, 2 without its joins
     // k_tile hands out white ids from 0 up and black ones from RING_CAP - 1 down; among the roots this workgroup joins, a tile's
@@ -1027,6 +1029,16 @@ struct FmFrame {
     __device__ __forceinline__ uint32_t id_of(int t, uint32_t l, uint32_t cnt) const {
         const uint32_t nw = mode == 2u ? (uint32_t)boff[t] : (mode == 1u ? cnt : 0u);
         return l < nw ? l : (uint32_t)(RING_CAP - 1) - (l - nw);
+    }
+    // slot (tile * RING_CAP + tile-local id) of root number r: its tile is the last one whose first number is <= r
+    __device__ __forceinline__ uint32_t slot_of(uint32_t r, int tiles) const {
+        int lo = 0, hi = tiles; // base[lo] <= r < base[hi]
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (base[mid] <= r) lo = mid; else hi = mid;
+        }
+        const uint32_t b0 = base[lo];
+        return (uint32_t)lo * (uint32_t)RING_CAP + id_of(lo, r - b0, base[lo + 1] - b0);
     }
 };
 // Calls emit(j0, j1, j2) once per boundary pixel slot and lane (uniformly: every lane of the workgroup makes the same number of
@@ -1077,7 +1089,7 @@ __device__ __forceinline__ void fm_edges(const FmFrame &f, int tiles, uint16_t *
 // form (numbers beyond 16 bits), used when `wide`.
 template <typename EmitQ, typename EmitWide>
 __device__ __forceinline__ void fm_boundaries(const FmFrame &f, int tid, bool wide, EmitQ &&emit_q, EmitWide &&emit_wide) {
-    const int w = f.w, h = f.h, tiles_x = f.tiles_x, tiles_y = f.tiles_y;
+    const int w = f.w, h = f.h, hb = f.hb, tiles_x = f.tiles_x, tiles_y = f.tiles_y;
     const FmRow8 none = {~0ull, ~0ull};
     const uint32_t mode = f.mode;
     auto acc = [mode](uint32_t e) -> bool { return (e != 0xFFFFu) & ((mode == 2u) | ((e >> 15) == mode)); };
@@ -1145,9 +1157,9 @@ __device__ __forceinline__ void fm_boundaries(const FmFrame &f, int tid, bool wi
             const uint32_t sg = f.vseg[item / (TH / FM_GRP)];
             txi = (int)(sg & 31u);
             Y = (int)(sg >> 5) * TH + (item % (TH / FM_GRP)) * FM_GRP;
-            if (Y < h && f.diag != 1) {
+            if (Y < hb && f.diag != 1) { // (rows are the band's own: its ring columns start at its first pixel row, their pitch is the frame's height)
                 const uint16_t *lf = f.VR + (size_t)(txi - 1) * h, *rt = f.VL + (size_t)txi * h;
-                P = fm_load8(rt, Y, h); Q = fm_load8(lf, Y, h);   // pixels (x, y ..) and (x - 1, y ..)
+                P = fm_load8(rt, Y, hb); Q = fm_load8(lf, Y, hb);   // pixels (x, y ..) and (x - 1, y ..)
                 if (Y > 0) { ql = lf[Y - 1]; pu = rt[Y - 1]; }
             }
         }
@@ -1274,7 +1286,7 @@ __device__ __forceinline__ void fm_global_begin(uint32_t n, uint32_t *gparent, u
     __syncthreads();
 }
 __device__ __forceinline__ void fm_global_end(const FmFrame &f, const ck_border_root *__restrict__ br, uint32_t n, uint32_t *gparent, uint32_t *gsz,
-                                              uint32_t *groot, uint32_t *gsize, int tiles) {
+                                              uint32_t *groot, uint32_t *gsize, int tiles, uint32_t *bslot, uint32_t *xpar, uint32_t slot_lo) {
     const int tid = threadIdx.x;
     __threadfence();
     __syncthreads();
@@ -1293,6 +1305,10 @@ __device__ __forceinline__ void fm_global_end(const FmFrame &f, const ck_border_
             const size_t slot = (size_t)t * RING_CAP + f.id_of(t, l, cnt);
             groot[slot] = br[r].root;
             gsize[slot] = gm_load(gsz, r);
+            if (bslot) { // a frame in bands: which band root the slot belongs to (frame-level slot numbers)
+                if (r == b0 + l) { bslot[slot] = slot_lo + (uint32_t)slot; xpar[slot] = slot_lo + (uint32_t)slot; }
+                else bslot[slot] = slot_lo + f.slot_of(r, tiles);
+            }
         }
     }
 }
@@ -1313,7 +1329,8 @@ __device__ unsigned long long g_fm_prof[16];
 __global__ __launch_bounds__(FM_NT, 4) __attribute__((amdgpu_num_sgpr(80))) void k_fmerge(ck_border_root *__restrict__ broots, const uint32_t *__restrict__ tile_count,
                                                   const uint16_t *__restrict__ ring, size_t ring_len, uint32_t *__restrict__ groot_all,
                                                   uint32_t *__restrict__ gsize_all, uint32_t *__restrict__ gscratch, size_t npix, int w, int h,
-                                                  int tiles_x, int tiles_y, int frame0, int n_frames, int min_comp, int lds_cap, int stop_after) {
+                                                  int tiles_x, int tiles_y_frame, int frame0, int n_frames, int min_comp, int lds_cap, int stop_after,
+                                                  int band_rows, uint32_t *__restrict__ xband) {
     extern __shared__ __attribute__((aligned(16))) uint8_t fm_lds[];
     __shared__ uint32_t wsum[2 * (FM_NT / 64)];
     __shared__ uint32_t segn[2];
@@ -1321,11 +1338,22 @@ __global__ __launch_bounds__(FM_NT, 4) __attribute__((amdgpu_num_sgpr(80))) void
     // whose roots fit one workgroup: they must not hold the LDS of a CU while white ones wait for it).  Workgroups b and b + 8
     // share an XCD: a frame's workgroups run where k_tile wrote its ring entries and root slices (XCD f % 8 when frames are
     // dealt to XCDs).
+    // Round 4: a frame with more tile rows than `band_rows` is joined in BANDS of whole tile rows — one (or two) workgroups per band, each
+    // with a band's roots in the keyed LDS path (2448 x 2048 of dense noise: 55 000 black roots per frame, which one workgroup had to join
+    // on the parents-only path with its sizes and smallest pixels in global memory) — and k_fseam / k_fapply join the bands.  A band
+    // works in its own coordinates: tile rows, pixel rows, tile indices and slots count from the band's first tile row (the pointers are
+    // advanced), so everything below reads as it did for a whole frame.
     const int half = (int)(gridDim.x >> 1); // a multiple of 8
     const uint32_t col = (int)blockIdx.x < half ? 1u : 0u; // 1 = white
-    const int frame = frame0 + (int)blockIdx.x - (col ? 0 : half), tid = threadIdx.x; // (frames [frame0, n_frames) of the batch)
+    const int bands = (tiles_y_frame + band_rows - 1) / band_rows, f8 = half / bands;
+    const int rel = (int)blockIdx.x - (col ? 0 : half), band = rel / f8;
+    const int frame = frame0 + rel - band * f8, tid = threadIdx.x; // (frames [frame0, n_frames) of the batch)
     if (frame >= n_frames) return;
-    const int tiles = tiles_x * tiles_y;
+    const int ty_lo = band * band_rows, tiles_y = min(tiles_y_frame - ty_lo, band_rows);
+    const int tiles = tiles_x * tiles_y, t_lo = ty_lo * tiles_x;                 // the band's tiles; its first tile in the frame
+    const int hb = min(h - ty_lo * TH, tiles_y * TH);                              // its pixel rows
+    const size_t frame_slots = (size_t)tiles_x * tiles_y_frame * RING_CAP, slot_lo = (size_t)t_lo * RING_CAP;
+    tile_count += (size_t)frame * tiles_x * tiles_y_frame + t_lo;
     uint16_t *parent = reinterpret_cast<uint16_t *>(fm_lds);
     uint16_t *size16 = parent + lds_cap;                                   // (lds_cap is even)
     uint32_t *base = reinterpret_cast<uint32_t *>(size16 + lds_cap);
@@ -1333,13 +1361,17 @@ __global__ __launch_bounds__(FM_NT, 4) __attribute__((amdgpu_num_sgpr(80))) void
     uint16_t *boff = reinterpret_cast<uint16_t *>(queue + (FM_NT / 64) * FM_WQS);
     uint16_t *hseg = boff + ((tiles + 7) & ~7), *vseg = hseg + ((tiles + 7) & ~7);
     uint32_t *numtab = reinterpret_cast<uint32_t *>(vseg + ((tiles + 7) & ~7));
-    const size_t slots = (size_t)tiles * RING_CAP;
-    const ck_border_root *slice = broots + (size_t)frame * 2 * slots;
-    uint32_t *groot = groot_all + (size_t)frame * slots, *gsize = gsize_all + (size_t)frame * slots;
+    const size_t slots = (size_t)tiles * RING_CAP; // of the band
+    const ck_border_root *slice = broots + (size_t)frame * 2 * frame_slots + slot_lo;
+    uint32_t *groot = groot_all + (size_t)frame * frame_slots + slot_lo, *gsize = gsize_all + (size_t)frame * frame_slots + slot_lo;
+    // what the joining of the bands needs of every slot (frame-level slot numbers; null for a frame in one band): bslot[slot] = slot of
+    // the component's root WITHIN ITS BAND; xpar[slot] = the band root's parent in the union-find over band roots (itself to begin with)
+    uint32_t *bslot = xband ? xband + (size_t)frame * 2 * frame_slots + slot_lo : nullptr, *xpar = xband ? bslot + frame_slots : nullptr;
     const uint16_t *fr = ring + (size_t)frame * ring_len;
     FmFrame f;
-    f.HT = fr; f.HB = fr + (size_t)tiles_y * w; f.VL = fr + 2 * (size_t)tiles_y * w; f.VR = f.VL + (size_t)tiles_x * h;
-    f.base = base; f.boff = boff; f.numtab = numtab; f.w = w; f.h = h; f.tiles_x = tiles_x; f.tiles_y = tiles_y;
+    f.HT = fr + (size_t)ty_lo * w; f.HB = fr + (size_t)tiles_y_frame * w + (size_t)ty_lo * w;
+    f.VL = fr + 2 * (size_t)tiles_y_frame * w + (size_t)ty_lo * TH; f.VR = f.VL + (size_t)tiles_x * h;
+    f.base = base; f.boff = boff; f.numtab = numtab; f.w = w; f.h = h; f.hb = hb; f.tiles_x = tiles_x; f.tiles_y = tiles_y;
     f.diag = stop_after == 20 ? 1 : (stop_after == 21 ? 2 : (stop_after == 22 ? 1 : 0));
     // numbers: the tiles' counts, scanned (up to four tiles per thread).  Both colours are counted first: when all of a frame's
     // roots fit the LDS path together, the white workgroup joins both colours in one sweep and the black one has nothing to do.
@@ -1349,7 +1381,7 @@ __global__ __launch_bounds__(FM_NT, 4) __attribute__((amdgpu_num_sgpr(80))) void
         uint32_t cw[4] = {0, 0, 0, 0}, cb[4] = {0, 0, 0, 0}, sw = 0, sb = 0;
         for (int k = 0; k < per; k++) {
             const int t = tid * per + k;
-            const uint32_t tc = t < tiles ? tile_count[(size_t)frame * tiles + t] : 0u; // white | black << 16
+            const uint32_t tc = t < tiles ? tile_count[t] : 0u; // white | black << 16
             cw[k] = tc & 0xFFFFu; cb[k] = tc >> 16;
             sw += cw[k]; sb += cb[k];
         }
@@ -1385,15 +1417,15 @@ __global__ __launch_bounds__(FM_NT, 4) __attribute__((amdgpu_num_sgpr(80))) void
     f.hseg = hseg; f.vseg = vseg; f.nhs = (int)segn[0]; f.nvs = (int)segn[1];
     // the same entries packed, a root's index = its number: from the front of the frame's second half — the black workgroup of a
     // frame whose colours are joined separately packs at its end (the two colours' roots together are at most `slots`)
-    ck_border_root *br = broots + (size_t)frame * 2 * slots + slots + (f.mode == 0u ? slots - n : 0);
-    uint32_t *sc = gscratch + (size_t)frame * 2 * slots + (f.mode == 0u ? slots - n : 0); // global-memory path: parents; the sizes `slots` further on
+    ck_border_root *br = broots + (size_t)frame * 2 * frame_slots + frame_slots + slot_lo + (f.mode == 0u ? slots - n : 0);
+    uint32_t *sc = gscratch + (size_t)frame * 2 * frame_slots + slot_lo + (f.mode == 0u ? slots - n : 0); // global-memory path: parents; the sizes a frame's slots further on
     // More roots than parents + keys fit: up to twice as many (and at most 65 535) still run their unions in LDS, on the parents
     // alone — hooked by root number, with the components' smallest pixels and sizes settled afterwards by atomics in global memory.
     const bool keyless = n > (uint32_t)lds_cap;
     // ... and beyond that (or with a min_component_px the 16-bit sizes cannot express) the same steps run in global memory; the
     // boundary sweep below is the same code for both (one instantiation: its joins go to the wave's queue or straight to gm_union)
     const bool gmode = n > 2u * (uint32_t)lds_cap || n > 0xFFFFu || min_comp > 0x7FFF;
-    uint32_t *gsz = sc + slots;
+    uint32_t *gsz = sc + frame_slots;
     // while the unions run, the size array holds the roots' pixel keys: pixel index >> key_shift, 16 bits
     int key_shift = 0;
     while ((npix - 1) >> key_shift > 0xFFFFu) key_shift++;
@@ -1488,7 +1520,7 @@ __global__ __launch_bounds__(FM_NT, 4) __attribute__((amdgpu_num_sgpr(80))) void
         },
         [&](uint32_t a0, uint32_t b0, uint32_t a1, uint32_t b1, uint32_t a2, uint32_t b2) { gm_union(sc, br, a0, b0); gm_union(sc, br, a1, b1); gm_union(sc, br, a2, b2); });
     FPROF(3);
-    if (gmode) { fm_global_end(f, br, n, sc, gsz, groot, gsize, tiles); return; }
+    if (gmode) { fm_global_end(f, br, n, sc, gsz, groot, gsize, tiles, bslot, xpar, (uint32_t)slot_lo); return; }
     drain();
     __syncthreads();
     FPROF(4);
@@ -1555,6 +1587,20 @@ __global__ __launch_bounds__(FM_NT, 4) __attribute__((amdgpu_num_sgpr(80))) void
 #pragma unroll
             for (int v = 0; v < 2; v++)
                 if (rr[u][v] != 0xFFFFFFFFu) { groot[slot[u][v]] = rootv[u][v]; gsize[slot[u][v]] = sizev[u][v]; }
+        if (bslot) { // a frame in bands: which band root every slot belongs to (frame-level slot numbers); a band root is its own parent
+#pragma unroll
+            for (int u = 0; u < FM_PT; u++)
+#pragma unroll
+                for (int v = 0; v < 2; v++) {
+                    const uint32_t r = rr[u][v];
+                    if (r == 0xFFFFFFFFu) continue;
+                    const int t = t0 + u * (FM_NT / 64);
+                    const uint32_t own = base[t] + (uint32_t)(tid & 63) + 64u * v;
+                    const uint32_t rs = r == own ? (uint32_t)slot[u][v] : f.slot_of(r, tiles);
+                    bslot[slot[u][v]] = (uint32_t)slot_lo + rs;
+                    if (r == own) xpar[slot[u][v]] = (uint32_t)slot_lo + rs;
+                }
+        }
         for (int u = 0; u < FM_PT; u++) { // (more than 128 roots in a tile: the rest)
             const int t = t0 + u * (FM_NT / 64);
             if (t >= tiles) break;
@@ -1564,6 +1610,11 @@ __global__ __launch_bounds__(FM_NT, 4) __attribute__((amdgpu_num_sgpr(80))) void
                 const size_t sl = (size_t)t * RING_CAP + f.id_of(t, l, cnt);
                 groot[sl] = keyless ? gm_load(sc, r) : br[r].root;
                 gsize[sl] = keyless ? gm_load(gsz, r) : size16[r];
+                if (bslot) {
+                    const uint32_t rs = r == b0 + l ? (uint32_t)sl : f.slot_of(r, tiles);
+                    bslot[sl] = (uint32_t)slot_lo + rs;
+                    if (r == b0 + l) xpar[sl] = (uint32_t)slot_lo + rs;
+                }
             }
         }
     }
@@ -1580,6 +1631,101 @@ extern "C" int ck_fm_profile_read(unsigned long long *out, int reset) {
 }
 namespace {
 #endif
+
+// ---- a frame in bands (round 4): the bands' components joined across the band boundaries ---------------------------------------
+// k_fmerge has joined every band of tile rows by itself and left, per slot, groot / gsize at the BAND's level, bslot[slot] = the slot
+// of the component's root within its band, and every band root its own parent in xpar[].  k_fseam (one workgroup per frame) replays
+// the connectivity rule across the band boundaries — the top row of a band's first tile row against the bottom row of the tile row
+// above it: up for both colours, up-left and up-right for white (crates/chalkydri-apriltags/src/lib.rs:501-549; the diagonal joins
+// of the tile corners on that row are among them, which is why k_fmerge's vertical sweep leaves a band's first pixel row alone) — as
+// unions over band roots in global memory (a few thousand joins per frame: hooked by slot number), then folds every joined band
+// root's smallest pixel and pixel count into its final root (each band root once: a claim bit in its xpar entry).  k_fapply, one
+// thread per slot, gives every slot the values of its final root.
+constexpr uint32_t XCLAIM = 0x80000000u;
+__device__ __forceinline__ uint32_t x_find(uint32_t *xpar, uint32_t a, bool halve) {
+    for (;;) {
+        const uint32_t n = gm_load(xpar, a) & ~XCLAIM;
+        if (n == a) return a;
+        const uint32_t g = gm_load(xpar, n) & ~XCLAIM;
+        if (g == n) return n;
+        if (halve) __hip_atomic_store(&xpar[a], g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // (no claim bits yet while the unions run)
+        a = g;
+    }
+}
+__global__ __launch_bounds__(FM_NT) void k_fseam(const uint16_t *__restrict__ ring, size_t ring_len, uint32_t *__restrict__ groot_all,
+                                                 uint32_t *__restrict__ gsize_all, uint32_t *__restrict__ xband, int w, int tiles_x, int tiles_y,
+                                                 int band_rows, int frame0, int n_frames) {
+    const int frame = frame0 + (int)blockIdx.x, tid = threadIdx.x;
+    if (frame >= n_frames) return;
+    const size_t slots = (size_t)tiles_x * tiles_y * RING_CAP;
+    uint32_t *groot = groot_all + (size_t)frame * slots, *gsize = gsize_all + (size_t)frame * slots;
+    const uint32_t *bslot = xband + (size_t)frame * 2 * slots;
+    uint32_t *xpar = xband + (size_t)frame * 2 * slots + slots;
+    const uint16_t *HT = ring + (size_t)frame * ring_len, *HB = HT + (size_t)tiles_y * w;
+    const int bands = (tiles_y + band_rows - 1) / band_rows;
+    const int items = (bands - 1) * w;
+#pragma unroll 1
+    for (int pass = 0; pass < 2; pass++) {
+#pragma unroll 1
+        for (int item = tid; item < items; item += FM_NT) {
+            const int b = item / w + 1, x = item - (b - 1) * w, ty = b * band_rows;
+            if (x < 1 || x > w - 2) continue; // only origin columns join
+            const uint16_t *lo = HT + (size_t)ty * w, *up = HB + (size_t)(ty - 1) * w;
+            const uint32_t p = lo[x];
+            if (p == 0xFFFFu) continue;
+            const uint32_t q[3] = {up[x], up[x - 1], up[x + 1]};
+            const bool pw = (p & 0x8000u) != 0;
+            const uint32_t A = bslot[(size_t)(ty * tiles_x + (x >> 7)) * RING_CAP + (p & 0x7FFFu)];
+            bool a_claimed = false;
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                const int xq = k == 0 ? x : (k == 1 ? x - 1 : x + 1);
+                const bool v = q[k] != 0xFFFFu && (k == 0 ? ((q[k] ^ p) & 0x8000u) == 0 : (pw && (q[k] & 0x8000u) != 0));
+                if (!v) continue;
+                const uint32_t B = bslot[(size_t)((ty - 1) * tiles_x + (xq >> 7)) * RING_CAP + (q[k] & 0x7FFFu)];
+                if (pass == 0) { // union: the band root with the larger slot number goes under the other
+                    uint32_t a = A, c = B;
+                    for (;;) {
+                        a = x_find(xpar, a, true); c = x_find(xpar, c, true);
+                        if (a == c) break;
+                        const uint32_t hi = a > c ? a : c, lw = a > c ? c : a;
+                        if (atomicCAS(&xpar[hi], hi, lw) == hi) break;
+                    }
+                } else { // fold: every band root that took part, once
+                    for (int e = a_claimed ? 1 : 0; e < 2; e++) {
+                        const uint32_t P = e ? B : A;
+                        if (atomicOr(&xpar[P], XCLAIM) & XCLAIM) continue;
+                        const uint32_t R = x_find(xpar, P, false);
+                        if (R == P) continue;
+                        atomicMin(&groot[R], gm_load(groot, P));
+                        atomicAdd(&gsize[R], gm_load(gsize, P));
+                    }
+                    a_claimed = true;
+                }
+            }
+        }
+        __threadfence();
+        __syncthreads();
+    }
+}
+__global__ __launch_bounds__(NT) void k_fapply(const uint32_t *__restrict__ tile_count, uint32_t *__restrict__ groot_all, uint32_t *__restrict__ gsize_all,
+                                               const uint32_t *__restrict__ xband, int tiles, int frame0) {
+    const int frame = frame0 + (int)blockIdx.y;
+    const uint32_t s = blockIdx.x * NT + threadIdx.x;
+    const size_t slots = (size_t)tiles * RING_CAP;
+    if (s >= slots) return;
+    const uint32_t t = s / RING_CAP, id = s - t * RING_CAP;
+    const uint32_t tc = tile_count[(size_t)frame * tiles + t]; // white | black << 16: white ids from 0 up, black ones from RING_CAP - 1 down
+    if (!(id < (tc & 0xFFFFu) || id >= (uint32_t)RING_CAP - (tc >> 16))) return;
+    const uint32_t *bslot = xband + (size_t)frame * 2 * slots, *xpar = bslot + slots;
+    uint32_t *groot = groot_all + (size_t)frame * slots, *gsize = gsize_all + (size_t)frame * slots;
+    uint32_t R = bslot[s];
+    if (xpar[R] == R) return; // its band root took part in no join across a band boundary (no claim bit): the band's values are final
+    for (;;) { const uint32_t n = xpar[R] & ~XCLAIM; if (n == R) break; R = n; }
+    if (R == s) return; // the final root holds its values already
+    groot[s] = groot[R];
+    gsize[s] = gsize[R];
+}
 
 // ---- parity / test path: canonical labels and exact sizes ---------------------------------------------------------------------
 __global__ __launch_bounds__(NT) void k_canon(const ck_label_t *__restrict__ labels, const uint32_t *__restrict__ groot, size_t slots,
@@ -1641,11 +1787,23 @@ int ck_launch_threshold_segment(ck_handle *h, const uint8_t *frames, int stride,
     // roots the LDS path of one workgroup holds (dense binary noise has about 90 per tile).  A frame whose roots fit is joined by ONE
     // workgroup, both colours in one sweep; a larger one by two, one per colour (1920 x 1080 of dense noise: 23 000 each); a
     // workgroup with more takes the global-memory path.
-    int cap = tiles * 120;
+    // Bands of tile rows (round 4): a frame with more than FM_BAND_TILES tiles is joined band by band (k_fmerge), then across the
+    // bands (k_fseam, k_fapply) — every band then runs the keyed LDS path of a 1280 x 800 frame (250 tiles), several bands of a
+    // frame at a time on different CUs.  2448 x 2048 (1280 tiles, six bands of 11 tile rows): k_fmerge 1.9 ms per 256 frames in one
+    // piece per colour.  CK_FMERGE_BAND_ROWS (diagnostics build, read per call) forces the band height: the path-forcing tests.
+    const int band_env = CK_KNOB("CK_FMERGE_BAND_ROWS", 0);
+    int band_rows = h->tiles_y;
+    if (tiles > FM_BAND_TILES) {
+        const int rows = FM_BAND_TILES / h->tiles_x > 0 ? FM_BAND_TILES / h->tiles_x : 1, nb = (h->tiles_y + rows - 1) / rows;
+        band_rows = (h->tiles_y + nb - 1) / nb; // bands of equal height
+    }
+    if (band_env > 0 && band_env < h->tiles_y) band_rows = band_env;
+    const int bands = (h->tiles_y + band_rows - 1) / band_rows, btiles = band_rows * h->tiles_x; // tiles of a (full) band
+    int cap = btiles * 120;
     cap = cap < 4096 ? 4096 : (cap > FM_CAP ? FM_CAP : cap);
     if (cap_env > 0 && cap_env < cap) cap = cap_env;
     // (the per-tile arrays and the join queues come first: very large frames leave less room for roots)
-    const size_t fixed = (size_t)((tiles + 1 + 3) & ~3) * 4 + (size_t)(FM_NT / 64) * FM_WQS * 4 + (size_t)((tiles + 7) & ~7) * 2 * 3 + (size_t)tiles * 8;
+    const size_t fixed = (size_t)((btiles + 1 + 3) & ~3) * 4 + (size_t)(FM_NT / 64) * FM_WQS * 4 + (size_t)((btiles + 7) & ~7) * 2 * 3 + (size_t)btiles * 8;
     const size_t lds_max = 160 * 1024 - 512;
     if ((size_t)cap * 4 + fixed > lds_max) cap = (int)((lds_max - fixed) / 4);
     cap &= ~1;
@@ -1675,9 +1833,15 @@ int ck_launch_threshold_segment(ck_handle *h, const uint8_t *frames, int stride,
             ms = h->seg_stream;
             forked = true;
         }
-        hipLaunchKernelGGL(k_fmerge, dim3((unsigned)(((cn + 7) / 8) * 16)), dim3(FM_NT), lds, ms, h->d_broots, h->d_tile_count, h->d_ring, h->ring_len,
+        hipLaunchKernelGGL(k_fmerge, dim3((unsigned)(((cn + 7) / 8) * 16 * bands)), dim3(FM_NT), lds, ms, h->d_broots, h->d_tile_count, h->d_ring, h->ring_len,
                            h->d_groot, h->d_gsize, h->d_gscratch, h->npix, h->qw, h->qh, h->tiles_x, h->tiles_y, f0, f1, h->cfg.min_component_px, cap,
-                           fm_stop);
+                           fm_stop, band_rows, bands > 1 ? h->d_xband : nullptr);
+        if (bands > 1 && fm_stop >= 99) {
+            hipLaunchKernelGGL(k_fseam, dim3((unsigned)cn), dim3(FM_NT), 0, ms, h->d_ring, h->ring_len, h->d_groot, h->d_gsize, h->d_xband, h->qw, h->tiles_x,
+                               h->tiles_y, band_rows, f0, f1);
+            hipLaunchKernelGGL(k_fapply, dim3((unsigned)((h->broot_cap + NT - 1) / NT), (unsigned)cn), dim3(NT), 0, ms, h->d_tile_count, h->d_groot,
+                               h->d_gsize, h->d_xband, tiles, f0);
+        }
     }
     if (forked) {
         CK_HIP(hipEventRecord(h->ev_seg_join, h->seg_stream));

@@ -1,6 +1,6 @@
 """Randomised parity stress of threshold + segmentation against the CPU oracle (test infrastructure: imports oracle/): random
 geometries (ragged widths / heights included), random content mixes, random min_white_black_diff / min_component_px and, through
-CK_FMERGE_CAP, every path of the merge kernel.  usage: python tests/stress_segment.py [cases] [seed]"""
+CK_FMERGE_CAP and CK_FMERGE_BAND_ROWS, every path of the merge kernels (one piece or bands of tile rows).  usage: python tests/stress_segment.py [cases] [seed]"""
 import os, sys, json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if __name__ == "__main__":   # CK_FMERGE_CAP is a knob of the diagnostics build: as a script this file runs against that library
@@ -29,9 +29,11 @@ def run(cases, seed):
         frames[:, y0:y0 + h // 2, x0:x0 + w // 2] = fb[:, y0:y0 + h // 2, x0:x0 + w // 2]   # two kinds of content side by side
         cap = int(rng.choice([16, 64, 300, 1200, 100000]))
         os.environ["CK_FMERGE_CAP"] = str(cap)
+        rows = int(rng.choice([0, 0, 1, 2, 3, 5]))   # (0: the library's own rule; else frames joined in bands of that many tile rows)
+        os.environ["CK_FMERGE_BAND_ROWS"] = str(rows)
         if os.environ.get("STRESS_LOG"):
             with open(os.environ["STRESS_LOG"], "a") as lf:
-                lf.write(json.dumps({"case": c, "w": w, "h": h, "n": n, "kinds": [str(ka), str(kb)], "cap": cap, "x0": x0, "y0": y0}) + "\n")
+                lf.write(json.dumps({"case": c, "w": w, "h": h, "n": n, "kinds": [str(ka), str(kb)], "cap": cap, "band_rows": rows, "x0": x0, "y0": y0}) + "\n")
         det = AprilTagDetector(w, h, max_batch=n)
         th = det.threshold(frames)
         labels, sizes = det.segment(frames)
@@ -41,10 +43,11 @@ def run(cases, seed):
             ok = np.array_equal(th[i], oth) and np.array_equal(labels[i], ol) and np.array_equal(sizes[i], osz)
             if not ok:
                 bad += 1
-                print(json.dumps({"case": c, "w": w, "h": h, "kinds": [str(ka), str(kb)], "cap": cap, "frame": i,
+                print(json.dumps({"case": c, "w": w, "h": h, "kinds": [str(ka), str(kb)], "cap": cap, "band_rows": rows, "frame": i,
                                   "thr_diff": int(np.count_nonzero(th[i] != oth)), "label_diff": int(np.count_nonzero(labels[i] != ol))}))
         det.close()
     print(json.dumps({"cases": cases, "mismatching_frames": bad}))
+    os.environ.pop("CK_FMERGE_BAND_ROWS", None)
     if cap_before is None:
         os.environ.pop("CK_FMERGE_CAP", None)
     else:

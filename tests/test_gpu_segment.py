@@ -87,6 +87,49 @@ def merge_path_cases():
     print("MERGE_PATHS_OK", len(MERGE_PATH_CASES))
 
 
+# (kind, width, height, CK_FMERGE_BAND_ROWS, CK_FMERGE_CAP): frames joined in bands of tile rows (k_fmerge per band, k_fseam / k_fapply across
+# them), every band height from one tile row up, ragged last bands and last tile rows, and the bands' own paths forced small
+BAND_CASES = [("noise", 640, 480, 1, 0), ("noise", 640, 480, 2, 0), ("noise", 640, 480, 7, 0), ("blobs", 640, 480, 3, 0), ("spiral", 640, 480, 1, 0),
+              ("spiral", 640, 480, 4, 0), ("checker1", 640, 480, 2, 0), ("vstripes1", 641, 450, 1, 0), ("synth", 641, 450, 5, 0), ("noise", 129, 33, 1, 0),
+              ("noise", 131, 99, 2, 0), ("noise", 640, 480, 2, 64), ("noise", 640, 480, 3, 600), ("spiral", 640, 480, 2, 64), ("stripes", 272, 200, 1, 0),
+              ("noise", 1280, 800, 6, 0), ("blobs", 1280, 800, 9, 0)]
+
+
+def band_cases():
+    """Runs in a child process against the diagnostics build (the knobs do not exist in the product library)."""
+    import os
+    import pyoracle
+    from chalkydri_amd import _lib, default_config, scenes
+    from chalkydri_amd.detector import AprilTagDetector
+    assert b"CK_FMERGE_BAND_ROWS" in open(_lib.LIB_PATH, "rb").read(), "not the diagnostics build: " + _lib.LIB_PATH
+    n = 2
+    for kind, w, h, rows, cap in BAND_CASES:
+        os.environ["CK_FMERGE_BAND_ROWS"] = str(rows)   # (both read per call)
+        os.environ["CK_FMERGE_CAP"] = str(cap)
+        frames = _frames(kind, w, h, n, 5)
+        det = AprilTagDetector(w, h, max_batch=n)
+        labels, sizes = det.segment(frames)
+        for i in range(n):
+            ol, osz = pyoracle.segment(pyoracle.threshold(frames[i]))
+            assert np.array_equal(labels[i], ol) and np.array_equal(sizes[i], osz), (kind, w, h, rows, cap, i)
+        det.close()
+    # the slot tables' sizes decide which components the later stages see: whole detections on frames joined in bands
+    os.environ["CK_FMERGE_CAP"] = "0"
+    for rows in (1, 3, 8):
+        os.environ["CK_FMERGE_BAND_ROWS"] = str(rows)
+        w, h = 1280, 800
+        frames = scenes.bench_stream(3, 2, w, h, 6)[0]
+        det = AprilTagDetector(w, h, max_batch=2)
+        dets = det.detect_batch(frames)
+        cfg = default_config(w, h)
+        for i in range(2):
+            want, _ = pyoracle.detect(frames[i], cfg)
+            assert [(d.id(), d.corners().tobytes()) for d in dets[i]] == [(d["id"], d["p"].tobytes()) for d in want], ("detections", rows, i)
+            assert len(want) > 0
+        det.close()
+    print("BAND_CASES_OK", len(BAND_CASES))
+
+
 def test_merge_paths_beyond_one_workgroups_lds(oracle):
     """A frame with more ring-touching roots than one merge workgroup's LDS holds (parents + keys) is joined by two workgroups,
     one per colour; a workgroup with still more roots keeps only the parents in LDS (up to twice the capacity), and beyond
@@ -100,6 +143,20 @@ def test_merge_paths_beyond_one_workgroups_lds(oracle):
             % (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests"), os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", code], env=diag_env(), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "MERGE_PATHS_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+def test_frames_joined_in_bands_of_tile_rows(oracle):
+    """A frame with more than 256 tiles is joined in bands of tile rows (k_fmerge per band, then k_fseam / k_fapply across the bands:
+    1920x1080 in two, 2448x2048 in six — test_large_frames_merge_per_colour runs those).  Here the band height is forced
+    (CK_FMERGE_BAND_ROWS, diagnostics build: hence the child process) on small and ragged frames, down to one tile row per band, with
+    the bands' own merge paths forced too, and whole detections are compared on frames joined that way."""
+    import os, subprocess, sys
+    from conftest import ROOT, diag_env
+    code = ("import sys; sys.path[:0] = [%r, %r, %r]; import importlib.util as u; "
+            "sp = u.spec_from_file_location('tseg', %r); m = u.module_from_spec(sp); sp.loader.exec_module(m); m.band_cases()"
+            % (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests"), os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], env=diag_env(), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "BAND_CASES_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
 
 
 @pytest.mark.parametrize("w,h", [(1920, 1080), (2448, 2048), (4092, 2200)])
