@@ -844,13 +844,32 @@ __global__ __launch_bounds__(KNT) __attribute__((amdgpu_num_sgpr(80))) void k_ti
                     const uint32_t sw8 = s2.x >> sh, sb8 = s2.y >> sh;
                     const uint32_t wt8 = m4.x >> sh, bt8 = m4.y >> sh, wb8 = b4.x >> sh, bb8 = b4.y >> sh;
                     uint32_t at[2][8];
+                    // Which entry a pixel reads — its column's white node, its black node or the one that says "no colour" — is chosen
+                    // without compares: a pixel's colour bit spread over a register (one signed bit-field extract) picks between two
+                    // values through one three-input bit operation, x ^ (mask & (x ^ y)).  (Round 4: as ?: it was a mask, a compare and
+                    // a select per level, two levels per pixel.)  A lane all of whose sixteen pixels have a colour — every lane of a
+                    // frame of dense noise — needs one level.
+                    // (as an instruction: from the shifts the compiler recognises a select and makes the compare and v_cndmask again)
+                    auto spread = [](uint32_t bits, int k) -> uint32_t { uint32_t m; __asm__("v_bfe_i32 %0, %1, %2, 1" : "=v"(m) : "v"(bits), "n"(k)); return m; };
+                    if ((any_t & any_b) == 255u) {
 #pragma unroll
-                    for (int k = 0; k < 8; k++) {
-                        const uint32_t upto = (2u << k) - 1u;
-                        const uint32_t iw = bw + (uint32_t)__popc(sw8 & upto), ib = bb + (uint32_t)__popc(sb8 & upto);
-                        // (a pixel without a colour reads the entry that says so)
-                        at[0][k] = (wt8 & (1u << k)) ? iw : ((bt8 & (1u << k)) ? ib : (uint32_t)TAB_NONE);
-                        at[1][k] = (wb8 & (1u << k)) ? iw : ((bb8 & (1u << k)) ? ib : (uint32_t)TAB_NONE);
+                        for (int k = 0; k < 8; k++) {
+                            const uint32_t upto = (2u << k) - 1u;
+                            const uint32_t iw = bw + (uint32_t)__popc(sw8 & upto), ib = bb + (uint32_t)__popc(sb8 & upto);
+                            const uint32_t x = iw ^ ib;
+                            at[0][k] = ib ^ (spread(wt8, k) & x);
+                            at[1][k] = ib ^ (spread(wb8, k) & x);
+                        }
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 8; k++) {
+                            const uint32_t upto = (2u << k) - 1u;
+                            const uint32_t iw = bw + (uint32_t)__popc(sw8 & upto), ib = bb + (uint32_t)__popc(sb8 & upto);
+                            // (a pixel without a colour reads the entry that says so; a pixel has at most one colour)
+                            const uint32_t xw = iw ^ (uint32_t)TAB_NONE, xb = ib ^ (uint32_t)TAB_NONE;
+                            at[0][k] = (uint32_t)TAB_NONE ^ (spread(wt8, k) & xw) ^ (spread(bt8, k) & xb);
+                            at[1][k] = (uint32_t)TAB_NONE ^ (spread(wb8, k) & xw) ^ (spread(bb8, k) & xb);
+                        }
                     }
                     if (edge8) { // (only the lanes at the frame's first and last column: those pixels are nodes of their own)
 #pragma unroll
@@ -1001,7 +1020,11 @@ namespace {
 // pixel, so a union hooks the root with the larger PIXEL under the other one (compare-and-swap on the root's own entry).
 constexpr int FM_NT = 1024;
 constexpr int FM_CAP = 30000;                 // roots a workgroup's LDS path holds with 16-bit pixel keys beside the parents (twice as many without)
-constexpr int FM_BAND_TILES = 256;            // a frame with more tiles is joined in bands of tile rows of at most this many tiles
+// Bands of tile rows: a frame with more than FM_BAND_MIN tiles is joined in bands of at most FM_BAND_TILES tiles.  What bands buy is the
+// PATH, not parallelism (a batch fills the chip either way): with about 48 black ring-touching roots per tile of dense noise a colour's
+// workgroup keeps parents and keys in LDS up to some 600 tiles (1920 x 1080: 510, stays in one piece: in two bands its k_fmerge took 0.66
+// against 0.75 ms per 512 frames, and the joining of the bands 0.7 on top); 2448 x 2048 (1280 tiles) ran on the parents-only path.
+constexpr int FM_BAND_MIN = 600, FM_BAND_TILES = 448;
 constexpr int FM_WQ = 384;                    // joins a wave's queue holds (one round of boundary pixels adds at most 192)
 constexpr int FM_WQS = FM_WQ + 8;             // a queue's stride in LDS: entry FM_WQ takes the joins that are none (stores without a branch)
 constexpr uint32_t NOJ = 0xFFFFFFFFu;         // "no join"
@@ -1652,79 +1675,84 @@ __device__ __forceinline__ uint32_t x_find(uint32_t *xpar, uint32_t a, bool halv
         a = g;
     }
 }
-__global__ __launch_bounds__(FM_NT) void k_fseam(const uint16_t *__restrict__ ring, size_t ring_len, uint32_t *__restrict__ groot_all,
-                                                 uint32_t *__restrict__ gsize_all, uint32_t *__restrict__ xband, int w, int tiles_x, int tiles_y,
-                                                 int band_rows, int frame0, int n_frames) {
-    const int frame = frame0 + (int)blockIdx.x, tid = threadIdx.x;
-    if (frame >= n_frames) return;
+// One thread per pixel of a band boundary's lower row (256 per workgroup: a thread's work is a chain of a dozen memory round trips,
+// so the grid is cut fine and many workgroups share a CU).  FOLD = false: the unions; FOLD = true, a launch later: every band root
+// that took part hands its smallest pixel and its pixel count to its final root.  A join the pixel on the left (or, for up-right,
+// the pixel on the right) makes as its own vertical join is left to it: along a run of one component over one component only the
+// run's ends join.
+template <bool FOLD>
+__global__ __launch_bounds__(NT) void k_fseam(const uint16_t *__restrict__ ring, size_t ring_len, uint32_t *__restrict__ groot_all,
+                                              uint32_t *__restrict__ gsize_all, uint32_t *__restrict__ xband, int w, int tiles_x, int tiles_y,
+                                              int band_rows, int frame0) {
+    const int frame = frame0 + (int)blockIdx.y;
+    const int item = (int)blockIdx.x * NT + (int)threadIdx.x;
+    const int bands = (tiles_y + band_rows - 1) / band_rows;
+    if (item >= (bands - 1) * w) return;
     const size_t slots = (size_t)tiles_x * tiles_y * RING_CAP;
     uint32_t *groot = groot_all + (size_t)frame * slots, *gsize = gsize_all + (size_t)frame * slots;
     const uint32_t *bslot = xband + (size_t)frame * 2 * slots;
     uint32_t *xpar = xband + (size_t)frame * 2 * slots + slots;
     const uint16_t *HT = ring + (size_t)frame * ring_len, *HB = HT + (size_t)tiles_y * w;
-    const int bands = (tiles_y + band_rows - 1) / band_rows;
-    const int items = (bands - 1) * w;
-#pragma unroll 1
-    for (int pass = 0; pass < 2; pass++) {
-#pragma unroll 1
-        for (int item = tid; item < items; item += FM_NT) {
-            const int b = item / w + 1, x = item - (b - 1) * w, ty = b * band_rows;
-            if (x < 1 || x > w - 2) continue; // only origin columns join
-            const uint16_t *lo = HT + (size_t)ty * w, *up = HB + (size_t)(ty - 1) * w;
-            const uint32_t p = lo[x];
-            if (p == 0xFFFFu) continue;
-            const uint32_t q[3] = {up[x], up[x - 1], up[x + 1]};
-            const bool pw = (p & 0x8000u) != 0;
-            const uint32_t A = bslot[(size_t)(ty * tiles_x + (x >> 7)) * RING_CAP + (p & 0x7FFFu)];
-            bool a_claimed = false;
+    const int b = item / w + 1, x = item - (b - 1) * w, ty = b * band_rows;
+    if (x < 1 || x > w - 2) return; // only origin columns join
+    const uint16_t *lo = HT + (size_t)ty * w, *up = HB + (size_t)(ty - 1) * w;
+    const uint32_t p = lo[x];
+    if (p == 0xFFFFu) return;
+    const uint32_t q[3] = {up[x], up[x - 1], up[x + 1]};
+    const bool pw = (p & 0x8000u) != 0;
+    // (ring entries are tile-local ids: comparable inside one tile column only)
+    const bool run_l = x - 1 >= 1 && (x & (TW - 1)) != 0 && lo[x - 1] == p, run_r = x + 1 <= w - 2 && ((x + 1) & (TW - 1)) != 0 && lo[x + 1] == p;
+    const bool dup[3] = {run_l && q[1] == q[0], run_l, run_r};
+    const uint32_t A = bslot[(size_t)(ty * tiles_x + (x >> 7)) * RING_CAP + (p & 0x7FFFu)];
+    bool a_done = false;
 #pragma unroll
-            for (int k = 0; k < 3; k++) {
-                const int xq = k == 0 ? x : (k == 1 ? x - 1 : x + 1);
-                const bool v = q[k] != 0xFFFFu && (k == 0 ? ((q[k] ^ p) & 0x8000u) == 0 : (pw && (q[k] & 0x8000u) != 0));
-                if (!v) continue;
-                const uint32_t B = bslot[(size_t)((ty - 1) * tiles_x + (xq >> 7)) * RING_CAP + (q[k] & 0x7FFFu)];
-                if (pass == 0) { // union: the band root with the larger slot number goes under the other
-                    uint32_t a = A, c = B;
-                    for (;;) {
-                        a = x_find(xpar, a, true); c = x_find(xpar, c, true);
-                        if (a == c) break;
-                        const uint32_t hi = a > c ? a : c, lw = a > c ? c : a;
-                        if (atomicCAS(&xpar[hi], hi, lw) == hi) break;
-                    }
-                } else { // fold: every band root that took part, once
-                    for (int e = a_claimed ? 1 : 0; e < 2; e++) {
-                        const uint32_t P = e ? B : A;
-                        if (atomicOr(&xpar[P], XCLAIM) & XCLAIM) continue;
-                        const uint32_t R = x_find(xpar, P, false);
-                        if (R == P) continue;
-                        atomicMin(&groot[R], gm_load(groot, P));
-                        atomicAdd(&gsize[R], gm_load(gsize, P));
-                    }
-                    a_claimed = true;
-                }
+    for (int k = 0; k < 3; k++) {
+        const int xq = k == 0 ? x : (k == 1 ? x - 1 : x + 1);
+        const bool v = q[k] != 0xFFFFu && (k == 0 ? ((q[k] ^ p) & 0x8000u) == 0 : (pw && (q[k] & 0x8000u) != 0));
+        if (!v || dup[k]) continue;
+        const uint32_t B = bslot[(size_t)((ty - 1) * tiles_x + (xq >> 7)) * RING_CAP + (q[k] & 0x7FFFu)];
+        if (!FOLD) { // union: the band root with the larger slot number goes under the other
+            uint32_t a = A, c = B;
+            for (;;) {
+                a = x_find(xpar, a, true); c = x_find(xpar, c, true);
+                if (a == c) break;
+                const uint32_t hi = a > c ? a : c, lw = a > c ? c : a;
+                if (atomicCAS(&xpar[hi], hi, lw) == hi) break;
             }
+        } else { // fold: every band root that took part, once (the claim bit)
+            for (int e = a_done ? 1 : 0; e < 2; e++) {
+                const uint32_t P = e ? B : A;
+                if (gm_load(xpar, P) & XCLAIM) continue;
+                if (atomicOr(&xpar[P], XCLAIM) & XCLAIM) continue;
+                const uint32_t R = x_find(xpar, P, false);
+                if (R == P) continue;
+                atomicMin(&groot[R], groot[P]);
+                atomicAdd(&gsize[R], gsize[P]);
+            }
+            a_done = true;
         }
-        __threadfence();
-        __syncthreads();
     }
 }
+// one wave per tile: its ring-touching components' slots (white ids from 0 up, black ones from RING_CAP - 1 down)
 __global__ __launch_bounds__(NT) void k_fapply(const uint32_t *__restrict__ tile_count, uint32_t *__restrict__ groot_all, uint32_t *__restrict__ gsize_all,
                                                const uint32_t *__restrict__ xband, int tiles, int frame0) {
     const int frame = frame0 + (int)blockIdx.y;
-    const uint32_t s = blockIdx.x * NT + threadIdx.x;
+    const int t = (int)blockIdx.x * (NT / 64) + (int)(threadIdx.x >> 6);
+    if (t >= tiles) return;
     const size_t slots = (size_t)tiles * RING_CAP;
-    if (s >= slots) return;
-    const uint32_t t = s / RING_CAP, id = s - t * RING_CAP;
-    const uint32_t tc = tile_count[(size_t)frame * tiles + t]; // white | black << 16: white ids from 0 up, black ones from RING_CAP - 1 down
-    if (!(id < (tc & 0xFFFFu) || id >= (uint32_t)RING_CAP - (tc >> 16))) return;
+    const uint32_t tc = tile_count[(size_t)frame * tiles + t]; // white | black << 16
+    const uint32_t nw = tc & 0xFFFFu, cnt = nw + (tc >> 16);
     const uint32_t *bslot = xband + (size_t)frame * 2 * slots, *xpar = bslot + slots;
     uint32_t *groot = groot_all + (size_t)frame * slots, *gsize = gsize_all + (size_t)frame * slots;
-    uint32_t R = bslot[s];
-    if (xpar[R] == R) return; // its band root took part in no join across a band boundary (no claim bit): the band's values are final
-    for (;;) { const uint32_t n = xpar[R] & ~XCLAIM; if (n == R) break; R = n; }
-    if (R == s) return; // the final root holds its values already
-    groot[s] = groot[R];
-    gsize[s] = gsize[R];
+    for (uint32_t l = threadIdx.x & 63u; l < cnt; l += 64u) {
+        const uint32_t s = (uint32_t)t * (uint32_t)RING_CAP + (l < nw ? l : (uint32_t)(RING_CAP - 1) - (l - nw));
+        uint32_t R = bslot[s];
+        if (xpar[R] == R) continue; // its band root took part in no join across a band boundary (no claim bit): the band's values are final
+        for (;;) { const uint32_t n = xpar[R] & ~XCLAIM; if (n == R) break; R = n; }
+        if (R == s) continue; // the final root holds its values already
+        groot[s] = groot[R];
+        gsize[s] = gsize[R];
+    }
 }
 
 // ---- parity / test path: canonical labels and exact sizes ---------------------------------------------------------------------
@@ -1787,13 +1815,14 @@ int ck_launch_threshold_segment(ck_handle *h, const uint8_t *frames, int stride,
     // roots the LDS path of one workgroup holds (dense binary noise has about 90 per tile).  A frame whose roots fit is joined by ONE
     // workgroup, both colours in one sweep; a larger one by two, one per colour (1920 x 1080 of dense noise: 23 000 each); a
     // workgroup with more takes the global-memory path.
-    // Bands of tile rows (round 4): a frame with more than FM_BAND_TILES tiles is joined band by band (k_fmerge), then across the
-    // bands (k_fseam, k_fapply) — every band then runs the keyed LDS path of a 1280 x 800 frame (250 tiles), several bands of a
-    // frame at a time on different CUs.  2448 x 2048 (1280 tiles, six bands of 11 tile rows): k_fmerge 1.9 ms per 256 frames in one
-    // piece per colour.  CK_FMERGE_BAND_ROWS (diagnostics build, read per call) forces the band height: the path-forcing tests.
+    // Bands of tile rows (round 4): a frame with more than FM_BAND_MIN tiles is joined band by band (k_fmerge), then across the
+    // bands (k_fseam twice, k_fapply) — every band's roots then fit the keyed LDS path.  2448 x 2048 (1280 tiles, three bands of 22
+    // tile rows), per 256 frames: k_fmerge 0.93 + k_fseam 0.15 + k_fapply 0.18 ms against 2.4 in one piece per colour (parents only
+    // in LDS, sizes and smallest pixels by atomics in global memory).  CK_FMERGE_BAND_ROWS (diagnostics build, read per call) forces
+    // the band height: the path-forcing tests.
     const int band_env = CK_KNOB("CK_FMERGE_BAND_ROWS", 0);
     int band_rows = h->tiles_y;
-    if (tiles > FM_BAND_TILES) {
+    if (tiles > FM_BAND_MIN) {
         const int rows = FM_BAND_TILES / h->tiles_x > 0 ? FM_BAND_TILES / h->tiles_x : 1, nb = (h->tiles_y + rows - 1) / rows;
         band_rows = (h->tiles_y + nb - 1) / nb; // bands of equal height
     }
@@ -1837,9 +1866,10 @@ int ck_launch_threshold_segment(ck_handle *h, const uint8_t *frames, int stride,
                            h->d_groot, h->d_gsize, h->d_gscratch, h->npix, h->qw, h->qh, h->tiles_x, h->tiles_y, f0, f1, h->cfg.min_component_px, cap,
                            fm_stop, band_rows, bands > 1 ? h->d_xband : nullptr);
         if (bands > 1 && fm_stop >= 99) {
-            hipLaunchKernelGGL(k_fseam, dim3((unsigned)cn), dim3(FM_NT), 0, ms, h->d_ring, h->ring_len, h->d_groot, h->d_gsize, h->d_xband, h->qw, h->tiles_x,
-                               h->tiles_y, band_rows, f0, f1);
-            hipLaunchKernelGGL(k_fapply, dim3((unsigned)((h->broot_cap + NT - 1) / NT), (unsigned)cn), dim3(NT), 0, ms, h->d_tile_count, h->d_groot,
+            const dim3 sg((unsigned)(((bands - 1) * h->qw + NT - 1) / NT), (unsigned)cn);
+            hipLaunchKernelGGL(k_fseam<false>, sg, dim3(NT), 0, ms, h->d_ring, h->ring_len, h->d_groot, h->d_gsize, h->d_xband, h->qw, h->tiles_x, h->tiles_y, band_rows, f0);
+            hipLaunchKernelGGL(k_fseam<true>, sg, dim3(NT), 0, ms, h->d_ring, h->ring_len, h->d_groot, h->d_gsize, h->d_xband, h->qw, h->tiles_x, h->tiles_y, band_rows, f0);
+            hipLaunchKernelGGL(k_fapply, dim3((unsigned)((tiles + NT / 64 - 1) / (NT / 64)), (unsigned)cn), dim3(NT), 0, ms, h->d_tile_count, h->d_groot,
                                h->d_gsize, h->d_xband, tiles, f0);
         }
     }

@@ -146,8 +146,8 @@ def test_merge_paths_beyond_one_workgroups_lds(oracle):
 
 
 def test_frames_joined_in_bands_of_tile_rows(oracle):
-    """A frame with more than 256 tiles is joined in bands of tile rows (k_fmerge per band, then k_fseam / k_fapply across the bands:
-    1920x1080 in two, 2448x2048 in six — test_large_frames_merge_per_colour runs those).  Here the band height is forced
+    """A frame with more than 600 tiles is joined in bands of tile rows (k_fmerge per band, then k_fseam / k_fapply across the bands:
+    2448x2048 in three, 4092x2200 in five — test_large_frames_merge_per_colour runs those).  Here the band height is forced
     (CK_FMERGE_BAND_ROWS, diagnostics build: hence the child process) on small and ragged frames, down to one tile row per band, with
     the bands' own merge paths forced too, and whole detections are compared on frames joined that way."""
     import os, subprocess, sys
