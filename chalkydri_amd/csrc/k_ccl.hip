@@ -97,15 +97,19 @@ static_assert(TH * TW <= CK_COUNT, "a component's pixel count fits below the fla
 // Two halving finds walked in lockstep: both chains have a read in flight at every step
 // (plain loads behind compiler barriers, not volatile ones: a volatile read is waited for before the next is issued, which
 // would put the two chains' reads one after the other).  A root is an entry with CK_ROOT set.
+// The byte offset of u16 entry i as i + i: the shift the compiler makes of `p[i]` is one of the vector instructions a SIMD takes
+// 4.2 clocks for, an add 2.6 (tools/probes/valu_rate_probe.hip) — and the chains of the union-find are walked entry by entry.
+__device__ __forceinline__ uint32_t twice(uint32_t i) { uint32_t r; __asm__("v_add_u32 %0, %1, %1" : "=v"(r) : "v"(i)); return r; }
+__device__ __forceinline__ uint32_t u16_at(const uint16_t *p, uint32_t i) { return *reinterpret_cast<const uint16_t *>(reinterpret_cast<const uint8_t *>(p) + twice(i)); }
 __device__ __forceinline__ void lds_find2(uint16_t *p, uint32_t &a, uint32_t &b) {
     for (;;) {
         __asm__ volatile("" ::: "memory");
-        const uint32_t na = p[a], nb = p[b];
+        const uint32_t na = u16_at(p, a), nb = u16_at(p, b);
         const bool da = (na & CK_ROOT) != 0, db = (nb & CK_ROOT) != 0;
         if (da && db) return;
         const uint32_t ia = da ? a : na, ib = db ? b : nb; // the parents (or the roots themselves)
         __asm__ volatile("" ::: "memory");
-        const uint32_t ga = p[ia], gb = p[ib];
+        const uint32_t ga = u16_at(p, ia), gb = u16_at(p, ib);
         if (!da) { if (!(ga & CK_ROOT)) { p[a] = (uint16_t)ga; a = ga; } else a = ia; }
         if (!db) { if (!(gb & CK_ROOT)) { p[b] = (uint16_t)gb; b = gb; } else b = ib; }
     }
@@ -675,7 +679,7 @@ __global__ __launch_bounds__(KNT) __attribute__((amdgpu_num_sgpr(80))) void k_ti
         }
         for (int it = 0; it < TH * TW; it++) { // plain loads behind a compiler barrier: the two reads of a step go out together
             __asm__ volatile("" ::: "memory");
-            const uint32_t n0 = parent[root[0]], n1 = parent[root[1]];
+            const uint32_t n0 = u16_at(parent, root[0]), n1 = u16_at(parent, root[1]);
             const bool d0 = (n0 & CK_ROOT) != 0, d1 = (n1 & CK_ROOT) != 0;
             if (d0 && d1) break;
             root[0] = d0 ? root[0] : n0; root[1] = d1 ? root[1] : n1;
