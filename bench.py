@@ -357,7 +357,7 @@ def main():
                          "launch_ms_p10_median_p90": [round(float(np.percentile(thr_ms, q)), 4) for q in (10, 50, 90)]},
             "stage_ms_last_step": {k: round(v, 3) for k, v in stage.items()},
         }
-        if world == 1:
+        if world == 1 and not args.no_extras:   # (--no-extras: the profiled runs, whose kernel averages must be over whole-batch launches only)
             # "Gradient extraction (next stage) = 5 B/px read (label + thresh) + compacted output, reported separately":
             # the clusters stage (k_emit -> k_scan -> k_scatter: boundary points between adjacent black / white components, keyed by the
             # component pair, compacted per cluster).  Algorithmic bytes = 5 per pixel read + 4 bytes per point written, read and

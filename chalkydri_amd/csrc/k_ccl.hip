@@ -510,7 +510,10 @@ __global__ __launch_bounds__(KNT) __attribute__((amdgpu_num_sgpr(80))) void k_ti
         // the diagonal ones to the second): the loop runs to HALF the busiest word's node count.
         // (Round 4, with the roles rotating: one wave per colour walking ALL of a word's nodes and links while the other two skip the
         // phase — 550 fewer wave-instructions per workgroup — measured 3.6 % SLOWER, 0.990 against 0.955 ms: the longer chain of the
-        // two working waves costs more than the duplicated mask work.)
+        // two working waves costs more than the duplicated mask work.  And at the round's end: the first wave of a colour forming the masks
+        // alone and handing the second its first links, diagonal masks and list offset through four words per pair word in the middle of
+        // the list array, behind one more barrier — 2/5 of the phase's instructions once per pair word instead of twice — measured
+        // 0.7 % slower, 0.8713 against 0.8655 ms: tools/wip/p4_prolog_handoff.patch.)
         const int c = __builtin_amdgcn_readfirstlane((tid >> 6) & 1), half = __builtin_amdgcn_readfirstlane(tid >> 7);
         const bool white = c == 0, has_l = wd > 0, has_u = p > 0, has_r = wd < NWD - 1;
         const int mi = ((2 * p) * NWD + wd) * 2 + c;

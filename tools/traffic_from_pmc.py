@@ -11,17 +11,21 @@ KERNELS = ("k_tile", "k_fmerge")
 
 
 def per_launch(d, counter):
-    tot, launches = 0.0, 0
+    """Bytes of the threshold+segment kernels per BATCH launch.  bench.py also makes one small call (8 frames: the point count behind
+    its `gradient` line), whose k_tile / k_fmerge dispatches must neither add bytes nor count as launches: only dispatches with the
+    largest grid of their kernel are taken."""
+    rows = []
     for p in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         for row in csv.DictReader(open(p)):
             if row["Counter_Name"] != counter:
                 continue
-            name = row["Kernel_Name"]
-            m = re.search(r"::(k_[a-z_]+)", name)
+            m = re.search(r"::(k_[a-z_]+)", row["Kernel_Name"])
             base = m.group(1) if m else ""
             if base in KERNELS:
-                tot += float(row["Counter_Value"]) * 1024.0
-                launches += base == "k_tile"
+                rows.append((base, int(row["Grid_Size"]), float(row["Counter_Value"]) * 1024.0))
+    full = {k: max((g for b, g, _ in rows if b == k), default=0) for k in KERNELS}
+    tot = sum(v for b, g, v in rows if g == full[b])
+    launches = sum(1 for b, g, _ in rows if b == "k_tile" and g == full[b])
     if launches == 0:
         raise SystemExit(f"no {counter} rows for {KERNELS} under {d}")
     return tot / launches, launches
