@@ -51,6 +51,9 @@ __device__ int homography_compute(const double corr[4][4], double *H, double *A)
     H[8] = 1.0;
     return 1;
 }
+// (Round 4: the same elimination spread over the lanes of the wave — every element update of a step by the lane that owns the element,
+// pivot by ballot, the back substitution's sums in index order from the lanes' products — returned the same bits and measured SLOWER,
+// 0.293 against 0.280 ms per 256 frames: eight steps of barriers and broadcasts cost more than one lane's walk through LDS.)
 __device__ __forceinline__ void hproject(const double *H, double x, double y, double *ox, double *oy) {
     double xx = H[0] * x + H[1] * y + H[2];
     double yy = H[3] * x + H[4] * y + H[5];
@@ -75,14 +78,15 @@ __device__ __forceinline__ unsigned long long code_rotate90(unsigned long long w
     return w;
 }
 
-// one wave per (frame, quad); loops over families
+// one wave per (frame, quad); loops over families.  (Round 4: about 115 of a frame's 1024 quad slots are in use on the bench batch, and
+// the kernel's time is the live quads' chains of dependent steps, some 50 us each at four waves per SIMD — not the dispatch of the
+// idle workgroups: a grid of 128 / 256 / 512 workgroups per frame looping over the quads measured 0.39-0.40 against 0.33 ms, five
+// waves per SIMD at 96 registers 0.32 against 0.29.)
 __global__ __launch_bounds__(64) void k_decode(DecodeArgs a) {
     __shared__ double sH[9], sA[72], sSamp[128][3];
     __shared__ double sC[2][3];      // gray models: [0] white, [1] black
     __shared__ double sVal[256], sSharp[256];
     __shared__ int sOk;
-    __shared__ unsigned long long sCode;
-    __shared__ double sMargin;
     const int lane = threadIdx.x, frame = blockIdx.y, qi = blockIdx.x;
     const ck_stage_ws &ws = a.ws;
     const uint32_t nq = min(ws.d_counters[(size_t)frame * CK_CNT_STRIDE + CK_CNT_QUADS], (uint32_t)ws.quad_cap);
@@ -193,37 +197,51 @@ __global__ __launch_bounds__(64) void k_decode(DecodeArgs a) {
         __syncthreads();
         for (int i = lane; i < tw * tw; i += 64) sVal[i] = sVal[i] + a.sharpening * sSharp[i];
         __syncthreads();
-        if (lane == 0) {
-            unsigned long long rcode = 0;
+        // The code word and the two scores are sums in bit order (the oracle's): lane i brings bit i's value (its cell of the
+        // sharpened grid; nbits <= 64), every lane adds them up in that order from the lanes' registers — as one lane's loop over the
+        // family's bit tables in global memory and the grid in LDS this was a chain of 36 memory round trips.
+        unsigned long long rcode = 0;
+        double margin;
+        {
+            double myv = 0.0;
+            if ((uint32_t)lane < fam.nbits) myv = sVal[((int)fam.bit_y[lane] - min_coord) * tw + (int)fam.bit_x[lane] - min_coord];
             double black_score = 0, white_score = 0, black_cnt = 1, white_cnt = 1;
             for (uint32_t i = 0; i < fam.nbits; i++) {
-                int bx = (int)fam.bit_x[i], by = (int)fam.bit_y[i];
+                const double v = __shfl(myv, (int)i, 64);
                 rcode <<= 1;
-                double v = sVal[(by - min_coord) * tw + bx - min_coord];
                 if (v > 0) { white_score += v; white_cnt += 1; rcode |= 1; }
                 else { black_score -= v; black_cnt += 1; }
             }
-            double ma = white_score / white_cnt, mb = black_score / black_cnt;
-            sCode = rcode; sMargin = ma < mb ? ma : mb;
+            const double ma = white_score / white_cnt, mb = black_score / black_cnt;
+            margin = ma < mb ? ma : mb;
         }
-        __syncthreads();
-        // codebook search: minimum (hamming, rotation, id)
+        // codebook search: minimum (hamming, rotation, id).  A lane's codes of a pass are asked for together and meet all four
+        // rotations of the code word in registers (one memory round trip per pass of 64 x DEC_CPL codes, not one per code and rotation).
         uint32_t bestkey = 0xFFFFFFFFu;
         {
-            unsigned long long rc = sCode;
-            for (int rot = 0; rot < 4; rot++) {
-                for (uint32_t k = lane; k < fam.ncodes; k += 64) {
-                    uint32_t hd = (uint32_t)__popcll(rc ^ fam.codes[k]);
-                    uint32_t key = (hd << 24) | ((uint32_t)rot << 20) | k;
-                    bestkey = min(bestkey, key);
-                }
-                rc = code_rotate90(rc, (int)fam.nbits);
+            unsigned long long rc4[4];
+            rc4[0] = rcode;
+#pragma unroll
+            for (int rot = 1; rot < 4; rot++) rc4[rot] = code_rotate90(rc4[rot - 1], (int)fam.nbits);
+            constexpr int DEC_CPL = 12;
+            for (uint32_t k0 = 0; k0 < fam.ncodes; k0 += 64u * DEC_CPL) {
+                unsigned long long cw[DEC_CPL];
+#pragma unroll
+                for (int j = 0; j < DEC_CPL; j++) { const uint32_t k = k0 + (uint32_t)lane + 64u * j; cw[j] = k < fam.ncodes ? fam.codes[k] : 0ull; }
+#pragma unroll
+                for (int rot = 0; rot < 4; rot++)
+#pragma unroll
+                    for (int j = 0; j < DEC_CPL; j++) {
+                        const uint32_t k = k0 + (uint32_t)lane + 64u * j;
+                        const uint32_t hd = (uint32_t)__popcll(rc4[rot] ^ cw[j]);
+                        const uint32_t key = (hd << 24) | ((uint32_t)rot << 20) | k;
+                        bestkey = min(bestkey, k < fam.ncodes ? key : 0xFFFFFFFFu);
+                    }
             }
 #pragma unroll
             for (int d = 32; d >= 1; d >>= 1) bestkey = min(bestkey, (uint32_t)__shfl_xor((int)bestkey, d, 64));
         }
         const int hd = (int)(bestkey >> 24), rot = (int)((bestkey >> 20) & 3), id = (int)(bestkey & 0xFFFFFu);
-        const double margin = sMargin;
         if (hd > a.max_hamming) continue;
         if (!(margin >= 0)) continue;
         if (lane == 0) {
