@@ -121,7 +121,6 @@ extern "C" int ck_create(const ck_config_t *cfg, ck_handle_t **out) {
     CK_TRY(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
     CK_TRY(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
     CK_TRY(hipEventCreateWithFlags(&h->ev_fit_fork, hipEventDisableTiming));
-    CK_TRY(hipEventCreateWithFlags(&h->ev_wimg, hipEventDisableTiming));
     for (auto &st : h->fit_stream) CK_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
     CK_TRY(hipStreamCreateWithFlags(&h->seg_stream, hipStreamNonBlocking));
     for (auto &e : h->ev_seg) CK_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -159,7 +158,6 @@ extern "C" void ck_destroy(ck_handle_t *h) {
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     if (h->ev_fit_fork) (void)hipEventDestroy(h->ev_fit_fork);
-    if (h->ev_wimg) (void)hipEventDestroy(h->ev_wimg);
     for (auto &e : h->ev_fit_join) if (e) (void)hipEventDestroy(e);
     for (auto &e : h->ev_seg) if (e) (void)hipEventDestroy(e);
     if (h->ev_seg_join) (void)hipEventDestroy(h->ev_seg_join);

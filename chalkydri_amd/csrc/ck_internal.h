@@ -164,8 +164,6 @@ struct ck_handle {
     hipStream_t seg_stream;
     hipEvent_t ev_seg[CK_SEG_CHUNKS_MAX], ev_seg_join;
     hipEvent_t ev_fit_fork, ev_fit_join[CK_FIT_SIDE_STREAMS];
-    hipEvent_t ev_wimg;       // the clusters stage's scan is done: the quad fit's weight image may start beside k_scatter (fit_stream[1])
-    bool wimg_early;          // ... and did, for the call at hand: ck_launch_fit_quads does not launch it again
     int w, h;            // full-resolution frame
     int qw, qh;          // geometry of the image the quad stages run on (w/decimate)
     int tiles_x, tiles_y;
@@ -269,10 +267,7 @@ int ck_stage_device_frames(ck_handle *h, const uint8_t *d_frames, int n, int str
                            int *use_stride, size_t *use_pitch);
 int ck_run_threshold_segment(ck_handle *h, const uint8_t *frames, int stride, size_t pitch, int n);
 // gradient clusters from thresh/labels/csize of frames [0,n)
-// (qframes != nullptr: the split quad fit follows and wants its weight image started beside k_scatter — ck_wimg_early_wanted)
-int ck_launch_clusters(ck_handle *h, int n, const uint8_t *qframes = nullptr, int qstride = 0, size_t qpitch = 0);
-bool ck_wimg_early_wanted(const ck_handle *h, int n);                                                     // k_quads.hip
-void ck_launch_weight_image(ck_handle *h, hipStream_t st, const uint8_t *qframes, int qstride, size_t qpitch, int n); // k_quads.hip
+int ck_launch_clusters(ck_handle *h, int n);
 // quad fit (+ edge refinement) of every cluster; qframes = image the clusters came from, frames = full resolution
 int ck_launch_fit_quads(ck_handle *h, const uint8_t *qframes, int qstride, size_t qpitch, const uint8_t *frames, int stride,
                         size_t pitch, int n);

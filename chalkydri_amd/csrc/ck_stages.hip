@@ -161,13 +161,12 @@ static ck_handle make_view(const ck_handle *h, int f0, bool second_stream = true
 // clusters -> quad fit -> decode of n frames on h->stream
 static int run_tail(ck_handle *h, const uint8_t *frames, int stride, size_t pitch, int n, int upto, bool events) {
     hipEvent_t *ev = h->ev;
-    const uint8_t *q = frames; int qs = stride; size_t qp = pitch;
-    if (h->cfg.quad_decimate > 1) { q = h->d_qframes; qs = (h->qw + 15) / 16 * 16; qp = (size_t)qs * h->qh; }
-    h->wimg_early = upto >= 2 && ck_wimg_early_wanted(h, n);
-    int rc = h->wimg_early ? ck_launch_clusters(h, n, q, qs, qp) : ck_launch_clusters(h, n);
+    int rc = ck_launch_clusters(h, n);
     if (rc != CK_OK) return rc;
     if (events) CK_HIP(hipEventRecord(ev[3], h->stream));
     if (upto >= 2) {
+        const uint8_t *q = frames; int qs = stride; size_t qp = pitch;
+        if (h->cfg.quad_decimate > 1) { q = h->d_qframes; qs = (h->qw + 15) / 16 * 16; qp = (size_t)qs * h->qh; }
         rc = ck_launch_fit_quads(h, q, qs, qp, frames, stride, pitch, n);
         if (rc != CK_OK) return rc;
     }

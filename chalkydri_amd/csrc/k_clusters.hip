@@ -691,7 +691,7 @@ __global__ __launch_bounds__(NT) void k_scatter(ck_stage_ws ws) {
 
 } // namespace
 
-int ck_launch_clusters(ck_handle *h, int n, const uint8_t *qframes, int qstride, size_t qpitch) {
+int ck_launch_clusters(ck_handle *h, int n) {
     ck_stage_ws &ws = h->ws;
     {   // one launch clears everything the rest of the call counts into: the frames' key / count tables and counters, the fit's
         // list counts and dequeue heads, the decode candidates' counts (five fills before; their launches were a twentieth of
@@ -718,12 +718,6 @@ int ck_launch_clusters(ck_handle *h, int n, const uint8_t *qframes, int qstride,
     }
     int min_cluster = h->cfg.min_cluster_pixels < 24 ? 24 : h->cfg.min_cluster_pixels;
     hipLaunchKernelGGL(k_scan, dim3((unsigned)n), dim3(SNT), 0, h->stream, ws, min_cluster, ws.max_cluster_points);
-    if (qframes) { // the quad fit's weight image — a streaming kernel that needs the frames only — beside k_scatter, which moves its points in
-                   // 64-128-byte pieces at 3 of the 8 TB/s and issues few instructions (beside k_emit it had cost more than it hid, §7)
-        CK_HIP(hipEventRecord(h->ev_wimg, h->stream));
-        CK_HIP(hipStreamWaitEvent(h->fit_stream[1], h->ev_wimg, 0));
-        ck_launch_weight_image(h, h->fit_stream[1], qframes, qstride, qpitch, n);
-    }
     if (n <= 4) hipLaunchKernelGGL(k_scatter<8>, dim3(256u, (unsigned)n), dim3(NT), 0, h->stream, ws);
     else {
         static const unsigned sc_wgs = (unsigned)CK_KNOB("CK_SCATTER_WGS", 32); // (diagnostics: workgroups per frame)

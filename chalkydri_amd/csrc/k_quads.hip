@@ -2402,27 +2402,6 @@ extern "C" int ck_fit_profile_read(unsigned long long *out, int reset) {
 }
 #endif
 
-// Which calls run the split fit with the weight image on the second side stream (ck_launch_fit_quads below): those may start it a stage
-// earlier, beside k_scatter (ck_launch_clusters) — CK_WIMG_EARLY=0 (diagnostics build) keeps it beside k_seq.
-static bool split_fit_with_wimg_aside(const ck_handle *h, int n) {
-    static const int flat_env0 = CK_KNOB("CK_FIT_FLAT", 1);
-    static const int wimg_aside_env = CK_KNOB("CK_FIT_WIMG_ASIDE", 1);
-    static const int tails_aside_ok0 = CK_KNOB("CK_FIT_TAILS_ASIDE", 1) && ck_streams_wanted() < 2;
-    static const int force_par = CK_KNOB("CK_FIT_PAR", 0);
-    const bool side_by_side = n <= (h->cfg.quad_decimate > 1 ? 2 * CK_FIT_PARALLEL_MAX_FRAMES : CK_FIT_PARALLEL_MAX_FRAMES) || force_par;
-    const bool flat0 = flat_env0 >= 2 || (flat_env0 == 1 && !side_by_side && (size_t)n * (size_t)h->qw * (size_t)h->qh >= ((size_t)100 << 20));
-    return flat0 && !side_by_side && tails_aside_ok0 && wimg_aside_env;
-}
-bool ck_wimg_early_wanted(const ck_handle *h, int n) {
-    static const int early = CK_KNOB("CK_WIMG_EARLY", 1);
-    return early && split_fit_with_wimg_aside(h, n);
-}
-void ck_launch_weight_image(ck_handle *h, hipStream_t st, const uint8_t *qframes, int qstride, size_t qpitch, int n) {
-    const int w4 = (h->qw + 3) / 4;
-    hipLaunchKernelGGL(k_weight_image, dim3((unsigned)((w4 + 63) / 64), (unsigned)((h->qh + 3) / 4), (unsigned)n), dim3(256), 0, st, qframes,
-                       qpitch, qstride, h->qw, h->qh, h->ws.d_wimg);
-}
-
 int ck_launch_fit_quads(ck_handle *h, const uint8_t *qframes, int qstride, size_t qpitch, const uint8_t *frames, int stride,
                         size_t pitch, int n) {
     ck_stage_ws &ws = h->ws;
@@ -2495,7 +2474,7 @@ int ck_launch_fit_quads(ck_handle *h, const uint8_t *qframes, int qstride, size_
     if (side_by_side || tails_aside) {
         CK_HIP(hipEventRecord(h->ev_fit_fork, h->stream));
         for (int k = 0; k < CK_FIT_SIDE_STREAMS; k++) CK_HIP(hipStreamWaitEvent(h->fit_stream[k], h->ev_fit_fork, 0));
-        if (wimg_aside && !h->wimg_early) launch_wimg(h->fit_stream[1]); // (joined with the side streams before k_chunk; `wimg_early`: it already runs there, started beside k_scatter)
+        if (wimg_aside) launch_wimg(h->fit_stream[1]); // (joined with the side streams before k_chunk)
     }
     static const int gk_env = CK_KNOB("CK_FIT_GK", 0); // (experiment: bit c set = class c keeps its keys in global memory: small LDS, more workgroups per CU)
     const int gk_mask = ws.d_hscratch ? gk_env : 0;
