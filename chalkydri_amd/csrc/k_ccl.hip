@@ -1815,7 +1815,8 @@ int ck_launch_threshold_segment(ck_handle *h, const uint8_t *frames, int stride,
     // bench batch (1280 x 800 x 256, same box): 1.07 ms whole, 1.10 in two chunks, 1.22 in four, 1.77 in eight: the merge's
     // workgroups (16 waves and most of a CU's LDS each) displace more of k_tile than their waiting hides.  So the default is one chunk.
     static const int chunks_env = CK_KNOB("CK_SEG_CHUNKS", 0);
-    int chunks = chunks_env > 0 ? chunks_env : 1;
+    // (not together with CK_STREAMS=2: the views of a split batch share the handle's one side stream and its events)
+    int chunks = chunks_env > 0 && ck_streams_wanted() < 2 ? chunks_env : 1;
     if (chunks > CK_SEG_CHUNKS_MAX) chunks = CK_SEG_CHUNKS_MAX;
     const int per = ((n + chunks - 1) / chunks + 7) & ~7;
     const int cap_env = CK_KNOB("CK_FMERGE_CAP", 0); // the path-forcing tests (diag build) force the global-memory path with a small value (read per call)

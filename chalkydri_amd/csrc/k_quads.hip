@@ -2477,7 +2477,8 @@ int ck_launch_fit_quads(ck_handle *h, const uint8_t *qframes, int qstride, size_
         if (wimg_aside) launch_wimg(h->fit_stream[1]); // (joined with the side streams before k_chunk)
     }
     static const int gk_env = CK_KNOB("CK_FIT_GK", 0); // (experiment: bit c set = class c keeps its keys in global memory: small LDS, more workgroups per CU)
-    const int gk_mask = ws.d_hscratch ? gk_env : 0;
+    // (not for a call whose classes run side by side: the classes with their keys in global memory index ONE scratch slice by workgroup)
+    const int gk_mask = ws.d_hscratch && !side_by_side ? gk_env : 0;
     static const int skip_mask = CK_KNOB("CK_FIT_SKIP", 0); // (diagnostics: bit c set = class c is not launched)
     // The split fit (k_seq per class -> k_chunk over all positions -> k_tail over all clusters): CK_FIT_FLAT = 0 never, 2 always,
     // 1 (default): for calls that run their classes one after the other AND bring enough pixels — its three stages each ramp a
